@@ -1,0 +1,65 @@
+"""ctypes binding of the gfx950 C-ABI library (include/butd_pointnet2.h).
+
+The product path has NO CPU fallback: if ``libbutd_detr_hip.so`` is missing or a symbol the headers
+declare is absent, importing/using the ops raises immediately.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbutd_detr_hip.so")
+
+_c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol the headers under include/ declare.
+POINTNET2_SYMBOLS = {
+    "butd_pointnet2_abi_version": (_c_int, []),
+    "butd_error_string": (ctypes.c_char_p, [_c_int]),
+    "butd_opt_n_threads": (_c_int, [_c_int]),
+    "butd_furthest_point_sampling": (_c_int, [_c_int] * 3 + [_c_void_p] * 4),
+    "butd_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
+    "butd_furthest_point_sampling_ws": (_c_int, [_c_int] * 3 + [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
+    "butd_gather_points": (_c_int, [_c_int] * 4 + [_c_void_p] * 4),
+    "butd_gather_points_grad": (_c_int, [_c_int] * 4 + [_c_void_p] * 4),
+    "butd_ball_query": (_c_int, [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 4),
+    "butd_group_points": (_c_int, [_c_int] * 5 + [_c_void_p] * 4),
+    "butd_group_points_grad": (_c_int, [_c_int] * 5 + [_c_void_p] * 4),
+    "butd_three_nn": (_c_int, [_c_int] * 3 + [_c_void_p] * 5),
+    "butd_three_interpolate": (_c_int, [_c_int] * 4 + [_c_void_p] * 5),
+    "butd_three_interpolate_grad": (_c_int, [_c_int] * 4 + [_c_void_p] * 5),
+}
+
+ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every declared entry point (loudly)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m butd_detr_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the product path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in ALL_SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryMissing(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(err, what):
+    if err != 0:
+        msg = load().butd_error_string(err)
+        raise RuntimeError(f"{what}: HIP error {err} ({msg.decode() if msg else '?'})")

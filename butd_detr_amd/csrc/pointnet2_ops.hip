@@ -1,0 +1,615 @@
+// pointnet2_ops.hip -- gfx950 (MI355X, CDNA4) kernels behind include/butd_pointnet2.h.
+//
+// Written for 64-lane wavefronts / 256 CUs; NOT a translation of the reference's
+// one-block-per-scene CUDA kernels (pointnet2/_ext_src/src/*.cu).  What is kept from the
+// reference is the arithmetic contract only: fp32, the expression order of the .cu sources,
+// one rounding per operation -- this TU is compiled with -ffp-contract=off so hipcc does not
+// fuse a*a+b*b into v_fma_f32 (which would change low bits and hence indices).
+//
+// Kernels
+//   fps_kernel<PPT, XYZ_IN_REGS>  furthest point sampling, one 1024-thread workgroup per scene,
+//                                 running min-distance kept in VGPRs, one barrier per iteration.
+//   ball_query_kernel<C>          C centres per wave (state in SGPRs), 64 points per step (one per
+//                                 lane, coalesced), v_cmp mask + popcount = ordered compaction.
+//   gather/group/interpolate      bandwidth kernels, coalesced on the index/output side.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/butd_pointnet2.h"
+
+namespace {
+
+constexpr int kWave = 64;
+
+__host__ __device__ inline int ilog2_floor(unsigned v) {
+  int r = 0;
+  while (v >>= 1) ++r;
+  return r;
+}
+
+// ----------------------------------------------------------------------------------------------
+// FPS
+// ----------------------------------------------------------------------------------------------
+// The reference block (sampling_gpu.cu:74-178) has `bs = opt_n_threads(n)` threads; thread t owns the
+// points k == t (mod bs), keeps its first strict maximum, and a shared-memory tree then prefers the
+// LOWER slot on ties, level by level from stride bs/2 down to 1.  Net effect ("FPS tie
+// rule"): among equal maxima the winner has the smallest bit-reversed slot (k mod bs), then the
+// smallest k.  That is a total order, so any reduction shape gives the reference's answer as long as
+// it maximises   (d2, -bitrev(k mod bs), -k).   We pack it into one u64 and take an integer max:
+//     hi 32 = float bits of d2 (d2 >= 0, so the bit pattern is monotone), lo 32 = ~key(k).
+// "No candidate" (every point of a thread skipped: best = -1, besti = 0 in the reference) packs to 0
+// and decodes to index 0.
+constexpr int kFpsThreads = 1024;
+constexpr int kFpsWaves = kFpsThreads / kWave;
+
+__device__ inline unsigned fps_key(unsigned k, int log2bs) {
+  const unsigned slot = k & ((1u << log2bs) - 1u);
+  const unsigned rev = log2bs ? (__brev(slot) >> (32 - log2bs)) : 0u;
+  return (rev << 23) | (k >> log2bs);
+}
+__device__ inline unsigned fps_unkey(unsigned key, int log2bs) {
+  const unsigned rev = key >> 23;
+  const unsigned slot = log2bs ? (__brev(rev) >> (32 - log2bs)) : 0u;
+  return ((key & 0x7FFFFFu) << log2bs) | slot;
+}
+
+__device__ inline unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+  lo = __shfl_xor(lo, mask, kWave);
+  hi = __shfl_xor(hi, mask, kWave);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const unsigned long long o = shfl_xor_u64(v, s);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+struct alignas(16) FpsSlot {
+  unsigned long long packed;
+  float x, y, z;
+  float pad[3];
+};
+
+// mag <= 1e-3 is a DOUBLE compare in the reference (sampling_gpu.cu:106): float32(1e-3) > 1e-3, so in
+// fp32 terms the skip condition is mag < float32(1e-3).
+__device__ inline bool fps_skipped(float x, float y, float z) {
+  const float mag = (x * x) + (y * y) + (z * z);
+  return (double)mag <= 1e-3;
+}
+
+template <int PPT, bool XYZ_IN_REGS>
+__global__ __launch_bounds__(kFpsThreads) void fps_kernel(int n, int m, int log2bs,
+                                                          const float *__restrict__ dataset,
+                                                          int *__restrict__ idxs) {
+  __shared__ FpsSlot slots[2][kFpsWaves];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  int *out = idxs + (size_t)blockIdx.x * m;
+
+  // running min distance per owned point; -1 marks "never competes" (skipped or out of range):
+  // min(d, -1) = -1 and -1 > best(-1) is false, exactly like `continue` in the reference.
+  float t[PPT];
+  float px[XYZ_IN_REGS ? PPT : 1], py[XYZ_IN_REGS ? PPT : 1], pz[XYZ_IN_REGS ? PPT : 1];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int k = tid + i * kFpsThreads;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (k < n) {
+      x = pts[k * 3 + 0];
+      y = pts[k * 3 + 1];
+      z = pts[k * 3 + 2];
+    }
+    t[i] = (k < n && !fps_skipped(x, y, z)) ? 1e10f : -1.0f;
+    if (XYZ_IN_REGS) {
+      px[i] = x;
+      py[i] = y;
+      pz[i] = z;
+    }
+  }
+  const float p0x = pts[0], p0y = pts[1], p0z = pts[2];
+  float x1 = p0x, y1 = p0y, z1 = p0z;
+  if (tid == 0) out[0] = 0;
+
+  for (int j = 1; j < m; ++j) {
+    float best = -1.0f;
+    int besti = 0;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int k = tid + i * kFpsThreads;
+      float x2, y2, z2;
+      if (XYZ_IN_REGS) {
+        x2 = px[i];
+        y2 = py[i];
+        z2 = pz[i];
+      } else {
+        const int kk = k < n ? k : 0;
+        x2 = pts[kk * 3 + 0];
+        y2 = pts[kk * 3 + 1];
+        z2 = pts[kk * 3 + 2];
+      }
+      const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+      const float d2 = fminf(d, t[i]);
+      t[i] = d2;
+      const bool better = d2 > best;
+      besti = better ? k : besti;
+      bx = better ? x2 : bx;
+      by = better ? y2 : by;
+      bz = better ? z2 : bz;
+      best = better ? d2 : best;
+    }
+    unsigned long long mine = 0ull;
+    if (best >= 0.0f)
+      mine = ((unsigned long long)__float_as_uint(best) << 32) |
+             (unsigned long long)(0xFFFFFFFFu - fps_key((unsigned)besti, log2bs));
+    const unsigned long long wbest = wave_max_u64(mine);
+    FpsSlot *buf = slots[j & 1];
+    if (mine == wbest && (wbest != 0ull || lane == 0)) {
+      buf[wave].packed = wbest;
+      buf[wave].x = bx;
+      buf[wave].y = by;
+      buf[wave].z = bz;
+    }
+    __syncthreads();
+    // every wave reduces the 16 wave winners redundantly: no second barrier for the broadcast
+    unsigned long long cand = lane < kFpsWaves ? buf[lane].packed : 0ull;
+    unsigned long long gbest = cand;
+#pragma unroll
+    for (int s = kFpsWaves / 2; s >= 1; s >>= 1) {
+      const unsigned long long o = shfl_xor_u64(gbest, s);
+      gbest = o > gbest ? o : gbest;
+    }
+    gbest = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(gbest >> 32)) << 32) |
+            (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)gbest);
+    int old = 0;
+    if (gbest != 0ull) {
+      const unsigned long long hit = __ballot(cand == gbest);
+      const int w = __ffsll((long long)hit) - 1;
+      x1 = buf[w].x;
+      y1 = buf[w].y;
+      z1 = buf[w].z;
+      old = (int)fps_unkey(0xFFFFFFFFu - (unsigned)gbest, log2bs);
+    } else {
+      x1 = p0x;
+      y1 = p0y;
+      z1 = p0z;
+    }
+    if (tid == 0) out[j] = old;
+  }
+}
+
+// Generic fallback for clouds too large for the register-resident kernel (n > 64K points): running
+// min distances live in the caller's `temp` scratch.
+__global__ __launch_bounds__(kFpsThreads) void fps_kernel_global(int n, int m, int log2bs,
+                                                                 const float *__restrict__ dataset,
+                                                                 float *__restrict__ temp,
+                                                                 int *__restrict__ idxs) {
+  __shared__ FpsSlot slots[2][kFpsWaves];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = tid >> 6;
+  const float *pts = dataset + (size_t)blockIdx.x * n * 3;
+  float *tmp = temp + (size_t)blockIdx.x * n;
+  int *out = idxs + (size_t)blockIdx.x * m;
+  for (int k = tid; k < n; k += kFpsThreads)
+    tmp[k] = fps_skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
+  const float p0x = pts[0], p0y = pts[1], p0z = pts[2];
+  float x1 = p0x, y1 = p0y, z1 = p0z;
+  if (tid == 0) out[0] = 0;
+  for (int j = 1; j < m; ++j) {
+    float best = -1.0f;
+    int besti = 0;
+    float bx = 0.f, by = 0.f, bz = 0.f;
+    for (int k = tid; k < n; k += kFpsThreads) {
+      const float x2 = pts[k * 3 + 0], y2 = pts[k * 3 + 1], z2 = pts[k * 3 + 2];
+      const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+      const float d2 = fminf(d, tmp[k]);
+      tmp[k] = d2;
+      const bool better = d2 > best;
+      besti = better ? k : besti;
+      bx = better ? x2 : bx;
+      by = better ? y2 : by;
+      bz = better ? z2 : bz;
+      best = better ? d2 : best;
+    }
+    unsigned long long mine = 0ull;
+    if (best >= 0.0f)
+      mine = ((unsigned long long)__float_as_uint(best) << 32) |
+             (unsigned long long)(0xFFFFFFFFu - fps_key((unsigned)besti, log2bs));
+    const unsigned long long wbest = wave_max_u64(mine);
+    FpsSlot *buf = slots[j & 1];
+    if (mine == wbest && (wbest != 0ull || lane == 0)) {
+      buf[wave].packed = wbest;
+      buf[wave].x = bx;
+      buf[wave].y = by;
+      buf[wave].z = bz;
+    }
+    __syncthreads();
+    unsigned long long cand = lane < kFpsWaves ? buf[lane].packed : 0ull;
+    unsigned long long gbest = cand;
+#pragma unroll
+    for (int s = kFpsWaves / 2; s >= 1; s >>= 1) {
+      const unsigned long long o = shfl_xor_u64(gbest, s);
+      gbest = o > gbest ? o : gbest;
+    }
+    gbest = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(gbest >> 32)) << 32) |
+            (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)gbest);
+    int old = 0;
+    if (gbest != 0ull) {
+      const unsigned long long hit = __ballot(cand == gbest);
+      const int w = __ffsll((long long)hit) - 1;
+      x1 = buf[w].x;
+      y1 = buf[w].y;
+      z1 = buf[w].z;
+      old = (int)fps_unkey(0xFFFFFFFFu - (unsigned)gbest, log2bs);
+    } else {
+      x1 = p0x;
+      y1 = p0y;
+      z1 = p0z;
+    }
+    if (tid == 0) out[j] = old;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Ball query
+// ----------------------------------------------------------------------------------------------
+// One wave owns C consecutive centres.  Centre coordinates, hit counters and first-hit indices are
+// wave-uniform (SGPRs); the wave walks the cloud 64 points at a time -- lane l tests point k0+l, so
+// the v_cmp result IS the ordered hit mask: popcount(mask below my lane) is my output slot and the
+// "first nsample in ascending index" rule (ball_query_gpu.cu:32-47) needs no sort.  Each 64-point
+// tile is loaded once (coalesced 12 B/lane) and reused for all C centres, which divides the L2
+// traffic of the logical M*N*12-byte stream by C.  Rows are finished (padding with the first hit, or
+// zeros) by the same wave, so idx needs no memset.
+constexpr int kBqThreads = 256;
+
+template <int C>
+__global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, float radius2,
+                                                               int nsample, int waves_per_scene,
+                                                               const float *__restrict__ new_xyz,
+                                                               const float *__restrict__ xyz,
+                                                               int *__restrict__ idx) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int gw = blockIdx.x * (kBqThreads / kWave) + wave_in_block;  // wave-uniform
+  const int scene = gw / waves_per_scene;
+  const int j0 = (gw - scene * waves_per_scene) * C;
+  if (j0 >= m) return;
+  const float *pts = xyz + (size_t)scene * n * 3;
+  const float *ctr = new_xyz + (size_t)scene * m * 3;
+  int *out = idx + (size_t)scene * m * nsample;
+
+  float cx[C], cy[C], cz[C];
+  int cnt[C], first[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = (j0 + c) < m ? (j0 + c) : (m - 1);
+    cx[c] = ctr[j * 3 + 0];
+    cy[c] = ctr[j * 3 + 1];
+    cz[c] = ctr[j * 3 + 2];
+    cnt[c] = (j0 + c) < m ? 0 : nsample;  // out-of-range centres are born "full"
+    first[c] = 0;
+  }
+
+  const unsigned long long below = (1ull << lane) - 1ull;
+  for (int k0 = 0; k0 < n; k0 += kWave) {
+    const int k = k0 + lane;
+    const bool in = k < n;
+    const int kk = in ? k : (n - 1);
+    const float x = pts[kk * 3 + 0];
+    const float y = pts[kk * 3 + 1];
+    const float z = pts[kk * 3 + 2];
+    bool all_full = true;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      if (cnt[c] < nsample) {  // scalar branch
+        all_full = false;
+        const float d2 = (cx[c] - x) * (cx[c] - x) + (cy[c] - y) * (cy[c] - y) +
+                         (cz[c] - z) * (cz[c] - z);
+        const bool hit = in && (d2 < radius2);
+        const unsigned long long mask = __ballot(hit);
+        if (mask != 0ull) {
+          if (cnt[c] == 0) first[c] = k0 + __ffsll((long long)mask) - 1;
+          const int pos = cnt[c] + __popcll(mask & below);
+          if (hit && pos < nsample) out[(size_t)(j0 + c) * nsample + pos] = k;
+          cnt[c] += __popcll(mask);
+        }
+      }
+    }
+    if (all_full) break;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int j = j0 + c;
+    if (j < m) {
+      const int have = cnt[c] < nsample ? cnt[c] : nsample;
+      const int fill = cnt[c] > 0 ? first[c] : 0;
+      for (int l = have + lane; l < nsample; l += kWave) out[(size_t)j * nsample + l] = fill;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// gather / group / interpolate: bandwidth kernels.  One thread per output position, looping over a
+// chunk of channels so the index is read once and every store is coalesced.
+// ----------------------------------------------------------------------------------------------
+constexpr int kChanChunk = 16;
+
+// points (b,c,n), idx (b,P) -> out (b,c,P); serves gather_points (P = npoints) and group_points
+// (P = npoints*nsample): both are out[b,l,p] = points[b,l,idx[b,p]].
+__global__ __launch_bounds__(256) void index_select_kernel(int c, int n, int P,
+                                                           const float *__restrict__ points,
+                                                           const int *__restrict__ idx,
+                                                           float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int l0 = blockIdx.y * kChanChunk;
+  const int l1 = min(l0 + kChanChunk, c);
+  const float *src = points + (size_t)b * c * n;
+  float *dst = out + (size_t)b * c * P;
+  const int *ix = idx + (size_t)b * P;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const int a = ix[p];
+    for (int l = l0; l < l1; ++l) dst[(size_t)l * P + p] = src[(size_t)l * n + a];
+  }
+}
+
+__global__ __launch_bounds__(256) void index_scatter_add_kernel(int c, int n, int P,
+                                                                const float *__restrict__ grad_out,
+                                                                const int *__restrict__ idx,
+                                                                float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int l0 = blockIdx.y * kChanChunk;
+  const int l1 = min(l0 + kChanChunk, c);
+  const float *src = grad_out + (size_t)b * c * P;
+  float *dst = grad_points + (size_t)b * c * n;
+  const int *ix = idx + (size_t)b * P;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const int a = ix[p];
+    for (int l = l0; l < l1; ++l) atomicAdd(dst + (size_t)l * n + a, src[(size_t)l * P + p]);
+  }
+}
+
+// three_nn: one thread per unknown point; the (small) known set is staged through LDS in tiles and
+// read as wave-uniform broadcasts.  Float compares against a +inf sentinel are equivalent to the
+// reference's double best*=1e40 (interpolate_gpu.cu:32): every candidate is an fp32 value.
+constexpr int kNnTile = 1024;
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ unknown,
+                                                       const float *__restrict__ known,
+                                                       float *__restrict__ dist2,
+                                                       int *__restrict__ idx) {
+  __shared__ float kn[kNnTile * 3];
+  const int b = blockIdx.y;
+  const float *u = unknown + (size_t)b * n * 3;
+  const float *kp = known + (size_t)b * m * 3;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = j < n;
+  float ux = 0.f, uy = 0.f, uz = 0.f;
+  if (live) {
+    ux = u[j * 3 + 0];
+    uy = u[j * 3 + 1];
+    uz = u[j * 3 + 2];
+  }
+  float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
+  int besti1 = 0, besti2 = 0, besti3 = 0;
+  for (int k0 = 0; k0 < m; k0 += kNnTile) {
+    const int cnt = min(kNnTile, m - k0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt * 3; i += blockDim.x) kn[i] = kp[(size_t)k0 * 3 + i];
+    __syncthreads();
+    for (int kk = 0; kk < cnt; ++kk) {
+      const float x = kn[kk * 3 + 0], y = kn[kk * 3 + 1], z = kn[kk * 3 + 2];
+      const float d = (ux - x) * (ux - x) + (uy - y) * (uy - y) + (uz - z) * (uz - z);
+      const int k = k0 + kk;
+      if (d < best1) {
+        best3 = best2; besti3 = besti2;
+        best2 = best1; besti2 = besti1;
+        best1 = d; besti1 = k;
+      } else if (d < best2) {
+        best3 = best2; besti3 = besti2;
+        best2 = d; besti2 = k;
+      } else if (d < best3) {
+        best3 = d; besti3 = k;
+      }
+    }
+  }
+  if (live) {
+    float *od = dist2 + ((size_t)b * n + j) * 3;
+    int *oi = idx + ((size_t)b * n + j) * 3;
+    od[0] = best1; od[1] = best2; od[2] = best3;
+    oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+  }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int c, int m, int n,
+                                                                const float *__restrict__ points,
+                                                                const int *__restrict__ idx,
+                                                                const float *__restrict__ weight,
+                                                                float *__restrict__ out) {
+  const int b = blockIdx.z;
+  const int l0 = blockIdx.y * kChanChunk;
+  const int l1 = min(l0 + kChanChunk, c);
+  const float *src = points + (size_t)b * c * m;
+  float *dst = out + (size_t)b * c * n;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const size_t o = ((size_t)b * n + j) * 3;
+    const float w1 = weight[o + 0], w2 = weight[o + 1], w3 = weight[o + 2];
+    const int i1 = idx[o + 0], i2 = idx[o + 1], i3 = idx[o + 2];
+    for (int l = l0; l < l1; ++l) {
+      const float *p = src + (size_t)l * m;
+      dst[(size_t)l * n + j] = p[i1] * w1 + p[i2] * w2 + p[i3] * w3;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void three_interpolate_grad_kernel(
+    int c, int n, int m, const float *__restrict__ grad_out, const int *__restrict__ idx,
+    const float *__restrict__ weight, float *__restrict__ grad_points) {
+  const int b = blockIdx.z;
+  const int l0 = blockIdx.y * kChanChunk;
+  const int l1 = min(l0 + kChanChunk, c);
+  const float *src = grad_out + (size_t)b * c * n;
+  float *dst = grad_points + (size_t)b * c * m;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const size_t o = ((size_t)b * n + j) * 3;
+    const float w1 = weight[o + 0], w2 = weight[o + 1], w3 = weight[o + 2];
+    const int i1 = idx[o + 0], i2 = idx[o + 1], i3 = idx[o + 2];
+    for (int l = l0; l < l1; ++l) {
+      const float g = src[(size_t)l * n + j];
+      float *p = dst + (size_t)l * m;
+      atomicAdd(p + i1, g * w1);
+      atomicAdd(p + i2, g * w2);
+      atomicAdd(p + i3, g * w3);
+    }
+  }
+}
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+inline dim3 chan_grid(int P, int c, int b) {
+  int gx = (P + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  if (gx < 1) gx = 1;
+  return dim3(gx, (c + kChanChunk - 1) / kChanChunk, b);
+}
+
+}  // namespace
+
+extern "C" {
+
+int butd_pointnet2_abi_version(void) { return BUTD_POINTNET2_ABI_VERSION; }
+
+const char *butd_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+int butd_opt_n_threads(int work_size) {
+  const int pow_2 = (int)(std::log(static_cast<double>(work_size)) / std::log(2.0));
+  int t = 1 << pow_2;
+  if (t > 512) t = 512;
+  if (t < 1) t = 1;
+  return t;
+}
+
+size_t butd_fps_workspace_bytes(int, int) { return 0; }
+
+int butd_furthest_point_sampling_ws(int b, int n, int m, const float *dataset, float *temp,
+                                    int *idxs, void *, size_t, butd_stream_t stream) {
+  return butd_furthest_point_sampling(b, n, m, dataset, temp, idxs, stream);
+}
+
+int butd_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs,
+                                 butd_stream_t stream) {
+  if (b <= 0 || m <= 0) return 0;
+  if (n <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const int log2bs = ilog2_floor((unsigned)butd_opt_n_threads(n));
+  const int ppt = (n + kFpsThreads - 1) / kFpsThreads;
+#define FPS_LAUNCH(P, R) \
+  hipLaunchKernelGGL((fps_kernel<P, R>), dim3(b), dim3(kFpsThreads), 0, s, n, m, log2bs, dataset, idxs)
+  if (ppt <= 1) FPS_LAUNCH(1, true);
+  else if (ppt <= 2) FPS_LAUNCH(2, true);
+  else if (ppt <= 4) FPS_LAUNCH(4, true);
+  else if (ppt <= 8) FPS_LAUNCH(8, true);
+  else if (ppt <= 16) FPS_LAUNCH(16, false);
+  else {  // larger clouds: streaming kernel (the pruned path in fps_pruned.hip supersedes it)
+    if (temp == nullptr) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(fps_kernel_global, dim3(b), dim3(kFpsThreads), 0, s, n, m, log2bs, dataset,
+                       temp, idxs);
+  }
+#undef FPS_LAUNCH
+  return launch_status();
+}
+
+int butd_gather_points(int b, int c, int n, int npoints, const float *points, const int *idx,
+                       float *out, butd_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  hipLaunchKernelGGL(index_select_kernel, chan_grid(npoints, c, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, npoints, points, idx, out);
+  return launch_status();
+}
+
+int butd_gather_points_grad(int b, int c, int n, int npoints, const float *grad_out, const int *idx,
+                            float *grad_points, butd_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0) return 0;
+  hipLaunchKernelGGL(index_scatter_add_kernel, chan_grid(npoints, c, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, npoints, grad_out, idx, grad_points);
+  return launch_status();
+}
+
+int butd_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                    const float *xyz, int *idx, butd_stream_t stream) {
+  if (b <= 0 || m <= 0 || nsample <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (n <= 0) return (int)hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * m * nsample, s);
+  const float radius2 = radius * radius;  // ball_query_gpu.cu:27 (fp32 product)
+  // centres per wave: as many as keep >= ~2 waves per SIMD busy (1024 SIMDs), at most 8
+  const long long total = (long long)b * m;
+  int C = 8;
+  while (C > 1 && total / C < 2048) C >>= 1;
+#define BQ_LAUNCH(CC)                                                                          \
+  {                                                                                            \
+    const int wps = (m + CC - 1) / CC;                                                         \
+    const long long waves = (long long)wps * b;                                                \
+    const int blocks = (int)((waves + (kBqThreads / kWave) - 1) / (kBqThreads / kWave));       \
+    hipLaunchKernelGGL((ball_query_kernel<CC>), dim3(blocks), dim3(kBqThreads), 0, s, n, m,    \
+                       radius2, nsample, wps, new_xyz, xyz, idx);                              \
+  }
+  switch (C) {
+    case 8: BQ_LAUNCH(8) break;
+    case 4: BQ_LAUNCH(4) break;
+    case 2: BQ_LAUNCH(2) break;
+    default: BQ_LAUNCH(1) break;
+  }
+#undef BQ_LAUNCH
+  return launch_status();
+}
+
+int butd_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
+                      const int *idx, float *out, butd_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0 || nsample <= 0) return 0;
+  const int P = npoints * nsample;
+  hipLaunchKernelGGL(index_select_kernel, chan_grid(P, c, b), dim3(256), 0, (hipStream_t)stream, c,
+                     n, P, points, idx, out);
+  return launch_status();
+}
+
+int butd_group_points_grad(int b, int c, int n, int npoints, int nsample, const float *grad_out,
+                           const int *idx, float *grad_points, butd_stream_t stream) {
+  if (b <= 0 || c <= 0 || npoints <= 0 || nsample <= 0) return 0;
+  const int P = npoints * nsample;
+  hipLaunchKernelGGL(index_scatter_add_kernel, chan_grid(P, c, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, P, grad_out, idx, grad_points);
+  return launch_status();
+}
+
+int butd_three_nn(int b, int n, int m, const float *unknown, const float *known, float *dist2,
+                  int *idx, butd_stream_t stream) {
+  if (b <= 0 || n <= 0) return 0;
+  hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, (hipStream_t)stream, n,
+                     m, unknown, known, dist2, idx);
+  return launch_status();
+}
+
+int butd_three_interpolate(int b, int c, int m, int n, const float *points, const int *idx,
+                           const float *weight, float *out, butd_stream_t stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  hipLaunchKernelGGL(three_interpolate_kernel, chan_grid(n, c, b), dim3(256), 0,
+                     (hipStream_t)stream, c, m, n, points, idx, weight, out);
+  return launch_status();
+}
+
+int butd_three_interpolate_grad(int b, int c, int n, int m, const float *grad_out, const int *idx,
+                                const float *weight, float *grad_points, butd_stream_t stream) {
+  if (b <= 0 || c <= 0 || n <= 0) return 0;
+  hipLaunchKernelGGL(three_interpolate_grad_kernel, chan_grid(n, c, b), dim3(256), 0,
+                     (hipStream_t)stream, c, n, m, grad_out, idx, weight, grad_points);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,226 @@
+"""MI355X replacement for the reference's pybind module ``pointnet2._ext``.
+
+Same nine functions, same signatures, argument order and checks as
+pointnet2/_ext_src/src/bindings.cpp:11-24 and the C++ shims they bind
+(src/{sampling,ball_query,group_points,interpolate}.cpp):
+
+* tensors must be contiguous, fp32 data / int32 indices, all on one device; violations raise
+  ``RuntimeError`` with the reference's message text (include/utils.h:10-30);
+* outputs are allocated here on the input's device;
+* CPU tensors raise ``RuntimeError("CPU not supported")`` like every reference wrapper -- there is
+  no host fallback in the product path;
+* kernels are enqueued on the caller's current stream, no host synchronisation.
+
+The compute lives in the C-ABI library (include/butd_pointnet2.h); this file only validates,
+allocates and forwards raw pointers through ctypes.
+"""
+import torch
+
+from . import _hiplib
+
+
+def _check_contiguous(x, name):
+    if not x.is_contiguous():
+        raise RuntimeError(f"{name} must be a contiguous tensor")
+
+
+def _check_float(x, name):
+    if x.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be a float tensor")
+
+
+def _check_int(x, name):
+    if x.dtype != torch.int32:
+        raise RuntimeError(f"{name} must be an int tensor")
+
+
+def _check_same_device(ref, x, name):
+    if ref.is_cuda and not x.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor")
+    if ref.is_cuda and x.device != ref.device:
+        raise RuntimeError(f"{name} must be on {ref.device}")
+
+
+def _require_gpu(x):
+    if not x.is_cuda:
+        raise RuntimeError("CPU not supported")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _run(name, ref, *args):
+    lib = _hiplib.load()
+    with torch.cuda.device(ref.device):
+        err = getattr(lib, name)(*args, _stream(ref))
+    _hiplib.check(err, name)
+
+
+def furthest_point_sampling(points, nsamples):
+    """(B,N,3) f32 -> (B,nsamples) i32.  src/sampling.cpp:70-91."""
+    _check_contiguous(points, "points")
+    _check_float(points, "points")
+    nsamples = int(nsamples)
+    b, n = points.size(0), points.size(1)
+    _require_gpu(points)
+    output = torch.empty((b, nsamples), dtype=torch.int32, device=points.device)
+    lib = _hiplib.load()
+    ws_bytes = int(lib.butd_fps_workspace_bytes(b, n))
+    # scratch: the reference's (B,N) `tmp`; the library initialises what it uses
+    tmp = torch.empty((b, n), dtype=torch.float32, device=points.device)
+    if ws_bytes:
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device)
+        with torch.cuda.device(points.device):
+            err = lib.butd_furthest_point_sampling_ws(b, n, nsamples, points.data_ptr(), tmp.data_ptr(),
+                                                      output.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                      _stream(points))
+        _hiplib.check(err, "butd_furthest_point_sampling_ws")
+    else:
+        _run("butd_furthest_point_sampling", points, b, n, nsamples, points.data_ptr(),
+             tmp.data_ptr(), output.data_ptr())
+    return output
+
+
+def gather_points(points, idx):
+    """points (B,C,N) f32, idx (B,M) i32 -> (B,C,M).  src/sampling.cpp:20-44."""
+    _check_contiguous(points, "points")
+    _check_contiguous(idx, "idx")
+    _check_float(points, "points")
+    _check_int(idx, "idx")
+    _check_same_device(points, idx, "idx")
+    _require_gpu(points)
+    b, c, n = points.shape
+    m = idx.size(1)
+    output = torch.empty((b, c, m), dtype=torch.float32, device=points.device)
+    _run("butd_gather_points", points, b, c, n, m, points.data_ptr(), idx.data_ptr(),
+         output.data_ptr())
+    return output
+
+
+def gather_points_grad(grad_out, idx, n):
+    """grad_out (B,C,M), idx (B,M), n -> (B,C,n).  src/sampling.cpp:46-69."""
+    _check_contiguous(grad_out, "grad_out")
+    _check_contiguous(idx, "idx")
+    _check_float(grad_out, "grad_out")
+    _check_int(idx, "idx")
+    _check_same_device(grad_out, idx, "idx")
+    _require_gpu(grad_out)
+    b, c, m = grad_out.shape
+    n = int(n)
+    output = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+    _run("butd_gather_points_grad", grad_out, b, c, n, m, grad_out.data_ptr(), idx.data_ptr(),
+         output.data_ptr())
+    return output
+
+
+def ball_query(new_xyz, xyz, radius, nsample):
+    """new_xyz (B,M,3), xyz (B,N,3) -> (B,M,nsample) i32 (centres first!).  src/ball_query.cpp:13-37."""
+    _check_contiguous(new_xyz, "new_xyz")
+    _check_contiguous(xyz, "xyz")
+    _check_float(new_xyz, "new_xyz")
+    _check_float(xyz, "xyz")
+    _check_same_device(new_xyz, xyz, "xyz")
+    _require_gpu(new_xyz)
+    b, m = new_xyz.size(0), new_xyz.size(1)
+    n = xyz.size(1)
+    nsample = int(nsample)
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
+    _run("butd_ball_query", new_xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(),
+         xyz.data_ptr(), idx.data_ptr())
+    return idx
+
+
+def group_points(points, idx):
+    """points (B,C,N), idx (B,M,S) -> (B,C,M,S).  src/group_points.cpp:17-40."""
+    _check_contiguous(points, "points")
+    _check_contiguous(idx, "idx")
+    _check_float(points, "points")
+    _check_int(idx, "idx")
+    _check_same_device(points, idx, "idx")
+    _require_gpu(points)
+    b, c, n = points.shape
+    m, s = idx.size(1), idx.size(2)
+    output = torch.empty((b, c, m, s), dtype=torch.float32, device=points.device)
+    _run("butd_group_points", points, b, c, n, m, s, points.data_ptr(), idx.data_ptr(),
+         output.data_ptr())
+    return output
+
+
+def group_points_grad(grad_out, idx, n):
+    """grad_out (B,C,M,S), idx (B,M,S), n -> (B,C,n).  src/group_points.cpp:42-65."""
+    _check_contiguous(grad_out, "grad_out")
+    _check_contiguous(idx, "idx")
+    _check_float(grad_out, "grad_out")
+    _check_int(idx, "idx")
+    _check_same_device(grad_out, idx, "idx")
+    _require_gpu(grad_out)
+    b, c = grad_out.size(0), grad_out.size(1)
+    m, s = idx.size(1), idx.size(2)
+    n = int(n)
+    output = torch.zeros((b, c, n), dtype=torch.float32, device=grad_out.device)
+    _run("butd_group_points_grad", grad_out, b, c, n, m, s, grad_out.data_ptr(), idx.data_ptr(),
+         output.data_ptr())
+    return output
+
+
+def three_nn(unknowns, knows):
+    """unknown (B,n,3), known (B,m,3) -> [dist2 (B,n,3) f32, idx (B,n,3) i32].  src/interpolate.cpp:19-48."""
+    _check_contiguous(unknowns, "unknowns")
+    _check_contiguous(knows, "knows")
+    _check_float(unknowns, "unknowns")
+    _check_float(knows, "knows")
+    _check_same_device(unknowns, knows, "knows")
+    _require_gpu(unknowns)
+    b, n = unknowns.size(0), unknowns.size(1)
+    m = knows.size(1)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=unknowns.device)
+    dist2 = torch.empty((b, n, 3), dtype=torch.float32, device=unknowns.device)
+    _run("butd_three_nn", unknowns, b, n, m, unknowns.data_ptr(), knows.data_ptr(),
+         dist2.data_ptr(), idx.data_ptr())
+    return [dist2, idx]
+
+
+def three_interpolate(points, idx, weight):
+    """points (B,c,m), idx (B,n,3) i32, weight (B,n,3) -> (B,c,n).  src/interpolate.cpp:50-77."""
+    _check_contiguous(points, "points")
+    _check_contiguous(idx, "idx")
+    _check_contiguous(weight, "weight")
+    _check_float(points, "points")
+    _check_int(idx, "idx")
+    _check_float(weight, "weight")
+    _check_same_device(points, idx, "idx")
+    _check_same_device(points, weight, "weight")
+    _require_gpu(points)
+    b, c, m = points.shape
+    n = idx.size(1)
+    output = torch.empty((b, c, n), dtype=torch.float32, device=points.device)
+    _run("butd_three_interpolate", points, b, c, m, n, points.data_ptr(), idx.data_ptr(),
+         weight.data_ptr(), output.data_ptr())
+    return output
+
+
+def three_interpolate_grad(grad_out, idx, weight, m):
+    """grad_out (B,c,n), idx, weight, m -> (B,c,m).  src/interpolate.cpp:79-104."""
+    _check_contiguous(grad_out, "grad_out")
+    _check_contiguous(idx, "idx")
+    _check_contiguous(weight, "weight")
+    _check_float(grad_out, "grad_out")
+    _check_int(idx, "idx")
+    _check_float(weight, "weight")
+    _check_same_device(grad_out, idx, "idx")
+    _check_same_device(grad_out, weight, "weight")
+    _require_gpu(grad_out)
+    b, c, n = grad_out.shape
+    m = int(m)
+    output = torch.zeros((b, c, m), dtype=torch.float32, device=grad_out.device)
+    _run("butd_three_interpolate_grad", grad_out, b, c, n, m, grad_out.data_ptr(), idx.data_ptr(),
+         weight.data_ptr(), output.data_ptr())
+    return output
+
+
+__all__ = [
+    "gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
+    "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
+    "group_points_grad",
+]

@@ -1,0 +1,217 @@
+"""-m gpu: the gfx950 operator library vs the CPU oracle, through the C ABI (ctypes) -- bit-exact for
+indices and for the fp32 gathers; atomic scatter-adds within fp32 reassociation tolerance."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from butd_detr_amd.synthetic_scenes import scannet_like_scene, scene_batch, uniform_cloud  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ext():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from butd_detr_amd import pointnet2_ext
+    return pointnet2_ext
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------- FPS
+@pytest.mark.parametrize("n,m", [(1, 1), (7, 7), (64, 10), (100, 64), (512, 256), (513, 100),
+                                 (1024, 512), (2048, 1024), (4096, 300), (5000, 128),
+                                 (9000, 64), (20000, 96)])
+def test_fps_random_bit_exact(ext, oracle, n, m):
+    rng = np.random.default_rng(n * 31 + m)
+    pts = rng.uniform(-2, 2, size=(3, n, 3)).astype(np.float32)
+    if n > 10:
+        pts[0, 5] = pts[0, 3]
+        pts[1, n // 2] = 0.0
+        pts[2, : n // 3] = pts[2, 0]  # massive ties
+    got = ext.furthest_point_sampling(dev(pts), m).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.furthest_point_sampling(pts, m))
+
+
+def test_fps_all_points_skipped(ext, oracle):
+    pts = np.full((2, 300, 3), 0.001, dtype=np.float32)  # |p|^2 = 3e-6 <= 1e-3 everywhere
+    got = ext.furthest_point_sampling(dev(pts), 20).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.furthest_point_sampling(pts, 20))
+    assert (got == 0).all()
+
+
+def test_fps_known_answers(ext):
+    pts = np.zeros((1, 9, 3), dtype=np.float32)
+    pts[0, :, 0] = np.arange(1, 10)
+    pts[0, :, 1] = 1.0
+    assert ext.furthest_point_sampling(dev(pts), 5).cpu().numpy()[0].tolist() == [0, 8, 4, 2, 6]
+    n = 1024
+    pts = np.ones((1, n, 3), dtype=np.float32)
+    pts[0, 0] = [3.0, 1.0, 1.0]
+    assert ext.furthest_point_sampling(dev(pts), 2).cpu().numpy()[0].tolist() == [0, 512]
+    pts[0, 512] = pts[0, 0]
+    assert ext.furthest_point_sampling(dev(pts), 2).cpu().numpy()[0].tolist() == [0, 256]
+
+
+def test_fps_config2_scene_four_levels(ext, oracle):
+    """BASELINE config 2: 50k-point ScanNet-shaped scene, the four SA levels' FPS, bit-exact."""
+    pc = scannet_like_scene(1184, 50000)[None, :, :3]
+    xyz = np.ascontiguousarray(pc)
+    for npoint in (2048, 1024, 512, 256):
+        ref = oracle.furthest_point_sampling(xyz, npoint, multithread=True)
+        got = ext.furthest_point_sampling(dev(xyz), npoint).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+        xyz = np.ascontiguousarray(np.take_along_axis(xyz, ref[..., None].astype(np.int64), 1))
+
+
+def test_fps_batch8_matches_oracle_and_is_permutation_free(ext, oracle):
+    pcs = scene_batch(8, 1184, 50000)[..., :3]
+    pcs = np.ascontiguousarray(pcs)
+    got = ext.furthest_point_sampling(dev(pcs), 2048).cpu().numpy()
+    # size-independent properties: starts at 0, no index repeated unless the cloud has duplicates
+    assert (got[:, 0] == 0).all()
+    assert got.min() >= 0 and got.max() < 50000
+    ref = oracle.furthest_point_sampling(pcs[:2], 2048, multithread=True)
+    np.testing.assert_array_equal(got[:2], ref)
+    # min-distance of successive samples is non-increasing (defining property of FPS)
+    sel = np.take_along_axis(pcs[2], got[2][:, None].astype(np.int64), 0).astype(np.float64)
+    dmin = np.full(50000, np.inf)
+    prev = np.inf
+    for j in range(1, 200):
+        dmin = np.minimum(dmin, ((pcs[2].astype(np.float64) - sel[j - 1]) ** 2).sum(-1))
+        dj = dmin[got[2, j]]
+        assert dj <= prev * (1 + 1e-5)
+        prev = dj
+
+
+# ---------------------------------------------------------------- ball query
+@pytest.mark.parametrize("n,m,ns,r", [(1, 1, 4, 0.5), (63, 5, 8, 0.5), (64, 64, 16, 0.3),
+                                      (65, 7, 64, 0.4), (1000, 100, 32, 0.2), (2048, 1024, 32, 0.4),
+                                      (5000, 333, 100, 0.5), (3000, 10, 3, 5.0)])
+def test_ball_query_random_bit_exact(ext, oracle, n, m, ns, r):
+    rng = np.random.default_rng(n + m + ns)
+    xyz = rng.uniform(-1, 1, size=(2, n, 3)).astype(np.float32)
+    new_xyz = np.ascontiguousarray(xyz[:, rng.integers(0, n, size=m)])
+    new_xyz[0, 0] = [50, 50, 50]
+    got = ext.ball_query(dev(new_xyz), dev(xyz), r, ns).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.ball_query(new_xyz, xyz, r, ns))
+
+
+def test_ball_query_known_answers(ext):
+    xyz = np.zeros((1, 8, 3), dtype=np.float32)
+    xyz[0, :, 0] = [0.0, 0.5, 1.0, 1.5, 2.0, 2.5, 3.0, 10.0]
+    centres = np.array([[[100, 0, 0], [10.0, 0, 0], [1.0, 0, 0], [1.5, 0, 0]]], dtype=np.float32)
+    got = ext.ball_query(dev(centres), dev(xyz), 1.0, 4).cpu().numpy()[0]
+    assert got.tolist() == [[0, 0, 0, 0], [7, 7, 7, 7], [1, 2, 3, 1], [2, 3, 4, 2]]
+
+
+def test_ball_query_config2_four_levels(ext, oracle):
+    pc = scannet_like_scene(1184, 50000)[None, :, :3]
+    xyz = np.ascontiguousarray(pc)
+    for npoint, r, ns in ((2048, 0.2, 64), (1024, 0.4, 32), (512, 0.8, 16), (256, 1.2, 16)):
+        inds = oracle.furthest_point_sampling(xyz, npoint, multithread=True)
+        new_xyz = np.ascontiguousarray(np.take_along_axis(xyz, inds[..., None].astype(np.int64), 1))
+        ref = oracle.ball_query(new_xyz, xyz, r, ns)
+        got = ext.ball_query(dev(new_xyz), dev(xyz), r, ns).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+        xyz = new_xyz
+
+
+def test_ball_query_batch8_properties(ext, oracle):
+    pcs = np.ascontiguousarray(scene_batch(8, 1184, 50000)[..., :3])
+    d = dev(pcs)
+    inds = ext.furthest_point_sampling(d, 2048)
+    new_xyz = torch.gather(d, 1, inds.long()[..., None].expand(-1, -1, 3)).contiguous()
+    got = ext.ball_query(new_xyz, d, 0.2, 64)
+    # every returned point is inside the ball (or the row is the all-zero "no hit" row), rows ascend
+    # until the padding starts, padding repeats the first element
+    g = got.long()
+    pts = torch.gather(d[:, None].expand(-1, 2048, -1, -1), 2, g[..., None].expand(-1, -1, -1, 3))
+    d2 = ((pts - new_xyz[:, :, None]) ** 2).sum(-1)
+    first_in = d2[..., 0] < 0.2 * 0.2 * (1 + 1e-5)
+    assert bool(((d2 < 0.2 * 0.2 * (1 + 1e-5)) | ~first_in[..., None]).all())
+    ref = oracle.ball_query(new_xyz[:2].cpu().numpy(), pcs[:2], 0.2, 64)
+    np.testing.assert_array_equal(got[:2].cpu().numpy(), ref)
+
+
+# ---------------------------------------------------------------- gather / group / interpolate
+def test_gather_and_group_bit_exact(ext, oracle):
+    rng = np.random.default_rng(0)
+    for (b, c, n, m, s) in [(2, 3, 500, 64, 8), (1, 131, 2048, 1024, 32), (3, 17, 70, 5, 1)]:
+        pts = rng.normal(size=(b, c, n)).astype(np.float32)
+        idx = rng.integers(0, n, size=(b, m)).astype(np.int32)
+        np.testing.assert_array_equal(ext.gather_points(dev(pts), dev(idx)).cpu().numpy(),
+                                      oracle.gather_points(pts, idx))
+        gidx = rng.integers(0, n, size=(b, m, s)).astype(np.int32)
+        np.testing.assert_array_equal(ext.group_points(dev(pts), dev(gidx)).cpu().numpy(),
+                                      oracle.group_points(pts, gidx))
+        g = rng.normal(size=(b, c, m, s)).astype(np.float32)
+        np.testing.assert_allclose(ext.group_points_grad(dev(g), dev(gidx), n).cpu().numpy(),
+                                   oracle.group_points_grad(g, gidx, n), rtol=1e-4, atol=1e-4)
+        g1 = rng.normal(size=(b, c, m)).astype(np.float32)
+        np.testing.assert_allclose(ext.gather_points_grad(dev(g1), dev(idx), n).cpu().numpy(),
+                                   oracle.gather_points_grad(g1, idx, n), rtol=1e-4, atol=1e-4)
+
+
+def test_three_nn_and_interpolate(ext, oracle):
+    rng = np.random.default_rng(1)
+    for (b, n, m, c) in [(2, 512, 256, 256), (1, 1024, 512, 64), (2, 33, 3, 5), (1, 10, 2, 4),
+                         (1, 300, 1500, 8)]:
+        unknown = rng.uniform(-1, 1, size=(b, n, 3)).astype(np.float32)
+        known = rng.uniform(-1, 1, size=(b, m, 3)).astype(np.float32)
+        if m >= 3:
+            known[0, 2] = known[0, 0]
+        d_ref, i_ref = oracle.three_nn(unknown, known)
+        d_got, i_got = ext.three_nn(dev(unknown), dev(known))
+        np.testing.assert_array_equal(i_got.cpu().numpy(), i_ref)
+        np.testing.assert_array_equal(d_got.cpu().numpy(), d_ref)
+        feats = rng.normal(size=(b, c, m)).astype(np.float32)
+        w = rng.random((b, n, 3)).astype(np.float32)
+        out = ext.three_interpolate(dev(feats), dev(i_ref), dev(w)).cpu().numpy()
+        np.testing.assert_array_equal(out, oracle.three_interpolate(feats, i_ref, w))
+        g = rng.normal(size=(b, c, n)).astype(np.float32)
+        gg = ext.three_interpolate_grad(dev(g), dev(i_ref), dev(w), m).cpu().numpy()
+        np.testing.assert_allclose(gg, oracle.three_interpolate_grad(g, i_ref, w, m),
+                                   rtol=1e-4, atol=1e-4)
+
+
+def test_three_interpolate_gradcheck_reference_case():
+    """Port of the reference's only test (pointnet2/pointnet2_test.py:18-30) to the Function API."""
+    from torch.autograd import gradcheck
+    from butd_detr_amd import pointnet2_utils
+    feats = torch.randn(1, 2, 4).float().cuda().requires_grad_(True)
+
+    def f(inputs):
+        idx = torch.tensor([[[0, 1, 2], [1, 2, 3]]], dtype=torch.int32).cuda()
+        weight = torch.tensor([[[1, 1, 1], [2, 2, 2]]], dtype=torch.float32).cuda()
+        return pointnet2_utils.three_interpolate(inputs, idx, weight)
+
+    assert gradcheck(f, feats, atol=1e-1, rtol=1e-1)
+
+
+# ---------------------------------------------------------------- error behaviour
+def test_argument_checks_raise_runtimeerror(ext):
+    x = torch.zeros(1, 8, 3, device="cuda")
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ext.furthest_point_sampling(x.transpose(1, 2), 2)
+    with pytest.raises(RuntimeError, match="float tensor"):
+        ext.furthest_point_sampling(x.double(), 2)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        ext.gather_points(x, torch.zeros(1, 2, dtype=torch.int64, device="cuda"))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ext.gather_points(x, torch.zeros(1, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        ext.furthest_point_sampling(torch.zeros(1, 8, 3), 2)
+
+
+def test_stream_and_graph_capture(ext, oracle):
+    """Launches go to the caller's current stream and are capturable (no sync, no malloc inside)."""
+    pts = uniform_cloud(0, 4096)[..., :3].copy()
+    d = dev(pts)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        a = ext.furthest_point_sampling(d, 128)
+    s.synchronize()
+    np.testing.assert_array_equal(a.cpu().numpy(), oracle.furthest_point_sampling(pts, 128))
