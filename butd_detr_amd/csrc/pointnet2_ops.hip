@@ -70,6 +70,13 @@ __device__ inline unsigned long long wave_max_u64(unsigned long long v) {
   return v;
 }
 
+// wave-uniform copy of lane 0's value (readfirstlane returns a signed int: cast before widening)
+__device__ inline unsigned long long uniform_u64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
+}
+
 struct alignas(16) FpsSlot {
   unsigned long long packed;
   float x, y, z;
@@ -167,8 +174,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(int n, int m, int log2
       const unsigned long long o = shfl_xor_u64(gbest, s);
       gbest = o > gbest ? o : gbest;
     }
-    gbest = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(gbest >> 32)) << 32) |
-            (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)gbest);
+    gbest = uniform_u64(gbest);
     int old = 0;
     if (gbest != 0ull) {
       const unsigned long long hit = __ballot(cand == gbest);
@@ -240,8 +246,7 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel_global(int n, int m, i
       const unsigned long long o = shfl_xor_u64(gbest, s);
       gbest = o > gbest ? o : gbest;
     }
-    gbest = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(gbest >> 32)) << 32) |
-            (unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)gbest);
+    gbest = uniform_u64(gbest);
     int old = 0;
     if (gbest != 0ull) {
       const unsigned long long hit = __ballot(cand == gbest);
