@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- scenes/sec fwd+bwd of the BUTD-DETR hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = forward + surrogate loss + backward + grad-clip + AdamW update of ``BeaUTyDETR`` on one
+synthetic batch per GPU (``--batch`` scenes of 50 000 points, 256 queries, 80 tokens, 132 box slots;
+BASELINE configs[2]/[3]: 8 scenes per GPU, weak scaling), inputs resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line with the throughput, the roofline of the dominant hand-written
+kernel (HIP-event timed on its own stream) and, at N=1, a CPU baseline (oracle ops + torch CPU fp32
+on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+FP32_MATRIX_PEAK_TF = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
+    ap.add_argument("--points", type=int, default=50000)
+    ap.add_argument("--queries", type=int, default=256)
+    ap.add_argument("--tokens", type=int, default=80)
+    ap.add_argument("--backend", default=os.environ.get("BUTD_ATTENTION_BACKEND", "auto"),
+                    choices=["auto", "torch", "hip"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-scenes", type=int, default=1)
+    return ap.parse_args()
+
+
+def build_model(args, device):
+    import warnings
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from butd_detr_amd.offline_text import offline_factory
+    backend = args.backend
+    if backend == "auto":
+        try:
+            attention_blocks.set_backend("hip")
+            backend = "hip"
+        except Exception:
+            attention_blocks.set_backend("torch")
+            backend = "torch"
+    else:
+        attention_blocks.set_backend(backend)
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3,
+                           num_queries=args.queries, num_decoder_layers=6,
+                           self_position_embedding="loc_learned", contrastive_align_loss=True,
+                           butd=True, self_attend=True, text_encoder_factory=offline_factory(0))
+    return model.to(device).train(), backend
+
+
+def ball_query_roofline(inputs, steps=20):
+    """SA1 ball query (M=2048 centres x N points, ns=64): algorithmic bytes = M*N*12 + M*ns*4 + M*12
+    per scene; duration from HIP events on the launch stream."""
+    from butd_detr_amd import pointnet2_ext as ext
+    xyz = inputs["point_clouds"][..., :3].contiguous()
+    b, n = xyz.shape[0], xyz.shape[1]
+    inds = ext.furthest_point_sampling(xyz, 2048)
+    new_xyz = torch.gather(xyz, 1, inds.long()[..., None].expand(-1, -1, 3)).contiguous()
+    for _ in range(3):
+        ext.ball_query(new_xyz, xyz, 0.2, 64)
+    stream = torch.cuda.current_stream()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(steps)]
+    for s, e in evs:
+        s.record(stream)
+        ext.ball_query(new_xyz, xyz, 0.2, 64)
+        e.record(stream)
+    torch.cuda.synchronize()
+    ms = sum(s.elapsed_time(e) for s, e in evs) / steps
+    alg_bytes = b * (2048 * n * 12 + 2048 * 64 * 4 + 2048 * 12)
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {"kernel": "ball_query_kernel (SA1: 2048 centres x %d points, nsample 64, B=%d)" % (n, b),
+            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "avg_launch_ms": round(ms, 5), "algorithmic_bytes_per_launch": alg_bytes}
+
+
+def cpu_baseline(args, scenes):
+    """Reference-shaped CPU path: this repo's host modules + the oracle's C operators (the reference
+    has no CPU operators of its own) + torch CPU fp32, all host cores; bounded sample."""
+    from butd_detr_amd import attention_blocks, pointnet2_utils
+    from butd_detr_amd.train_step import make_optimizer, synthetic_batch, train_step
+    from oracle import ext_adapter
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    prev_ext, prev_backend = pointnet2_utils._ext, attention_blocks.get_backend()
+    pointnet2_utils._ext = ext_adapter          # cpu_baseline leg only: oracle as the timed CPU port
+    attention_blocks.set_backend("torch")
+    try:
+        ns = argparse.Namespace(**vars(args))
+        ns.backend = "torch"
+        model, _ = build_model(ns, torch.device("cpu"))
+        opt = make_optimizer(model)
+        inputs, targets = synthetic_batch(scenes, torch.device("cpu"), n_points=args.points,
+                                          tokens=args.tokens)
+        train_step(model, opt, inputs, targets)      # warm-up
+        t0 = time.perf_counter()
+        reps = 2
+        for _ in range(reps):
+            train_step(model, opt, inputs, targets)
+        dt = (time.perf_counter() - t0) / reps
+    finally:
+        pointnet2_utils._ext = prev_ext
+        attention_blocks.set_backend(prev_backend)
+    return {"value": round(scenes / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} timed fwd+bwd+optimizer steps of {scenes} scene(s) x {args.points} points "
+                      f"after 1 warm-up, oracle C ops (OpenMP) + torch CPU fp32"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from butd_detr_amd.train_step import (make_optimizer, synthetic_batch, train_step,
+                                          wrap_data_parallel)
+    model, backend = build_model(args, device)
+    ddp = wrap_data_parallel(model, device)
+    opt = make_optimizer(model)
+    inputs, targets = synthetic_batch(args.batch, device, n_points=args.points, tokens=args.tokens,
+                                      rank=rank)
+
+    for _ in range(args.warmup):
+        train_step(ddp, opt, inputs, targets)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(ddp, opt, inputs, targets)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        scenes = args.batch * world * args.steps
+        out = {
+            "metric": "scenes/sec fwd+bwd (50k pts, 256 queries, 80 tokens)",
+            "value": round(scenes / elapsed, 3), "unit": "scenes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[2]/[3]: {args.batch} scenes/GPU x {args.points} "
+                                   f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "
+                                   "3 encoder + 6 decoder layers, fwd+loss+bwd+clip+AdamW, train mode",
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "attention_backend": backend, "final_loss": round(float(loss), 4)},
+        }
+        out["roofline"] = ball_query_roofline(inputs)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""PointNet++ single-scale-grouping backbone of BUTD-DETR (models/backbone_module.py:35-153).
+
+Four set-abstraction levels (2048/0.2/64, 1024/0.4/32, 512/0.8/16, 256/1.2/16; all with
+``use_xyz`` and radius-normalised local xyz) and two feature-propagation levels back up to the
+1024 seed points; emits the ``sa{1..4}_*`` and ``fp2_*`` entries of ``end_points``.
+"""
+from torch import nn
+
+from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
+
+# (npoint, radius, nsample, hidden width, output width) per level -- backbone_module.py:53-87
+SA_LEVELS = ((2048, 0.2, 64, 64, 128), (1024, 0.4, 32, 128, 256),
+             (512, 0.8, 16, 128, 256), (256, 1.2, 16, 128, 256))
+
+
+class Pointnet2Backbone(nn.Module):
+    def __init__(self, input_feature_dim=0, width=1, depth=2, output_dim=288):
+        super().__init__()
+        self.depth, self.width = depth, width
+        c_in = input_feature_dim
+        for level, (npoint, radius, nsample, hidden, c_out) in enumerate(SA_LEVELS, start=1):
+            widths = [c_in] + [hidden * width] * depth + [c_out * width]
+            setattr(self, f"sa{level}", PointnetSAModuleVotes(
+                npoint=npoint, radius=radius, nsample=nsample, mlp=widths,
+                use_xyz=True, normalize_xyz=True))
+            c_in = c_out * width
+        self.fp1 = PointnetFPModule(mlp=[512 * width, 256 * width, 256 * width])
+        self.fp2 = PointnetFPModule(mlp=[512 * width, 256 * width, output_dim])
+
+    @staticmethod
+    def _break_up_pc(pc):
+        xyz = pc[..., 0:3].contiguous()
+        features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
+        return xyz, features
+
+    def forward(self, pointcloud, end_points=None):
+        """pointcloud (B, N, 3 + input_feature_dim) -> end_points dict."""
+        end_points = end_points if end_points else {}
+        xyz, features = self._break_up_pc(pointcloud)
+        for level in (1, 2, 3, 4):
+            xyz, features, inds = getattr(self, f"sa{level}")(xyz, features)
+            if level <= 2:  # the reference only records inds of the first two levels (:127,:132)
+                end_points[f"sa{level}_inds"] = inds
+            end_points[f"sa{level}_xyz"] = xyz
+            end_points[f"sa{level}_features"] = features
+        features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
+                            end_points["sa3_features"], end_points["sa4_features"])
+        features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
+                            end_points["sa2_features"], features)
+        end_points["fp2_features"] = features
+        end_points["fp2_xyz"] = end_points["sa2_xyz"]
+        num_seed = end_points["fp2_xyz"].shape[1]
+        # seeds are a prefix of the sa1 samples: indices into the full input cloud (:150-151)
+        end_points["fp2_inds"] = end_points["sa1_inds"][:, 0:num_seed]
+        return end_points

@@ -1,0 +1,208 @@
+"""BeaUTyDETR: the 3D language grounder, MI355X build (models/bdetr.py).
+
+Constructor kwargs are exactly the reference's (bdetr.py:46-52, as passed by
+train_dist_mod.py:88-99); ``forward(inputs) -> end_points`` consumes and produces the same dict
+keys; sub-module / parameter names equal the reference's so released
+checkpoints load with ``strict=True``.
+
+Differences that are deliberate and documented:
+* the text tower is built by ``text_encoder_factory`` (default: HF ``roberta-base`` via
+  ``from_pretrained`` like bdetr.py:73-75).  Offline boxes inject a random-init RoBERTa-shaped
+  encoder and a tokenizer stand-in; parameter names under ``text_encoder.*`` are unaffected.
+* ``data/class_embeddings3d.npy`` (bdetr.py:88-91, cwd-relative) is loaded when present; when it is
+  absent the embedding keeps its random init and a warning is emitted (a checkpoint overrides it).
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .backbone_module import Pointnet2Backbone
+from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer
+from .modules import (ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule,
+                      PositionEmbeddingLearned)
+
+
+def _hf_roberta_factory():
+    from transformers import RobertaModel, RobertaTokenizerFast
+    return (RobertaTokenizerFast.from_pretrained("roberta-base"),
+            RobertaModel.from_pretrained("roberta-base"))
+
+
+def _align_mlp(d_model):
+    return nn.Sequential(nn.Linear(d_model, d_model), nn.ReLU(),
+                         nn.Linear(d_model, d_model), nn.ReLU(), nn.Linear(d_model, 64))
+
+
+class BeaUTyDETR(nn.Module):
+    """See module docstring.  ``num_encoder_layers`` (default 3) exposes the depth the reference
+    hard-codes at bdetr.py:104."""
+
+    def __init__(self, num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=256,
+                 num_decoder_layers=6, self_position_embedding="loc_learned",
+                 contrastive_align_loss=True, d_model=288, butd=True, pointnet_ckpt=None,
+                 self_attend=True, *, text_encoder_factory=None, num_encoder_layers=3,
+                 class_embeddings_path="data/class_embeddings3d.npy"):
+        super().__init__()
+        self.num_queries = num_queries
+        self.num_decoder_layers = num_decoder_layers
+        self.self_position_embedding = self_position_embedding
+        self.contrastive_align_loss = contrastive_align_loss
+        self.butd = butd
+
+        # visual encoder
+        self.backbone_net = Pointnet2Backbone(input_feature_dim=input_feature_dim, width=1)
+        if input_feature_dim == 3 and pointnet_ckpt is not None:
+            self.backbone_net.load_state_dict(torch.load(pointnet_ckpt), strict=False)
+
+        # text encoder (frozen)
+        self.tokenizer, self.text_encoder = (text_encoder_factory or _hf_roberta_factory)()
+        for param in self.text_encoder.parameters():
+            param.requires_grad = False
+        self.text_projector = nn.Sequential(
+            nn.Linear(self.text_encoder.config.hidden_size, d_model),
+            nn.LayerNorm(d_model, eps=1e-12), nn.Dropout(0.1))
+
+        # detected-box stream
+        if self.butd:
+            self.butd_class_embeddings = nn.Embedding(num_obj_class, 768)
+            if class_embeddings_path and os.path.exists(class_embeddings_path):
+                saved = torch.from_numpy(np.load(class_embeddings_path, allow_pickle=True))
+                self.butd_class_embeddings.weight.data.copy_(saved)
+            else:
+                warnings.warn(f"{class_embeddings_path} not found: butd_class_embeddings keeps "
+                              "its random init until a checkpoint is loaded")
+            # NB the reference sets .requires_grad on the *module* (bdetr.py:92), which is a no-op:
+            # the embedding weight stays trainable and is part of the DDP all-reduce.
+            self.butd_class_embeddings.requires_grad = False
+            self.class_embeddings = nn.Linear(768, d_model - 128)
+            self.box_embeddings = PositionEmbeddingLearned(6, 128)
+
+        # cross-modal encoder
+        self.pos_embed = PositionEmbeddingLearned(3, d_model)
+        bi_layer = BiEncoderLayer(d_model, dropout=0.1, activation="relu", n_heads=8,
+                                  dim_feedforward=256, self_attend_lang=self_attend,
+                                  self_attend_vis=self_attend, use_butd_enc_attn=butd)
+        self.cross_encoder = BiEncoder(bi_layer, num_encoder_layers)
+
+        # query initialisation
+        self.points_obj_cls = PointsObjClsModule(d_model)
+        self.gsample_module = GeneralSamplingModule()
+        self.decoder_query_proj = nn.Conv1d(d_model, d_model, kernel_size=1)
+
+        def head():
+            return ClsAgnosticPredictHead(num_class, 1, num_queries, d_model, objectness=False,
+                                          heading=False, compute_sem_scores=True)
+
+        self.proposal_head = head()
+        self.decoder = nn.ModuleList(
+            BiDecoderLayer(d_model, n_heads=8, dim_feedforward=256, dropout=0.1, activation="relu",
+                           self_position_embedding=self_position_embedding, butd=self.butd)
+            for _ in range(num_decoder_layers))
+        self.prediction_heads = nn.ModuleList(head() for _ in range(num_decoder_layers))
+
+        if contrastive_align_loss:
+            self.contrastive_align_projection_image = _align_mlp(d_model)
+            self.contrastive_align_projection_text = _align_mlp(d_model)
+
+        self.init_bn_momentum()
+
+    # ------------------------------------------------------------------ backbones
+    def _run_backbones(self, inputs):
+        end_points = self.backbone_net(inputs["point_clouds"], end_points={})
+        end_points["seed_inds"] = end_points["fp2_inds"]
+        end_points["seed_xyz"] = end_points["fp2_xyz"]
+        end_points["seed_features"] = end_points["fp2_features"]
+        tokenized = self.tokenizer.batch_encode_plus(
+            inputs["text"], padding="longest", return_tensors="pt"
+        ).to(inputs["point_clouds"].device)
+        encoded_text = self.text_encoder(**tokenized)
+        end_points["text_feats"] = self.text_projector(encoded_text.last_hidden_state)
+        # HF masks are 1 = token; torch attention wants True = padding (bdetr.py:171)
+        end_points["text_attention_mask"] = tokenized.attention_mask.ne(1).bool()
+        end_points["tokenized"] = tokenized
+        return end_points
+
+    def _generate_queries(self, xyz, features, end_points):
+        logits = self.points_obj_cls(features)
+        end_points["seeds_obj_cls_logits"] = logits
+        sample_inds = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int()
+        xyz, features, sample_inds = self.gsample_module(xyz, features, sample_inds)
+        end_points["query_points_xyz"] = xyz
+        end_points["query_points_feature"] = features
+        end_points["query_points_sample_inds"] = sample_inds
+        return end_points
+
+    def _normalized_proj(self, x):
+        return F.normalize(self.contrastive_align_projection_image(x), p=2, dim=-1)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs):
+        """inputs: point_clouds (B,N,3+C), text list[str]; with butd also det_boxes (B,132,6),
+        det_bbox_label_mask (B,132) bool, det_class_ids (B,132) i64.  Returns ``end_points``."""
+        end_points = self._run_backbones(inputs)
+        points_xyz = end_points["fp2_xyz"]                       # (B, V, 3)
+        points_features = end_points["fp2_features"]             # (B, d, V)
+        text_feats = end_points["text_feats"]                    # (B, L, d)
+        text_padding_mask = end_points["text_attention_mask"]    # (B, L)
+
+        detected_mask = detected_feats = None
+        if self.butd:
+            detected_mask = ~inputs["det_bbox_label_mask"]
+            class_feats = self.class_embeddings(self.butd_class_embeddings(inputs["det_class_ids"]))
+            detected_feats = torch.cat(
+                [self.box_embeddings(inputs["det_boxes"]), class_feats.transpose(1, 2)], 1
+            ).transpose(1, 2).contiguous()                       # (B, D, d)
+
+        vis, text_feats = self.cross_encoder(
+            vis_feats=points_features.transpose(1, 2).contiguous(),
+            pos_feats=self.pos_embed(points_xyz).transpose(1, 2).contiguous(),
+            padding_mask=torch.zeros(points_xyz.shape[:2], dtype=torch.bool,
+                                     device=points_xyz.device),
+            text_feats=text_feats, text_padding_mask=text_padding_mask, end_points=end_points,
+            detected_feats=detected_feats, detected_mask=detected_mask)
+        points_features = vis.transpose(1, 2).contiguous()       # (B, d, V)
+        end_points["text_memory"] = text_feats
+        end_points["seed_features"] = points_features
+        if self.contrastive_align_loss:
+            end_points["proj_tokens"] = F.normalize(
+                self.contrastive_align_projection_text(text_feats), p=2, dim=-1)
+
+        end_points = self._generate_queries(points_xyz, points_features, end_points)
+        cluster_feature = end_points["query_points_feature"]     # (B, d, Q)
+        cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
+        query = self.decoder_query_proj(cluster_feature).transpose(1, 2).contiguous()
+        if self.contrastive_align_loss:
+            end_points["proposal_proj_queries"] = self._normalized_proj(query)
+
+        center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
+                                          end_points=end_points, prefix="proposal_")
+        base_xyz, base_size = center.detach().clone(), size.detach().clone()
+
+        for i, (layer, head) in enumerate(zip(self.decoder, self.prediction_heads)):
+            prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
+            if self.self_position_embedding == "none":
+                query_pos = None
+            elif self.self_position_embedding == "xyz_learned":
+                query_pos = base_xyz
+            elif self.self_position_embedding == "loc_learned":
+                query_pos = torch.cat([base_xyz, base_size], -1)
+            else:
+                raise NotImplementedError
+            query = layer(query, vis, text_feats, query_pos, None, text_padding_mask,
+                          detected_feats=detected_feats if self.butd else None,
+                          detected_mask=detected_mask if self.butd else None)
+            if self.contrastive_align_loss:
+                end_points[f"{prefix}proj_queries"] = self._normalized_proj(query)
+            center, size = head(query.transpose(1, 2).contiguous(), base_xyz=cluster_xyz,
+                                end_points=end_points, prefix=prefix)
+            base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        return end_points
+
+    def init_bn_momentum(self):
+        for m in self.modules():
+            if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.momentum = 0.1

@@ -1,0 +1,248 @@
+"""Cross-modal encoder / decoder layers of BUTD-DETR (models/encoder_decoder_layers.py).
+
+Same classes, constructor arguments, forward signatures and parameter names as the reference --
+``PositionEmbeddingLearned`` (:19-34), ``CrossAttentionLayer`` (:37-124),
+``TransformerEncoderLayerNoFFN`` (:127-156), ``PosTransformerEncoderLayerNoFFN`` (:159-186),
+``BiEncoderLayer`` (:189-255), ``BiEncoder`` (:258-284), ``BiDecoderLayer`` (:287-406) -- but all
+tensors stay batch-first (B, L, d): the reference's seq-first transposes only exist to feed
+``nn.MultiheadAttention(batch_first=False)`` and are arithmetic no-ops.
+
+Every attention / FFN block is routed through ``attention_blocks`` (fused gfx950 kernels when
+enabled, plain torch ops otherwise -- same maths as torch/nn/functional.py multi_head_attention_forward:
+packed in-proj, q * sqrt(1/head_dim), additive -inf key-padding mask, softmax, dropout, out-proj).
+"""
+from copy import deepcopy
+
+import torch
+from torch import nn
+
+from . import attention_blocks as ab
+
+
+def _get_clones(module, n):
+    return nn.ModuleList([deepcopy(module) for _ in range(n)])
+
+
+class PositionEmbeddingLearned(nn.Module):
+    """Conv1d(k->F) + BN1d + ReLU + Conv1d(F->F): xyz (B,N,k) -> (B,F,N)."""
+
+    def __init__(self, input_channel, num_pos_feats=288):
+        super().__init__()
+        self.position_embedding_head = nn.Sequential(
+            nn.Conv1d(input_channel, num_pos_feats, kernel_size=1),
+            nn.BatchNorm1d(num_pos_feats),
+            nn.ReLU(inplace=True),
+            nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
+
+    def forward(self, xyz):
+        return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
+
+
+class MultiheadAttention(nn.Module):
+    """Parameter container with ``nn.MultiheadAttention``'s names and init (``in_proj_weight``
+    (3d,d) xavier-uniform, ``in_proj_bias`` zeros, ``out_proj.{weight,bias}``), batch-first maths.
+
+    forward(query (B,Lq,d), key (B,Lk,d), value (B,Lk,d), key_padding_mask (B,Lk) bool | None)
+        -> (B,Lq,d)  [the reference discards the averaged attention weights with ``[0]``]
+    """
+
+    def __init__(self, embed_dim, num_heads, dropout=0.0):
+        super().__init__()
+        assert embed_dim % num_heads == 0
+        self.embed_dim, self.num_heads, self.dropout = embed_dim, num_heads, dropout
+        self.head_dim = embed_dim // num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.empty(3 * embed_dim))
+        self.out_proj = nn.Linear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.in_proj_bias, 0.0)
+        nn.init.constant_(self.out_proj.bias, 0.0)
+
+    def forward(self, query, key, value, key_padding_mask=None):
+        return ab.multi_head_attention(self, query, key, value, key_padding_mask)
+
+
+def _ffn(d_model, dim_feedforward, dropout):
+    return nn.Sequential(
+        nn.Linear(d_model, dim_feedforward), nn.ReLU(), nn.Dropout(dropout),
+        nn.Linear(dim_feedforward, d_model), nn.Dropout(dropout))
+
+
+class CrossAttentionLayer(nn.Module):
+    """text<-vision, vision<-text, [vision<-boxes], FFNs; post-LayerNorm everywhere."""
+
+    def __init__(self, d_model=256, dropout=0.1, n_heads=8, dim_feedforward=256,
+                 use_butd_enc_attn=False):
+        super().__init__()
+        self.use_butd_enc_attn = use_butd_enc_attn
+        self.cross_lv = MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout_lv = nn.Dropout(dropout)
+        self.norm_lv = nn.LayerNorm(d_model)
+        self.ffn_lv = _ffn(d_model, dim_feedforward, dropout)
+        self.norm_lv2 = nn.LayerNorm(d_model)
+
+        self.cross_vl = deepcopy(self.cross_lv)
+        self.dropout_vl = nn.Dropout(dropout)
+        self.norm_vl = nn.LayerNorm(d_model)
+        self.ffn_vl = deepcopy(self.ffn_lv)
+        self.norm_vl2 = nn.LayerNorm(d_model)
+
+        if use_butd_enc_attn:
+            self.cross_d = MultiheadAttention(d_model, n_heads, dropout=dropout)
+            self.dropout_d = nn.Dropout(dropout)
+            self.norm_d = nn.LayerNorm(d_model)
+
+    def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
+                pos_feats, detected_feats=None, detected_mask=None):
+        """vis/pos (B,V,d), text (B,L,d), boxes (B,D,d); masks True = padding."""
+        vis_query = vis_feats + pos_feats  # positional features only on the query (:79-80)
+        text_in = text_feats               # keys/values of cross_vl are the layer INPUT (:83,:101-102)
+        # language attends to vision, then its FFN
+        text_feats = ab.attention_block(self.cross_lv, self.dropout_lv, self.norm_lv,
+                                        residual=text_feats, query=text_feats,
+                                        key=vis_feats, value=vis_feats,
+                                        key_padding_mask=vis_key_padding_mask)
+        text_feats = ab.ffn_block(self.ffn_lv, self.norm_lv2, text_feats)
+        # vision attends to language
+        vis_feats = ab.attention_block(self.cross_vl, self.dropout_vl, self.norm_vl,
+                                       residual=vis_feats, query=vis_query,
+                                       key=text_in, value=text_in,
+                                       key_padding_mask=text_key_padding_mask)
+        if detected_feats is not None and self.use_butd_enc_attn:
+            vis_feats = ab.attention_block(self.cross_d, self.dropout_d, self.norm_d,
+                                           residual=vis_feats, query=vis_feats,
+                                           key=detected_feats, value=detected_feats,
+                                           key_padding_mask=detected_mask)
+        vis_feats = ab.ffn_block(self.ffn_vl, self.norm_vl2, vis_feats)
+        return vis_feats, text_feats
+
+
+class TransformerEncoderLayerNoFFN(nn.Module):
+    """Self-attention + residual + LayerNorm, no FFN.  src (B,S,d)."""
+
+    def __init__(self, d_model, nhead, dropout):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None):
+        assert src_mask is None, "attn_mask is never used on this path"
+        return ab.attention_block(self.self_attn, self.dropout1, self.norm1, residual=src,
+                                  query=src, key=src, value=src,
+                                  key_padding_mask=src_key_padding_mask)
+
+
+class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
+    """Same, with the positional embedding added to query and key (not value)."""
+
+    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None):
+        assert src_mask is None, "attn_mask is never used on this path"
+        qk = src + pos
+        return ab.attention_block(self.self_attn, self.dropout1, self.norm1, residual=src,
+                                  query=qk, key=qk, value=src,
+                                  key_padding_mask=src_key_padding_mask)
+
+
+class BiEncoderLayer(nn.Module):
+    """visual self-attn -> language self-attn -> CrossAttentionLayer."""
+
+    def __init__(self, d_model=256, dropout=0.1, activation="relu", n_heads=8,
+                 dim_feedforward=256, self_attend_lang=True, self_attend_vis=True,
+                 use_butd_enc_attn=False):
+        super().__init__()
+        self.self_attention_lang = (TransformerEncoderLayerNoFFN(d_model, n_heads, dropout)
+                                    if self_attend_lang else None)
+        self.self_attention_visual = (PosTransformerEncoderLayerNoFFN(d_model, n_heads, dropout)
+                                      if self_attend_vis else None)
+        self.cross_layer = CrossAttentionLayer(d_model, dropout, n_heads, dim_feedforward,
+                                               use_butd_enc_attn)
+
+    def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
+                end_points={}, detected_feats=None, detected_mask=None):
+        if self.self_attention_visual is not None:
+            vis_feats = self.self_attention_visual(vis_feats, pos_feats,
+                                                   src_key_padding_mask=padding_mask)
+        if self.self_attention_lang is not None:
+            text_feats = self.self_attention_lang(text_feats,
+                                                  src_key_padding_mask=text_padding_mask)
+        return self.cross_layer(vis_feats=vis_feats, vis_key_padding_mask=padding_mask,
+                                text_feats=text_feats, text_key_padding_mask=text_padding_mask,
+                                pos_feats=pos_feats, detected_feats=detected_feats,
+                                detected_mask=detected_mask)
+
+
+class BiEncoder(nn.Module):
+    def __init__(self, bi_layer, num_layers):
+        super().__init__()
+        self.layers = _get_clones(bi_layer, num_layers)
+        self.num_layers = num_layers
+
+    def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
+                end_points={}, detected_feats=None, detected_mask=None):
+        for i, layer in enumerate(self.layers):
+            vis_feats, text_feats = layer(vis_feats, pos_feats, padding_mask, text_feats,
+                                          text_padding_mask, end_points,
+                                          detected_feats=detected_feats,
+                                          detected_mask=detected_mask)
+            if "lv_attention" in end_points:
+                end_points["lv_attention%d" % i] = end_points["lv_attention"]
+        return vis_feats, text_feats
+
+
+class BiDecoderLayer(nn.Module):
+    """query self-attn -> cross to language -> [cross to boxes] -> cross to vision -> FFN."""
+
+    def __init__(self, d_model, n_heads, dim_feedforward=2048, dropout=0.1, activation="relu",
+                 self_position_embedding="loc_learned", butd=False):
+        super().__init__()
+        self.self_attn = MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout)
+
+        self.cross_l = MultiheadAttention(d_model, n_heads, dropout=dropout)
+        self.dropout_l = nn.Dropout(dropout)
+        self.norm_l = nn.LayerNorm(d_model)
+
+        if butd:
+            self.cross_d = deepcopy(self.cross_l)
+            self.dropout_d = nn.Dropout(dropout)
+            self.norm_d = nn.LayerNorm(d_model)
+
+        self.cross_v = deepcopy(self.cross_l)
+        self.dropout_v = nn.Dropout(dropout)
+        self.norm_v = nn.LayerNorm(d_model)
+
+        self.ffn = _ffn(d_model, dim_feedforward, dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+        if self_position_embedding == "xyz_learned":
+            self.self_posembed = PositionEmbeddingLearned(3, d_model)
+        elif self_position_embedding == "loc_learned":
+            self.self_posembed = PositionEmbeddingLearned(6, d_model)
+        else:
+            self.self_posembed = None
+
+    def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask,
+                text_key_padding_mask, detected_feats=None, detected_mask=None):
+        """query (B,Q,d), vis (B,V,d), lang (B,L,d), query_pos (B,Q,3|6) -> (B,Q,d)."""
+        if self.self_posembed is not None:
+            query_pos = self.self_posembed(query_pos).transpose(1, 2).contiguous()
+        else:
+            query_pos = torch.zeros_like(query)
+
+        qk = query + query_pos
+        query = ab.attention_block(self.self_attn, self.dropout1, self.norm1, residual=query,
+                                   query=qk, key=qk, value=query, key_padding_mask=padding_mask)
+        query = ab.attention_block(self.cross_l, self.dropout_l, self.norm_l, residual=query,
+                                   query=query + query_pos, key=lang_feats, value=lang_feats,
+                                   key_padding_mask=text_key_padding_mask)
+        if detected_feats is not None:
+            query = ab.attention_block(self.cross_d, self.dropout_d, self.norm_d, residual=query,
+                                       query=query + query_pos, key=detected_feats,
+                                       value=detected_feats, key_padding_mask=detected_mask)
+        query = ab.attention_block(self.cross_v, self.dropout_v, self.norm_v, residual=query,
+                                   query=query + query_pos, key=vis_feats, value=vis_feats,
+                                   key_padding_mask=None)
+        query = ab.ffn_block(self.ffn, self.norm2, query)
+        return query.contiguous()

@@ -1,0 +1,102 @@
+"""Query-generation and prediction-head modules between encoder and decoder (models/modules.py).
+
+``PointsObjClsModule`` (:19-49), ``GeneralSamplingModule`` (:70-86), ``ThreeLayerMLP`` (:89-108) and
+``ClsAgnosticPredictHead`` (:111-180); ``PositionEmbeddingLearned`` is shared with the
+encoder/decoder file.  Small Conv1d+BN1d stacks: stock torch ops (SURVEY.md section 8(f)-2 ranks their
+fusion as "next").
+"""
+import numpy as np
+import torch.nn.functional as F
+from torch import nn
+
+from .encoder_decoder_layers import PositionEmbeddingLearned  # noqa: F401  (re-export, modules.py:52)
+from .pointnet2_utils import gather_operation
+
+
+class PointsObjClsModule(nn.Module):
+    """Per-seed objectness logit: (B, C, K) -> (B, 1, K)."""
+
+    def __init__(self, seed_feature_dim):
+        super().__init__()
+        self.in_dim = seed_feature_dim
+        self.conv1 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.bn1 = nn.BatchNorm1d(self.in_dim)
+        self.conv2 = nn.Conv1d(self.in_dim, self.in_dim, 1)
+        self.bn2 = nn.BatchNorm1d(self.in_dim)
+        self.conv3 = nn.Conv1d(self.in_dim, 1, 1)
+
+    def forward(self, seed_features):
+        net = F.relu(self.bn1(self.conv1(seed_features)))
+        net = F.relu(self.bn2(self.conv2(net)))
+        return self.conv3(net)
+
+
+class GeneralSamplingModule(nn.Module):
+    """Gather xyz (B,K,3) and features (B,C,K) at ``sample_inds`` (B,Q) i32."""
+
+    def forward(self, xyz, features, sample_inds):
+        new_xyz = gather_operation(xyz.transpose(1, 2).contiguous(),
+                                   sample_inds).transpose(1, 2).contiguous()
+        new_features = gather_operation(features, sample_inds).contiguous()
+        return new_xyz, new_features, sample_inds
+
+
+class ThreeLayerMLP(nn.Module):
+    """Conv1d-BN-ReLU-Dropout(0.3) x2 + Conv1d on (B, dim, N)."""
+
+    def __init__(self, dim, out_dim):
+        super().__init__()
+        self.net = nn.Sequential(
+            nn.Conv1d(dim, dim, 1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(), nn.Dropout(0.3),
+            nn.Conv1d(dim, dim, 1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(), nn.Dropout(0.3),
+            nn.Conv1d(dim, out_dim, 1))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class ClsAgnosticPredictHead(nn.Module):
+    """Box centre / size / soft-token class heads writing ``{prefix}*`` into ``end_points``."""
+
+    def __init__(self, num_class, num_heading_bin, num_proposal, seed_feat_dim=256,
+                 objectness=True, heading=False, compute_sem_scores=True):
+        super().__init__()
+        self.num_class = num_class
+        self.num_heading_bin = num_heading_bin
+        self.num_proposal = num_proposal
+        self.seed_feat_dim = seed_feat_dim
+        self.objectness = objectness
+        self.heading = heading
+        self.compute_sem_scores = compute_sem_scores
+        if objectness:
+            self.objectness_scores_head = ThreeLayerMLP(seed_feat_dim, 1)
+        self.center_residual_head = ThreeLayerMLP(seed_feat_dim, 3)
+        if heading:
+            self.heading_class_head = nn.Conv1d(seed_feat_dim, num_heading_bin, 1)
+            self.heading_residual_head = nn.Conv1d(seed_feat_dim, num_heading_bin, 1)
+        self.size_pred_head = ThreeLayerMLP(seed_feat_dim, 3)
+        if compute_sem_scores:
+            self.sem_cls_scores_head = ThreeLayerMLP(seed_feat_dim, self.num_class)
+
+    def forward(self, features, base_xyz, end_points, prefix=""):
+        """features (B, C, Q), base_xyz (B, Q, 3) -> (center (B,Q,3), pred_size (B,Q,3))."""
+        batch_size, num_proposal = features.shape[0], features.shape[-1]
+        if self.objectness:
+            scores = self.objectness_scores_head(features).transpose(2, 1)
+            end_points[f"{prefix}objectness_scores"] = scores.squeeze(-1)
+        center = base_xyz + self.center_residual_head(features).transpose(2, 1)
+        if self.heading:
+            heading_scores = self.heading_class_head(features).transpose(2, 1)
+            normalized = self.heading_residual_head(features).transpose(2, 1)
+            end_points[f"{prefix}heading_scores"] = heading_scores
+            end_points[f"{prefix}heading_residuals_normalized"] = normalized
+            end_points[f"{prefix}heading_residuals"] = normalized * (np.pi / self.num_heading_bin)
+        pred_size = self.size_pred_head(features).transpose(2, 1).view(
+            [batch_size, num_proposal, 3])
+        end_points[f"{prefix}base_xyz"] = base_xyz
+        end_points[f"{prefix}center"] = center
+        end_points[f"{prefix}pred_size"] = pred_size
+        if self.compute_sem_scores:
+            end_points[f"{prefix}sem_cls_scores"] = self.sem_cls_scores_head(
+                features).transpose(2, 1)
+        return center, pred_size
