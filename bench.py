@@ -100,9 +100,10 @@ def cpu_baseline(args, scenes):
     has no CPU operators of its own) + torch CPU fp32, all host cores; bounded sample."""
     from butd_detr_amd import attention_blocks, pointnet2_utils
     from butd_detr_amd.train_step import make_optimizer, synthetic_batch, train_step
-    from oracle import ext_adapter
-    cores = os.cpu_count() or 1
+    from oracle import ext_adapter, pointnet2_oracle
+    cores = pointnet2_oracle.host_cores()   # affinity capped by the cgroup quota (16 on the GPU boxes)
     torch.set_num_threads(cores)
+    pointnet2_oracle.set_num_threads(cores)
     prev_ext, prev_backend = pointnet2_utils._ext, attention_blocks.get_backend()
     pointnet2_utils._ext = ext_adapter          # cpu_baseline leg only: oracle as the timed CPU port
     attention_blocks.set_backend("torch")

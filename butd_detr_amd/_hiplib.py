@@ -6,6 +6,9 @@ declare is absent, importing/using the ops raises immediately.
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its own libamdhip64; loading
+              # ours first would bring up a second HIP runtime that does not see torch's context.
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libbutd_detr_hip.so")
 

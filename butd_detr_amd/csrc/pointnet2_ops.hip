@@ -15,8 +15,11 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/butd_pointnet2.h"
+#include "fps_common.h"
 
 namespace {
 
@@ -29,97 +32,43 @@ __host__ __device__ inline int ilog2_floor(unsigned v) {
 }
 
 // ----------------------------------------------------------------------------------------------
-// FPS
+// FPS (small / medium clouds; large ones take the pruned path in fps_pruned.hip)
 // ----------------------------------------------------------------------------------------------
-// The reference block (sampling_gpu.cu:74-178) has `bs = opt_n_threads(n)` threads; thread t owns the
-// points k == t (mod bs), keeps its first strict maximum, and a shared-memory tree then prefers the
-// LOWER slot on ties, level by level from stride bs/2 down to 1.  Net effect ("FPS tie
-// rule"): among equal maxima the winner has the smallest bit-reversed slot (k mod bs), then the
-// smallest k.  That is a total order, so any reduction shape gives the reference's answer as long as
-// it maximises   (d2, -bitrev(k mod bs), -k).   We pack it into one u64 and take an integer max:
-//     hi 32 = float bits of d2 (d2 >= 0, so the bit pattern is monotone), lo 32 = ~key(k).
-// "No candidate" (every point of a thread skipped: best = -1, besti = 0 in the reference) packs to 0
-// and decodes to index 0.
-constexpr int kFpsThreads = 1024;
-constexpr int kFpsWaves = kFpsThreads / kWave;
-
-__device__ inline unsigned fps_key(unsigned k, int log2bs) {
-  const unsigned slot = k & ((1u << log2bs) - 1u);
-  const unsigned rev = log2bs ? (__brev(slot) >> (32 - log2bs)) : 0u;
-  return (rev << 23) | (k >> log2bs);
-}
-__device__ inline unsigned fps_unkey(unsigned key, int log2bs) {
-  const unsigned rev = key >> 23;
-  const unsigned slot = log2bs ? (__brev(rev) >> (32 - log2bs)) : 0u;
-  return ((key & 0x7FFFFFu) << log2bs) | slot;
-}
-
-__device__ inline unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
-  unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-  lo = __shfl_xor(lo, mask, kWave);
-  hi = __shfl_xor(hi, mask, kWave);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-  for (int s = 32; s >= 1; s >>= 1) {
-    const unsigned long long o = shfl_xor_u64(v, s);
-    v = o > v ? o : v;
-  }
-  return v;
-}
-
-// wave-uniform copy of lane 0's value (readfirstlane returns a signed int: cast before widening)
-__device__ inline unsigned long long uniform_u64(unsigned long long v) {
-  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
-  return ((unsigned long long)hi << 32) | (unsigned long long)lo;
-}
-
-struct alignas(16) FpsSlot {
-  unsigned long long packed;
-  float x, y, z;
-  float pad[3];
-};
-
-// mag <= 1e-3 is a DOUBLE compare in the reference (sampling_gpu.cu:106): float32(1e-3) > 1e-3, so in
-// fp32 terms the skip condition is mag < float32(1e-3).
-__device__ inline bool fps_skipped(float x, float y, float z) {
-  const float mag = (x * x) + (y * y) + (z * z);
-  return (double)mag <= 1e-3;
-}
-
-template <int PPT, bool XYZ_IN_REGS>
-__global__ __launch_bounds__(kFpsThreads) void fps_kernel(int n, int m, int log2bs,
-                                                          const float *__restrict__ dataset,
-                                                          int *__restrict__ idxs) {
-  __shared__ FpsSlot slots[2][kFpsWaves];
+// One workgroup per scene, coordinates + running min distance + tie-break key of every owned point
+// in VGPRs.  The iteration is a pure latency chain (update -> in-wave arg-max -> cross-wave arg-max ->
+// next sample), and every resident wave replays the reduction/selection instructions on its SIMD, so
+// the kernel runs ONE wave per SIMD (256 threads) and gives each lane up to 16 points instead of
+// spreading 1024 threads over the points: 2-3x shorter iterations at n <= 4096.
+template <int THREADS, int PPT>
+__global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, int log2bs,
+                                                      const float *__restrict__ dataset,
+                                                      int *__restrict__ idxs) {
+  constexpr int kNumWaves = THREADS / kWave;
+  __shared__ fps::Slot slots[2][fps::kMaxWaves];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   int *out = idxs + (size_t)blockIdx.x * m;
 
   // running min distance per owned point; -1 marks "never competes" (skipped or out of range):
-  // min(d, -1) = -1 and -1 > best(-1) is false, exactly like `continue` in the reference.
-  float t[PPT];
-  float px[XYZ_IN_REGS ? PPT : 1], py[XYZ_IN_REGS ? PPT : 1], pz[XYZ_IN_REGS ? PPT : 1];
+  // min(d, -1) = -1 never beats a candidate, exactly like `continue` in the reference.
+  float t[PPT], px[PPT], py[PPT], pz[PPT];
+  unsigned key[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
-    const int k = tid + i * kFpsThreads;
+    const int k = tid + i * THREADS;
     float x = 0.f, y = 0.f, z = 0.f;
     if (k < n) {
       x = pts[k * 3 + 0];
       y = pts[k * 3 + 1];
       z = pts[k * 3 + 2];
     }
-    t[i] = (k < n && !fps_skipped(x, y, z)) ? 1e10f : -1.0f;
-    if (XYZ_IN_REGS) {
-      px[i] = x;
-      py[i] = y;
-      pz[i] = z;
-    }
+    t[i] = (k < n && !fps::skipped(x, y, z)) ? 1e10f : -1.0f;
+    px[i] = x;
+    py[i] = y;
+    pz[i] = z;
+    key[i] = fps::key_of((unsigned)k, log2bs);
   }
   const float p0x = pts[0], p0y = pts[1], p0z = pts[2];
   float x1 = p0x, y1 = p0y, z1 = p0z;
@@ -127,90 +76,52 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel(int n, int m, int log2
 
   for (int j = 1; j < m; ++j) {
     float best = -1.0f;
-    int besti = 0;
+    unsigned bkey = 0xFFFFFFFFu;
     float bx = 0.f, by = 0.f, bz = 0.f;
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
-      const int k = tid + i * kFpsThreads;
-      float x2, y2, z2;
-      if (XYZ_IN_REGS) {
-        x2 = px[i];
-        y2 = py[i];
-        z2 = pz[i];
-      } else {
-        const int kk = k < n ? k : 0;
-        x2 = pts[kk * 3 + 0];
-        y2 = pts[kk * 3 + 1];
-        z2 = pts[kk * 3 + 2];
-      }
-      const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+      const float d = (px[i] - x1) * (px[i] - x1) + (py[i] - y1) * (py[i] - y1) +
+                      (pz[i] - z1) * (pz[i] - z1);
       const float d2 = fminf(d, t[i]);
       t[i] = d2;
-      const bool better = d2 > best;
-      besti = better ? k : besti;
-      bx = better ? x2 : bx;
-      by = better ? y2 : by;
-      bz = better ? z2 : bz;
+      // value descending, then key ascending (the reference's tie order, fps_common.h)
+      const bool better = d2 > best || (d2 == best && key[i] < bkey);
+      bkey = better ? key[i] : bkey;
+      bx = better ? px[i] : bx;
+      by = better ? py[i] : by;
+      bz = better ? pz[i] : bz;
       best = better ? d2 : best;
     }
-    unsigned long long mine = 0ull;
-    if (best >= 0.0f)
-      mine = ((unsigned long long)__float_as_uint(best) << 32) |
-             (unsigned long long)(0xFFFFFFFFu - fps_key((unsigned)besti, log2bs));
-    const unsigned long long wbest = wave_max_u64(mine);
-    FpsSlot *buf = slots[j & 1];
-    if (mine == wbest && (wbest != 0ull || lane == 0)) {
-      buf[wave].packed = wbest;
-      buf[wave].x = bx;
-      buf[wave].y = by;
-      buf[wave].z = bz;
-    }
+    fps::Slot *buf = slots[j & 1];
+    fps::publish_wave_best(buf, wave, lane, best >= 0.0f, __float_as_uint(best), bkey, bx, by, bz);
     __syncthreads();
-    // every wave reduces the 16 wave winners redundantly: no second barrier for the broadcast
-    unsigned long long cand = lane < kFpsWaves ? buf[lane].packed : 0ull;
-    unsigned long long gbest = cand;
-#pragma unroll
-    for (int s = kFpsWaves / 2; s >= 1; s >>= 1) {
-      const unsigned long long o = shfl_xor_u64(gbest, s);
-      gbest = o > gbest ? o : gbest;
-    }
-    gbest = uniform_u64(gbest);
-    int old = 0;
-    if (gbest != 0ull) {
-      const unsigned long long hit = __ballot(cand == gbest);
-      const int w = __ffsll((long long)hit) - 1;
-      x1 = buf[w].x;
-      y1 = buf[w].y;
-      z1 = buf[w].z;
-      old = (int)fps_unkey(0xFFFFFFFFu - (unsigned)gbest, log2bs);
-    } else {
-      x1 = p0x;
-      y1 = p0y;
-      z1 = p0z;
-    }
+    const int old = fps::select_global_best<kNumWaves>(buf, lane, log2bs, p0x, p0y, p0z, x1, y1, z1);
     if (tid == 0) out[j] = old;
   }
 }
 
-// Generic fallback for clouds too large for the register-resident kernel (n > 64K points): running
-// min distances live in the caller's `temp` scratch.
+// Streaming fallback for clouds that fit neither the register-resident kernel nor the pruned path's
+// workspace: running min distances live in the caller's `temp` scratch.
+constexpr int kFpsThreads = 1024;
 __global__ __launch_bounds__(kFpsThreads) void fps_kernel_global(int n, int m, int log2bs,
                                                                  const float *__restrict__ dataset,
                                                                  float *__restrict__ temp,
                                                                  int *__restrict__ idxs) {
-  __shared__ FpsSlot slots[2][kFpsWaves];
+  __shared__ fps::Slot slots[2][fps::kMaxWaves];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
   float *tmp = temp + (size_t)blockIdx.x * n;
   int *out = idxs + (size_t)blockIdx.x * m;
   for (int k = tid; k < n; k += kFpsThreads)
-    tmp[k] = fps_skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
+    tmp[k] = fps::skipped(pts[k * 3 + 0], pts[k * 3 + 1], pts[k * 3 + 2]) ? -1.0f : 1e10f;
   const float p0x = pts[0], p0y = pts[1], p0z = pts[2];
   float x1 = p0x, y1 = p0y, z1 = p0z;
   if (tid == 0) out[0] = 0;
   for (int j = 1; j < m; ++j) {
+    // 1024 is a multiple of the reference block size, so all of a thread's points share one
+    // reference slot and its FIRST strict maximum is the slot's winner.
     float best = -1.0f;
     int besti = 0;
     float bx = 0.f, by = 0.f, bz = 0.f;
@@ -226,40 +137,11 @@ __global__ __launch_bounds__(kFpsThreads) void fps_kernel_global(int n, int m, i
       bz = better ? z2 : bz;
       best = better ? d2 : best;
     }
-    unsigned long long mine = 0ull;
-    if (best >= 0.0f)
-      mine = ((unsigned long long)__float_as_uint(best) << 32) |
-             (unsigned long long)(0xFFFFFFFFu - fps_key((unsigned)besti, log2bs));
-    const unsigned long long wbest = wave_max_u64(mine);
-    FpsSlot *buf = slots[j & 1];
-    if (mine == wbest && (wbest != 0ull || lane == 0)) {
-      buf[wave].packed = wbest;
-      buf[wave].x = bx;
-      buf[wave].y = by;
-      buf[wave].z = bz;
-    }
+    fps::Slot *buf = slots[j & 1];
+    fps::publish_wave_best(buf, wave, lane, best >= 0.0f, __float_as_uint(best),
+                           fps::key_of((unsigned)besti, log2bs), bx, by, bz);
     __syncthreads();
-    unsigned long long cand = lane < kFpsWaves ? buf[lane].packed : 0ull;
-    unsigned long long gbest = cand;
-#pragma unroll
-    for (int s = kFpsWaves / 2; s >= 1; s >>= 1) {
-      const unsigned long long o = shfl_xor_u64(gbest, s);
-      gbest = o > gbest ? o : gbest;
-    }
-    gbest = uniform_u64(gbest);
-    int old = 0;
-    if (gbest != 0ull) {
-      const unsigned long long hit = __ballot(cand == gbest);
-      const int w = __ffsll((long long)hit) - 1;
-      x1 = buf[w].x;
-      y1 = buf[w].y;
-      z1 = buf[w].z;
-      old = (int)fps_unkey(0xFFFFFFFFu - (unsigned)gbest, log2bs);
-    } else {
-      x1 = p0x;
-      y1 = p0y;
-      z1 = p0z;
-    }
+    const int old = fps::select_global_best<kFpsThreads / kWave>(buf, lane, log2bs, p0x, p0y, p0z, x1, y1, z1);
     if (tid == 0) out[j] = old;
   }
 }
@@ -501,12 +383,7 @@ int butd_opt_n_threads(int work_size) {
   return t;
 }
 
-size_t butd_fps_workspace_bytes(int, int) { return 0; }
-
-int butd_furthest_point_sampling_ws(int b, int n, int m, const float *dataset, float *temp,
-                                    int *idxs, void *, size_t, butd_stream_t stream) {
-  return butd_furthest_point_sampling(b, n, m, dataset, temp, idxs, stream);
-}
+// butd_fps_workspace_bytes / butd_furthest_point_sampling_ws: see fps_pruned.hip
 
 int butd_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                                  butd_stream_t stream) {
@@ -514,14 +391,28 @@ int butd_furthest_point_sampling(int b, int n, int m, const float *dataset, floa
   if (n <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const int log2bs = ilog2_floor((unsigned)butd_opt_n_threads(n));
-  const int ppt = (n + kFpsThreads - 1) / kFpsThreads;
-#define FPS_LAUNCH(P, R) \
-  hipLaunchKernelGGL((fps_kernel<P, R>), dim3(b), dim3(kFpsThreads), 0, s, n, m, log2bs, dataset, idxs)
-  if (ppt <= 1) FPS_LAUNCH(1, true);
-  else if (ppt <= 2) FPS_LAUNCH(2, true);
-  else if (ppt <= 4) FPS_LAUNCH(4, true);
-  else if (ppt <= 8) FPS_LAUNCH(8, true);
-  else if (ppt <= 16) FPS_LAUNCH(16, false);
+#define FPS_LAUNCH(T, P) \
+  hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), 0, s, n, m, log2bs, dataset, idxs)
+  const char *cfg = getenv("BUTD_FPS_CFG");  // tuning hook: "threads,ppt"
+  int ct = 0, cp = 0;
+  if (cfg && sscanf(cfg, "%d,%d", &ct, &cp) == 2 && (long long)ct * cp >= n) {
+    if (ct == 256 && cp == 2) FPS_LAUNCH(256, 2);
+    else if (ct == 256 && cp == 4) FPS_LAUNCH(256, 4);
+    else if (ct == 256 && cp == 8) FPS_LAUNCH(256, 8);
+    else if (ct == 512 && cp == 1) FPS_LAUNCH(512, 1);
+    else if (ct == 512 && cp == 2) FPS_LAUNCH(512, 2);
+    else if (ct == 512 && cp == 4) FPS_LAUNCH(512, 4);
+    else if (ct == 1024 && cp == 1) FPS_LAUNCH(1024, 1);
+    else if (ct == 1024 && cp == 2) FPS_LAUNCH(1024, 2);
+    else return (int)hipErrorInvalidValue;
+    return launch_status();
+  }
+  if (n <= 256) FPS_LAUNCH(256, 1);
+  else if (n <= 512) FPS_LAUNCH(256, 2);
+  else if (n <= 1024) FPS_LAUNCH(256, 4);
+  else if (n <= 2048) FPS_LAUNCH(1024, 2);   // measured on MI355X: see DESIGN.md "FPS tuning"
+  else if (n <= 4096) FPS_LAUNCH(1024, 4);
+  else if (n <= 8192) FPS_LAUNCH(1024, 8);
   else {  // larger clouds: streaming kernel (the pruned path in fps_pruned.hip supersedes it)
     if (temp == nullptr) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(fps_kernel_global, dim3(b), dim3(kFpsThreads), 0, s, n, m, log2bs, dataset,

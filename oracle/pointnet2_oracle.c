@@ -35,6 +35,16 @@
 
 #define TOTAL_THREADS 512
 
+/* OpenMP team size for every routine below (the GPU boxes expose 256 logical CPUs under a 16-CPU
+ * cgroup quota: the default team would oversubscribe pathologically). */
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
+
 /* include/cuda_utils.h:18-24 -- opt_n_threads(): 2^floor(log2(work_size)) clamped to [1, 512],
  * with the same double-precision log()/log() quotient truncation. */
 int oracle_opt_n_threads(int work_size) {

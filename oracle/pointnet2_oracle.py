@@ -33,15 +33,31 @@ def build(force=False):
     return _LIB_PATH
 
 
+def host_cores():
+    """Usable cores: affinity mask capped by the cgroup v2 CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def lib():
     global _lib
     if _lib is None:
-        if not os.path.exists(_LIB_PATH):
-            build()
+        build()
         _lib = ctypes.CDLL(_LIB_PATH)
         _lib.oracle_opt_n_threads.restype = ctypes.c_int
         _lib.oracle_opt_n_threads.argtypes = [ctypes.c_int]
+        _lib.oracle_set_num_threads(ctypes.c_int(host_cores()))
     return _lib
+
+
+def set_num_threads(n):
+    lib().oracle_set_num_threads(ctypes.c_int(int(n)))
 
 
 def _f(a):
