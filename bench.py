@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--backend", default=os.environ.get("BUTD_ATTENTION_BACKEND", "auto"),
                     choices=["auto", "torch", "hip"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="plain eager launches + DDP instead of hipGraph replay")
     ap.add_argument("--cpu-scenes", type=int, default=1)
     return ap.parse_args()
 
@@ -142,13 +143,24 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
-    from butd_detr_amd.train_step import (make_optimizer, synthetic_batch, train_step,
-                                          wrap_data_parallel)
+    from butd_detr_amd.train_step import (GraphedTrainStep, make_optimizer, synthetic_batch,
+                                          train_step as eager_step, wrap_data_parallel)
     model, backend = build_model(args, device)
-    ddp = wrap_data_parallel(model, device)
-    opt = make_optimizer(model)
     inputs, targets = synthetic_batch(args.batch, device, n_points=args.points, tokens=args.tokens,
                                       rank=rank)
+    if args.eager:
+        ddp = wrap_data_parallel(model, device)
+        opt = make_optimizer(model)
+
+        def train_step(_m, _o, i, t):
+            return eager_step(ddp, opt, i, t)
+    else:
+        opt = make_optimizer(model, capturable=True)
+        graphed = GraphedTrainStep(model, opt)
+        ddp = model
+
+        def train_step(_m, _o, i, t):
+            return graphed(i, t)
 
     for _ in range(args.warmup):
         train_step(ddp, opt, inputs, targets)
@@ -179,7 +191,7 @@ def main():
                                    f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "
                                    "3 encoder + 6 decoder layers, fwd+loss+bwd+clip+AdamW, train mode",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "attention_backend": backend, "final_loss": round(float(loss), 4)},
+                       "attention_backend": backend, "launch": "eager+DDP" if args.eager else "hipGraph replay + flat-gradient all-reduce", "final_loss": round(float(loss), 4)},
         }
         out["roofline"] = ball_query_roofline(inputs)
         if world == 1 and not args.no_cpu_baseline:

@@ -111,14 +111,20 @@ class BeaUTyDETR(nn.Module):
         self.init_bn_momentum()
 
     # ------------------------------------------------------------------ backbones
-    def _run_backbones(self, inputs):
+    def tokenize(self, inputs):
+        """Host-side part of the forward: tokenizer + H2D copy (bdetr.py:164-166).  Split out so a
+        captured hipGraph can replay everything after it (``forward_tokenized``)."""
+        return self.tokenizer.batch_encode_plus(
+            inputs["text"], padding="longest", return_tensors="pt"
+        ).to(inputs["point_clouds"].device)
+
+    def _run_backbones(self, inputs, tokenized=None):
         end_points = self.backbone_net(inputs["point_clouds"], end_points={})
         end_points["seed_inds"] = end_points["fp2_inds"]
         end_points["seed_xyz"] = end_points["fp2_xyz"]
         end_points["seed_features"] = end_points["fp2_features"]
-        tokenized = self.tokenizer.batch_encode_plus(
-            inputs["text"], padding="longest", return_tensors="pt"
-        ).to(inputs["point_clouds"].device)
+        if tokenized is None:
+            tokenized = self.tokenize(inputs)
         encoded_text = self.text_encoder(**tokenized)
         end_points["text_feats"] = self.text_projector(encoded_text.last_hidden_state)
         # HF masks are 1 = token; torch attention wants True = padding (bdetr.py:171)
@@ -143,7 +149,12 @@ class BeaUTyDETR(nn.Module):
     def forward(self, inputs):
         """inputs: point_clouds (B,N,3+C), text list[str]; with butd also det_boxes (B,132,6),
         det_bbox_label_mask (B,132) bool, det_class_ids (B,132) i64.  Returns ``end_points``."""
-        end_points = self._run_backbones(inputs)
+        return self.forward_tokenized(inputs, None)
+
+    def forward_tokenized(self, inputs, tokenized):
+        """Device-side forward given an already tokenised (and device-resident) utterance batch;
+        ``tokenized=None`` tokenises here (the reference behaviour)."""
+        end_points = self._run_backbones(inputs, tokenized)
         points_xyz = end_points["fp2_xyz"]                       # (B, V, 3)
         points_features = end_points["fp2_features"]             # (B, d, V)
         text_feats = end_points["text_feats"]                    # (B, L, d)
