@@ -108,6 +108,8 @@ class BeaUTyDETR(nn.Module):
             self.contrastive_align_projection_image = _align_mlp(d_model)
             self.contrastive_align_projection_text = _align_mlp(d_model)
 
+        self.overlap_text_tower = True
+        self._side_stream = None
         self.init_bn_momentum()
 
     # ------------------------------------------------------------------ backbones
@@ -118,18 +120,40 @@ class BeaUTyDETR(nn.Module):
             inputs["text"], padding="longest", return_tensors="pt"
         ).to(inputs["point_clouds"].device)
 
-    def _run_backbones(self, inputs, tokenized=None):
-        end_points = self.backbone_net(inputs["point_clouds"], end_points={})
-        end_points["seed_inds"] = end_points["fp2_inds"]
-        end_points["seed_xyz"] = end_points["fp2_xyz"]
-        end_points["seed_features"] = end_points["fp2_features"]
-        if tokenized is None:
-            tokenized = self.tokenize(inputs)
+    def _run_text_tower(self, tokenized, end_points):
         encoded_text = self.text_encoder(**tokenized)
         end_points["text_feats"] = self.text_projector(encoded_text.last_hidden_state)
         # HF masks are 1 = token; torch attention wants True = padding (bdetr.py:171)
         end_points["text_attention_mask"] = tokenized.attention_mask.ne(1).bool()
         end_points["tokenized"] = tokenized
+
+    def _run_backbones(self, inputs, tokenized=None):
+        """Visual and text towers.  They are independent until the cross-encoder, and the FPS chain of
+        the point backbone is a long serial kernel on a handful of CUs -- so on a GPU the text tower is
+        issued on a side stream and joins before the encoder (fork/join is capturable in a hipGraph)."""
+        if tokenized is None:
+            tokenized = self.tokenize(inputs)
+        pc = inputs["point_clouds"]
+        text_out = {}
+        if pc.is_cuda and self.overlap_text_tower:
+            main = torch.cuda.current_stream(pc.device)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(pc.device)
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._run_text_tower(tokenized, text_out)
+            end_points = self.backbone_net(pc, end_points={})
+            main.wait_stream(side)
+            for v in (text_out["text_feats"], text_out["text_attention_mask"]):
+                v.record_stream(main)
+        else:
+            end_points = self.backbone_net(pc, end_points={})
+            self._run_text_tower(tokenized, text_out)
+        end_points["seed_inds"] = end_points["fp2_inds"]
+        end_points["seed_xyz"] = end_points["fp2_xyz"]
+        end_points["seed_features"] = end_points["fp2_features"]
+        end_points.update(text_out)
         return end_points
 
     def _generate_queries(self, xyz, features, end_points):

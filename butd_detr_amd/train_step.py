@@ -105,23 +105,33 @@ def wrap_data_parallel(model, device):
 
 
 class FlatGradients:
-    """All trainable gradients as views into ONE contiguous fp32 buffer, so the data-parallel exchange
-    is a single large all-reduce (85.7 MB for the full model) instead of 601 small ones -- the
-    message size RCCL's ring over the 7 xGMI links is efficient at.  Autograd
-    accumulates in place into existing ``.grad`` tensors, so the views survive ``backward()``."""
+    """One contiguous fp32 buffer holding every trainable gradient, so the data-parallel exchange is a
+    single large all-reduce (85.7 MB for the full model) instead of 601 small ones -- the message size
+    RCCL's ring over the 7 xGMI links is efficient at.  ``views[i]`` aliases the
+    slice of parameter i; ``gather`` fills the buffer from freshly produced ``.grad`` tensors with
+    multi-tensor copies (a handful of launches), after which the parameters' ``.grad`` point at the
+    views so clip/AdamW read the reduced values in place."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=torch.float32, device=ref.device)
-        off = 0
+        self.views, off = [], 0
         for p in self.params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
-    def zero_(self):
-        self.flat.zero_()
+    def gather(self, grads):
+        torch._foreach_copy_(self.views, grads)
+
+    def attach(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def detach(self):
+        for p in self.params:
+            p.grad = None
 
     def all_reduce_mean(self, group=None):
         import torch.distributed as dist
@@ -132,8 +142,9 @@ class FlatGradients:
 
 class GraphedTrainStep:
     """The whole iteration as hipGraph replays: tokenise on the host, copy into static buffers, replay
-    ``forward_tokenized -> surrogate loss -> backward`` (graph 1), all-reduce the flat gradient buffer
-    across ranks (outside the graph; skipped at world size 1), replay ``clip -> AdamW`` (graph 2).
+    ``forward_tokenized -> surrogate loss -> backward -> gather grads into the flat buffer`` (graph 1),
+    all-reduce the flat buffer across ranks (outside the graph; skipped at world size 1), replay
+    ``clip -> AdamW`` on the flat views (graph 2).
 
     Eager PyTorch launches ~4 900 kernels per step here and is host-bound ("HIP streams and
     graphs instead of a tracing compiler"); a graph replay removes the launch overhead without
@@ -150,13 +161,15 @@ class GraphedTrainStep:
     def _fwd_bwd(self):
         end_points = self.model.forward_tokenized(self.s_inputs, self.s_tok)
         loss = surrogate_loss(end_points, self.s_targets)
-        self.flat.zero_()
+        self.flat.detach()                      # fresh .grad tensors: no per-parameter accumulate
         loss.backward()
+        self.flat.gather([p.grad for p in self.flat.params])
         return loss.detach()
 
     def _update(self):
+        self.flat.attach()
         if self.clip_norm:
-            torch.nn.utils.clip_grad_norm_(self.flat.params, self.clip_norm, foreach=True)
+            torch.nn.utils.clip_grad_norm_(self.flat.views, self.clip_norm, foreach=True)
         self.optimizer.step()
 
     def _copy_in(self, inputs, targets, tok):
