@@ -35,6 +35,13 @@ def get_backend():
     return _BACKEND
 
 
+def new_step(device):
+    """Called once per model forward: advances the fused kernels' dropout step counter."""
+    if _BACKEND == "hip" and torch.device(device).type == "cuda":
+        from . import fused_attention
+        fused_attention.new_step(torch.device(device))
+
+
 def _mha_torch(attn, query, key, value, key_padding_mask):
     b, lq, d = query.shape
     lk = key.shape[1]

@@ -20,6 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import attention_blocks
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer
 from .modules import (ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule,
@@ -178,6 +179,7 @@ class BeaUTyDETR(nn.Module):
     def forward_tokenized(self, inputs, tokenized):
         """Device-side forward given an already tokenised (and device-resident) utterance batch;
         ``tokenized=None`` tokenises here (the reference behaviour)."""
+        attention_blocks.new_step(inputs["point_clouds"].device)
         end_points = self._run_backbones(inputs, tokenized)
         points_xyz = end_points["fp2_xyz"]                       # (B, V, 3)
         points_features = end_points["fp2_features"]             # (B, d, V)

@@ -1,0 +1,283 @@
+"""Fused attention / FFN blocks on the gfx950 kernels of include/butd_attention.h.
+
+One ``autograd.Function`` per *block* (not per op): the forward of
+``LayerNorm(residual + Dropout(MHA(query, key, value)))`` is 4 launches -- grouped Q/K/V projection
+(fp32 MFMA GEMM, ``src + pos`` folded into the operand load, ``1/sqrt(head_dim)`` and bias in the
+epilogue), flash-style attention core, output projection, residual+dropout+LayerNorm -- and the
+hand-written backward is 7; ``LayerNorm(x + FFN(x))`` is 3 + 3.  The stock-torch chain behind the
+same reference code (encoder_decoder_layers.py:87-122,149-155,179-185,356-404) is ~25 + ~50 launches
+per block, which is what made the 45 attention blocks of a step launch-bound.
+
+Dropout masks come from a counter-based hash (csrc/rng.h): nothing is stored, backward regenerates
+them from (step counter, site id, element index).  ``new_step()`` bumps the device-resident counter
+once per model forward, so a captured hipGraph draws fresh masks on every replay.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _hiplib
+from ._hiplib import GemmProblem
+
+_lib = _hiplib.load()
+
+_rng_counters = {}
+_site = [0]
+
+
+def rng_counter(device):
+    t = _rng_counters.get(device)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int64, device=device)
+        _rng_counters[device] = t
+    return t
+
+
+def new_step(device):
+    """Advance the dropout step counter (device-side add: capturable) and restart site numbering."""
+    rng_counter(device).add_(1)
+    _site[0] = 0
+
+
+def _next_site():
+    _site[0] += 1
+    return _site[0]
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.0, bias=None,
+             bias_grad=None, scale=1.0, relu=False, accumulate=False, ones_col=False, split_k=1,
+             dropout_p=0.0, site=0):
+    return GemmProblem(_ptr(a), _ptr(a2), _ptr(b), _ptr(bias), _ptr(c), _ptr(bias_grad), M, N, K,
+                       lda[0], lda[1], ldb[0], ldb[1], ldc, scale, a2_mode, a2_scale, int(relu),
+                       int(accumulate), int(ones_col), split_k, dropout_p, site)
+
+
+def _gemm(problems, ref):
+    arr = (GemmProblem * len(problems))(*problems)
+    with torch.cuda.device(ref.device):
+        err = _lib.butd_gemm_grouped(arr, len(problems), rng_counter(ref.device).data_ptr(), _stream(ref))
+    _hiplib.check(err, "butd_gemm_grouped")
+
+
+# operand descriptors ------------------------------------------------------------------------------
+def _fwd(x, w, y, M, N, K, **kw):
+    """y[M,N] = x[M,K] @ w[N,K]^T (both contraction-contiguous)."""
+    return _problem(x, w, y, M, N, K, (K, 1), (K, 1), N, **kw)
+
+
+def _dgrad(dy, w, dx, M, N, K, **kw):
+    """dx[M,K] = dy[M,N] @ w[N,K]: contraction over N; B(col=k, n) = w[n*K + k]."""
+    return _problem(dy, w, dx, M, K, N, (N, 1), (1, K), K, **kw)
+
+
+def _wgrad(dy, x, dw, db, M, N, K, **kw):
+    """dw[N,K] += dy[M,N]^T @ x[M,K], db[N] += column sums of dy: contraction over M (split-K)."""
+    split = max(1, min(32, M // 256))
+    return _problem(dy, x, dw, N, K, M, (1, N), (1, K), K, bias_grad=db, ones_col=db is not None,
+                    accumulate=True, split_k=split, **kw)
+
+
+def _check(*tensors):
+    for t in tensors:
+        if t is not None:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
+                "fused attention kernels take contiguous fp32 CUDA tensors"
+
+
+class _AttentionBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, residual, xq, xk, xv, mask, w_in, b_in, w_o, b_o, gamma, beta,
+                num_heads, eps, p_attn, p_out, site_attn, site_out):
+        B, Lq, E = xq.shape
+        Lk = xk.shape[1]
+        H, D = num_heads, E // num_heads
+        Mq, Mk = B * Lq, B * Lk
+        dev = xq.device
+        q = torch.empty((B, Lq, E), device=dev)
+        k = torch.empty((B, Lk, E), device=dev)
+        v = torch.empty((B, Lk, E), device=dev)
+        scale = math.sqrt(1.0 / float(D))
+        _gemm([_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale),
+               _fwd(xk, w_in[E:2 * E], k, Mk, E, E, bias=b_in[E:2 * E]),
+               _fwd(xv, w_in[2 * E:], v, Mk, E, E, bias=b_in[2 * E:])], xq)
+        att = torch.empty((B, Lq, E), device=dev)
+        lse = torch.empty((B, H, Lq), device=dev)
+        with torch.cuda.device(dev):
+            err = _lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                          _ptr(mask), att.data_ptr(), lse.data_ptr(), p_attn, site_attn,
+                                          rng_counter(dev).data_ptr(), _stream(xq))
+        _hiplib.check(err, "butd_attention_fwd")
+        proj = torch.empty((B, Lq, E), device=dev)
+        _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], xq)
+        y = torch.empty((B, Lq, E), device=dev)
+        mean = torch.empty((Mq,), device=dev)
+        rstd = torch.empty((Mq,), device=dev)
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_fwd(
+                Mq, E, proj.data_ptr(), residual.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
+                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
+                rng_counter(dev).data_ptr(), _stream(xq))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
+        ctx.save_for_backward(residual, xq, xk, xv, mask, w_in, w_o, gamma, q, k, v, att, lse, proj,
+                              mean, rstd)
+        ctx.cfg = (H, p_attn, p_out, site_attn, site_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (residual, xq, xk, xv, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean,
+         rstd) = ctx.saved_tensors
+        H, p_attn, p_out, site_attn, site_out = ctx.cfg
+        B, Lq, E = xq.shape
+        Lk = xk.shape[1]
+        D = E // H
+        Mq, Mk = B * Lq, B * Lk
+        dev = xq.device
+        dy = dy.contiguous()
+        # one zero-filled slab for everything that is accumulated with atomics
+        slab = torch.zeros(3 * E * E + 3 * E + E * E + E + 2 * E, device=dev)
+        o = 0
+        d_w_in = slab[o:o + 3 * E * E].view(3 * E, E); o += 3 * E * E
+        d_b_in = slab[o:o + 3 * E]; o += 3 * E
+        d_w_o = slab[o:o + E * E].view(E, E); o += E * E
+        d_b_o = slab[o:o + E]; o += E
+        d_gamma = slab[o:o + E]; o += E
+        d_beta = slab[o:o + E]
+        d_res = torch.empty((B, Lq, E), device=dev)
+        d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else d_res
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_bwd(
+                Mq, E, dy.data_ptr(), proj.data_ptr(), residual.data_ptr(), gamma.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr(), d_proj.data_ptr(), d_res.data_ptr(),
+                d_gamma.data_ptr(), d_beta.data_ptr(), p_out, site_out, rng_counter(dev).data_ptr(),
+                _stream(xq))
+        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        d_att = torch.empty((B, Lq, E), device=dev)
+        _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
+               _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], xq)
+        dq = torch.empty((B, Lq, E), device=dev)
+        dk = torch.empty((B, Lk, E), device=dev)
+        dv = torch.empty((B, Lk, E), device=dev)
+        delta = torch.empty((B, H, Lq), device=dev)
+        with torch.cuda.device(dev):
+            err = _lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                          _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
+                                          delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                                          p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(xq))
+        _hiplib.check(err, "butd_attention_bwd")
+        scale = math.sqrt(1.0 / float(D))
+        d_xq = torch.empty((B, Lq, E), device=dev)
+        d_xk = torch.empty((B, Lk, E), device=dev)
+        d_xv = torch.empty((B, Lk, E), device=dev)
+        _gemm([_dgrad(dq, w_in[:E], d_xq, Mq, E, E, scale=scale),
+               _dgrad(dk, w_in[E:2 * E], d_xk, Mk, E, E),
+               _dgrad(dv, w_in[2 * E:], d_xv, Mk, E, E)], xq)
+        _gemm([_wgrad(dq, xq, d_w_in[:E], d_b_in[:E], Mq, E, E, scale=scale),
+               _wgrad(dk, xk, d_w_in[E:2 * E], d_b_in[E:2 * E], Mk, E, E),
+               _wgrad(dv, xv, d_w_in[2 * E:], d_b_in[2 * E:], Mk, E, E)], xq)
+        return (d_res, d_xq, d_xk, d_xv, None, d_w_in, d_b_in, d_w_o, d_b_o, d_gamma, d_beta,
+                None, None, None, None, None, None)
+
+
+class _FfnBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, p2, site1, site2):
+        B, L, E = x.shape
+        Fh = w1.shape[0]
+        M = B * L
+        dev = x.device
+        h = torch.empty((B, L, Fh), device=dev)
+        _gemm([_fwd(x, w1, h, M, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
+        o = torch.empty((B, L, E), device=dev)
+        _gemm([_fwd(h, w2, o, M, E, Fh, bias=b2)], x)
+        y = torch.empty((B, L, E), device=dev)
+        mean = torch.empty((M,), device=dev)
+        rstd = torch.empty((M,), device=dev)
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_fwd(
+                M, E, o.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
+        ctx.save_for_backward(x, w1, w2, gamma, h, o, mean, rstd)
+        ctx.cfg = (p1, p2, site1, site2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2, gamma, h, o, mean, rstd = ctx.saved_tensors
+        p1, p2, site1, site2 = ctx.cfg
+        B, L, E = x.shape
+        Fh = w1.shape[0]
+        M = B * L
+        dev = x.device
+        dy = dy.contiguous()
+        slab = torch.zeros(Fh * E + Fh + E * Fh + E + 2 * E, device=dev)
+        off = 0
+        d_w1 = slab[off:off + Fh * E].view(Fh, E); off += Fh * E
+        d_b1 = slab[off:off + Fh]; off += Fh
+        d_w2 = slab[off:off + E * Fh].view(E, Fh); off += E * Fh
+        d_b2 = slab[off:off + E]; off += E
+        d_gamma = slab[off:off + E]; off += E
+        d_beta = slab[off:off + E]
+        d_x = torch.empty((B, L, E), device=dev)          # residual path first, FFN path accumulates
+        d_o = torch.empty((B, L, E), device=dev)
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_bwd(
+                M, E, dy.data_ptr(), o.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                rstd.data_ptr(), d_o.data_ptr(), d_x.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
+                p2, site2, rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        d_h = torch.empty((B, L, Fh), device=dev)
+        _gemm([_dgrad(d_o, w2, d_h, M, E, Fh),
+               _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)], x)
+        gate = 1.0 / (1.0 - p1) if p1 > 0 else 1.0        # h = relu(z) * keep / (1-p): h > 0 <=> live
+        _gemm([_dgrad(d_h, w1, d_x, M, Fh, E, a2=h, a2_mode=1, a2_scale=gate, accumulate=True),
+               _wgrad(d_h, x, d_w1, d_b1, M, Fh, E, a2=h, a2_mode=1, a2_scale=gate)], x)
+        return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None
+
+
+def _as_mask(mask):
+    if mask is None:
+        return None
+    m = mask if mask.dtype == torch.bool else mask.bool()
+    return m.contiguous()
+
+
+def attention_block(attn, dropout, norm, residual, query, key, value, key_padding_mask=None):
+    """LayerNorm(residual + Dropout(MHA(query, key, value)))."""
+    training = attn.training
+    p_attn = float(attn.dropout) if training else 0.0
+    p_out = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
+    residual, query, key, value = (t.contiguous() for t in (residual, query, key, value))
+    _check(residual, query, key, value)
+    return _AttentionBlock.apply(
+        residual, query, key, value, _as_mask(key_padding_mask),
+        attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
+        norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
+        _next_site(), _next_site())
+
+
+def ffn_block(ffn, norm, x):
+    """LayerNorm(x + FFN(x)); ffn = Sequential(Linear, ReLU, Dropout, Linear, Dropout)."""
+    lin1, _, drop1, lin2, drop2 = ffn
+    p1 = float(drop1.p) if drop1.training else 0.0
+    p2 = float(drop2.p) if drop2.training else 0.0
+    x = x.contiguous()
+    _check(x)
+    return _FfnBlock.apply(x, lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm.weight, norm.bias,
+                           float(norm.eps), p1, p2, _next_site(), _next_site())
+
+
+def multi_head_attention(attn, query, key, value, key_padding_mask=None):
+    """Bare MHA (no residual / norm) -- not on the model's path; routed through the torch maths."""
+    from . import attention_blocks
+    return attention_blocks._mha_torch(attn, query, key, value, key_padding_mask)

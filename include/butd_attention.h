@@ -1,0 +1,85 @@
+/*
+ * butd_attention.h -- C ABI of the fused cross-modal attention / FFN kernels (gfx950, fp32 MFMA).
+ *
+ * These replace the stock-torch op chains behind nn.MultiheadAttention / nn.Linear / nn.LayerNorm at
+ * the reference call sites models/encoder_decoder_layers.py:47-73,87-122,133-155,297-330,356-404
+ * (arithmetic: torch/nn/functional.py multi_head_attention_forward).  All tensors are dense fp32,
+ * row-major, batch-first; pointers are device pointers; `stream` is a hipStream_t; every call is an
+ * asynchronous launch that neither allocates nor synchronises (hipGraph-capturable); return value 0
+ * or a hipError_t.
+ */
+#ifndef BUTD_ATTENTION_H
+#define BUTD_ATTENTION_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *butd_stream_t; /* hipStream_t */
+
+/* One dense problem   C[M,N] (op)= epilogue( sum_k A(m,k) * B(n,k) ).
+ * A(m,k) = a[m*lda_m + k*lda_k], combined with a2[...] (same strides) when a2 != NULL:
+ *          a2_mode 0: a + a2 (e.g. src + pos);  a2_mode 1: a * (a2 > 0 ? a2_scale : 0)  (ReLU/dropout gate),
+ * B(n,k) = b[n*ldb_n + k*ldb_k];  exactly one of each stride pair is 1 (the contiguous one).
+ * epilogue(v) = relu?( (v + bias[n]) * scale ) , optionally * dropout keep-mask / (1-p);
+ * accumulate != 0 adds into C with atomics (used with split_k > 1 for weight gradients).
+ * ones_col != 0: B gets a virtual extra column n == N of ones whose results are atomically added to
+ * bias_grad[m] instead of C (column sums -> bias gradient in the same pass). */
+typedef struct {
+  const float *a, *a2, *b, *bias;
+  float *c, *bias_grad;
+  int M, N, K;
+  long lda_m, lda_k, ldb_n, ldb_k, ldc;
+  float scale;
+  int a2_mode;
+  float a2_scale;
+  int relu, accumulate, ones_col, split_k;
+  float dropout_p;        /* 0 = off */
+  uint32_t dropout_site;  /* stream id of the counter-based RNG */
+} butd_gemm_problem;
+
+/* Launches up to 4 independent problems in ONE grid (blockIdx.z selects the problem).
+ * rng_counter: device pointer to a uint64 step counter (may be NULL when no problem uses dropout). */
+int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64_t *rng_counter,
+                      butd_stream_t stream);
+
+/* Scaled-dot-product attention core for head_dim <= 48 (BUTD-DETR: 8 heads x 36).
+ * q (B,Lq,H*D) already scaled by 1/sqrt(D) (the projection's epilogue does it), k, v (B,Lk,H*D);
+ * key_padding_mask (B,Lk) uint8, nonzero = masked (may be NULL); out (B,Lq,H*D);
+ * lse (B,H,Lq) = log-sum-exp of each score row (saved for backward).
+ * Dropout with probability dropout_p on the softmax probabilities (0 = off). */
+int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                       const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
+                       float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                       butd_stream_t stream);
+
+/* Backward of the above.  delta (B,H,Lq) scratch; dq (B,Lq,H*D), dk, dv (B,Lk,H*D) are overwritten. */
+int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                       const float *v, const uint8_t *key_padding_mask, const float *out,
+                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                       float *dv, float dropout_p, uint32_t dropout_site,
+                       const uint64_t *rng_counter, butd_stream_t stream);
+
+/* y = LayerNorm(residual + dropout(x)) over the last dim (cols <= 1024), eps as nn.LayerNorm.
+ * Saves mean/rstd (rows) for backward. */
+int butd_add_dropout_layernorm_fwd(int rows, int cols, const float *x, const float *residual,
+                                   const float *gamma, const float *beta, float eps, float *y,
+                                   float *mean, float *rstd, float dropout_p, uint32_t dropout_site,
+                                   const uint64_t *rng_counter, butd_stream_t stream);
+
+/* Backward: given dy and the saved statistics, produces d_residual (= d of the pre-norm sum) and
+ * dx (= d_residual * dropout mask / (1-p)); accumulates dgamma/dbeta (cols) with atomics
+ * (caller zero-fills them).  dx may alias d_residual when dropout_p == 0. */
+int butd_add_dropout_layernorm_bwd(int rows, int cols, const float *dy, const float *x,
+                                   const float *residual, const float *gamma, const float *mean,
+                                   const float *rstd, float *dx, float *d_residual, float *dgamma,
+                                   float *dbeta, float dropout_p, uint32_t dropout_site,
+                                   const uint64_t *rng_counter, butd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUTD_ATTENTION_H */

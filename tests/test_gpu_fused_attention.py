@@ -1,0 +1,172 @@
+"""-m gpu: fused gfx950 attention / FFN blocks vs the plain-torch maths (the arithmetic of
+torch.nn.functional.multi_head_attention_forward), forward and backward, tolerance 1e-3 fp32
+(north_star).  Dropout is checked for determinism, keep-rate and fwd/bwd mask consistency."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    assert torch.cuda.is_available()
+    from butd_detr_amd import attention_blocks as ab
+    from butd_detr_amd import fused_attention as fa
+    from butd_detr_amd.encoder_decoder_layers import MultiheadAttention, _ffn
+    return ab, fa, MultiheadAttention, _ffn
+
+
+def _close(a, b, tol=1e-3):
+    a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+    scale = max(np.abs(b).max(), 1e-6)
+    np.testing.assert_allclose(a / scale, b / scale, rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("B,Lq,Lk,masked", [(2, 64, 64, False), (2, 80, 1024, False), (3, 1024, 80, True),
+                                            (2, 256, 132, True), (1, 17, 5, True), (2, 100, 100, True)])
+def test_attention_block_matches_torch(mods, B, Lq, Lk, masked):
+    ab, fa, MHA, _ = mods
+    torch.manual_seed(Lq + Lk)
+    E, H = 288, 8
+    attn = MHA(E, H, dropout=0.1).cuda().eval()
+    with torch.no_grad():
+        attn.in_proj_bias.uniform_(-0.1, 0.1)
+        attn.out_proj.bias.uniform_(-0.1, 0.1)
+    norm = torch.nn.LayerNorm(E).cuda()
+    with torch.no_grad():
+        norm.weight.uniform_(0.8, 1.2)
+        norm.bias.uniform_(-0.1, 0.1)
+    drop = torch.nn.Dropout(0.1).eval()
+    self_attn = Lq == Lk
+    res = torch.randn(B, Lq, E, device="cuda", requires_grad=True)
+    xq = torch.randn(B, Lq, E, device="cuda", requires_grad=True)
+    xk = xq if self_attn else torch.randn(B, Lk, E, device="cuda", requires_grad=True)
+    xv = torch.randn(B, Lk, E, device="cuda", requires_grad=True)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+        for b in range(B):
+            mask[b, Lk - 1 - b:] = True
+    probe = torch.randn(B, Lq, E, device="cuda")
+    params = list(attn.parameters()) + list(norm.parameters())
+
+    def run(fn):
+        for t in [res, xq, xk, xv] + params:
+            t.grad = None
+        y = fn(attn, drop, norm, residual=res, query=xq, key=xk, value=xv, key_padding_mask=mask)
+        (y * probe).sum().backward()
+        return y, [t.grad.clone() for t in ([res, xq, xv] + ([] if self_attn else [xk]) + params)]
+
+    y_ref, g_ref = run(lambda a, d, n, **kw: n(kw["residual"] + d(ab._mha_torch(a, kw["query"], kw["key"], kw["value"], kw["key_padding_mask"]))))
+    y_hip, g_hip = run(lambda a, d, n, **kw: fa.attention_block(a, d, n, kw["residual"], kw["query"], kw["key"], kw["value"], kw["key_padding_mask"]))
+    _close(y_hip, y_ref)
+    for gh, gr in zip(g_hip, g_ref):
+        _close(gh, gr, 2e-3)
+
+
+def test_fully_masked_row_is_nan_like_torch(mods):
+    ab, fa, MHA, _ = mods
+    attn = MHA(288, 8, dropout=0.0).cuda().eval()
+    norm = torch.nn.LayerNorm(288).cuda()
+    x = torch.randn(2, 16, 288, device="cuda")
+    kv = torch.randn(2, 10, 288, device="cuda")
+    mask = torch.zeros(2, 10, dtype=torch.bool, device="cuda")
+    mask[1] = True
+    y = fa.attention_block(attn, None, norm, x, x, kv, kv, mask)
+    ref = norm(x + ab._mha_torch(attn, x, kv, kv, mask))
+    assert torch.isnan(y[1]).all() and torch.isnan(ref[1]).all()
+    _close(y[0], ref[0])
+
+
+@pytest.mark.parametrize("B,L", [(2, 80), (8, 1024), (1, 7)])
+def test_ffn_block_matches_torch(mods, B, L):
+    ab, fa, _, make_ffn = mods
+    torch.manual_seed(L)
+    E = 288
+    ffn = make_ffn(E, 256, 0.1).cuda().eval()
+    norm = torch.nn.LayerNorm(E).cuda()
+    x = torch.randn(B, L, E, device="cuda", requires_grad=True)
+    probe = torch.randn(B, L, E, device="cuda")
+    params = list(ffn.parameters()) + list(norm.parameters())
+
+    def run(fn):
+        for t in [x] + params:
+            t.grad = None
+        y = fn(x)
+        (y * probe).sum().backward()
+        return y, [t.grad.clone() for t in [x] + params]
+
+    y_ref, g_ref = run(lambda t: norm(t + ffn(t)))
+    y_hip, g_hip = run(lambda t: fa.ffn_block(ffn, norm, t))
+    _close(y_hip, y_ref)
+    for gh, gr in zip(g_hip, g_ref):
+        _close(gh, gr, 2e-3)
+
+
+def test_dropout_is_deterministic_per_step_and_consistent_between_fwd_and_bwd(mods):
+    ab, fa, MHA, make_ffn = mods
+    torch.manual_seed(0)
+    E = 288
+    ffn = make_ffn(E, 256, 0.1).cuda().train()
+    norm = torch.nn.LayerNorm(E).cuda()
+    x = torch.randn(4, 256, E, device="cuda", requires_grad=True)
+    dev = x.device
+
+    def f(t):
+        fa._site[0] = 100            # same sites -> same masks within a step
+        return fa.ffn_block(ffn, norm, t)
+
+    fa.new_step(dev)
+    y1 = f(x)
+    y2 = f(x)
+    assert torch.equal(y1, y2)
+    # directional derivative vs autograd: masks must be identical in forward and backward
+    v = torch.randn_like(x)
+    probe = torch.randn_like(x)
+    (y1 * probe).sum().backward()
+    analytic = (x.grad * v).sum().item()
+    eps = 1e-2
+    with torch.no_grad():
+        num = (((f(x + eps * v) - f(x - eps * v)) / (2 * eps)) * probe).sum().item()
+    assert abs(num - analytic) <= 3e-2 * max(abs(analytic), 1.0)
+    fa.new_step(dev)
+    y3 = f(x)
+    assert not torch.equal(y1, y3)   # a new step draws a new mask
+
+
+def test_attention_dropout_keep_rate(mods):
+    ab, fa, MHA, _ = mods
+    attn = MHA(288, 8, dropout=0.3).cuda().train()
+    norm = torch.nn.LayerNorm(288).cuda()
+    with torch.no_grad():            # V projection = identity-ish probe: out = mean of kept probs
+        attn.in_proj_weight.zero_()
+        attn.in_proj_bias.zero_()
+        attn.in_proj_bias[2 * 288:] = 1.0      # every value vector = ones -> context = sum of kept p/(1-p)
+        attn.out_proj.weight.copy_(torch.eye(288))
+        attn.out_proj.bias.zero_()
+    x = torch.randn(2, 512, 288, device="cuda")
+    fa.new_step(x.device)
+    q = torch.zeros_like(x)
+    # uniform attention (q = 0): context = (1/Lk) * sum_k keep_k/(1-p); expectation 1, variance small
+    out = fa._AttentionBlock.apply(torch.zeros_like(x), q, x, x, None, attn.in_proj_weight, attn.in_proj_bias,
+                                   attn.out_proj.weight, attn.out_proj.bias, torch.ones(288, device="cuda"),
+                                   torch.zeros(288, device="cuda"), 8, 0.0, 0.3, 0.0, 7, 8)
+    # LayerNorm of a constant row is 0; instead read the pre-norm via a second call without norm effect
+    # -> check through the saved context statistics: rerun the core directly
+    import ctypes
+    from butd_detr_amd import _hiplib
+    lib = _hiplib.load()
+    B, L, E, H, D = 2, 512, 288, 8, 36
+    qq = torch.zeros(B, L, E, device="cuda")
+    kk = torch.zeros(B, L, E, device="cuda")
+    vv = torch.ones(B, L, E, device="cuda")
+    o = torch.empty(B, L, E, device="cuda")
+    lse = torch.empty(B, H, L, device="cuda")
+    err = lib.butd_attention_fwd(B, H, L, L, D, qq.data_ptr(), kk.data_ptr(), vv.data_ptr(), None, o.data_ptr(),
+                                 lse.data_ptr(), 0.3, 11, fa.rng_counter(x.device).data_ptr(),
+                                 torch.cuda.current_stream().cuda_stream)
+    assert err == 0
+    torch.cuda.synchronize()
+    assert abs(o.mean().item() - 1.0) < 0.01
+    assert 0.02 < o.std().item() < 0.06          # sqrt(p/(1-p)/Lk) = 0.029

@@ -1,0 +1,141 @@
+"""-m gpu: the build's modules ON THE GPU (HIP operators + fused attention kernels) vs the golden vectors
+captured from the reference (tests/golden/make_golden.py).  Tolerance: north_star's 1e-3 fp32 on
+outputs, bit-exact indices."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import text_stub, weights
+from tests.golden.cases import (backbone_inputs, bdetr_inputs, decoder_inputs, encoder_inputs,
+                                probe)
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def close(t, ref, tol=1e-3):
+    a = t.detach().float().cpu().numpy()
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    np.testing.assert_allclose(a / scale, ref / scale, rtol=0, atol=tol)
+
+
+def cuda(d):
+    return {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+@pytest.fixture(params=["torch", "hip"])
+def backend(request):
+    from butd_detr_amd import attention_blocks
+    prev = attention_blocks.get_backend()
+    attention_blocks.set_backend(request.param)
+    yield request.param
+    attention_blocks.set_backend(prev)
+
+
+def test_encoder_golden(backend):
+    from butd_detr_amd.encoder_decoder_layers import BiEncoder, BiEncoderLayer
+    g = load("encoder_small.npz")
+    layer = BiEncoderLayer(288, dropout=0.1, activation="relu", n_heads=8, dim_feedforward=256,
+                           self_attend_lang=True, self_attend_vis=True, use_butd_enc_attn=True)
+    model = weights.fill_(BiEncoder(layer, 3), seed=11).cuda().eval()
+    inp = cuda(encoder_inputs())
+    for k in ("vis", "text", "pos", "boxes"):
+        inp[k].requires_grad_(True)
+    vis_out, text_out = model(inp["vis"], inp["pos"], inp["vis_mask"], inp["text"], inp["text_mask"],
+                              {}, detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
+    close(vis_out, g["vis_out"])
+    close(text_out, g["text_out"])
+    ((vis_out * probe(vis_out.shape, 1).cuda()).sum() + (text_out * probe(text_out.shape, 2).cuda()).sum()).backward()
+    close(inp["vis"].grad, g["g_vis"], 2e-3)
+    close(inp["text"].grad, g["g_text"], 2e-3)
+    close(inp["pos"].grad, g["g_pos"], 2e-3)
+    close(inp["boxes"].grad, g["g_boxes"], 2e-3)
+    p = dict(model.named_parameters())
+    close(p["layers.0.cross_layer.cross_lv.in_proj_weight"].grad, g["g_l0_cross_lv_in_proj_weight"], 2e-3)
+    close(p["layers.2.self_attention_visual.self_attn.out_proj.weight"].grad,
+          g["g_l2_self_attention_visual_out_proj_weight"], 2e-3)
+    close(p["layers.1.cross_layer.ffn_vl.0.weight"].grad, g["g_l1_ffn_vl_0_weight"], 2e-3)
+    close(p["layers.1.cross_layer.norm_d.weight"].grad, g["g_l1_norm_d_weight"], 2e-3)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_decoder_layer_golden(backend, mode):
+    from butd_detr_amd.encoder_decoder_layers import BiDecoderLayer
+    g = load(f"decoder_small_{mode}.npz")
+    layer = BiDecoderLayer(288, n_heads=8, dim_feedforward=256, dropout=0.1 if mode == "eval" else 0.0,
+                           activation="relu", self_position_embedding="loc_learned", butd=True)
+    weights.fill_(layer, seed=12).cuda()
+    layer.train(mode == "train")
+    inp = cuda(decoder_inputs())
+    for k in ("query", "vis", "text", "boxes"):
+        inp[k].requires_grad_(True)
+    out = layer(inp["query"], inp["vis"], inp["text"], inp["query_pos"], None, inp["text_mask"],
+                detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
+    close(out, g["out"])
+    (out * probe(out.shape, 3).cuda()).sum().backward()
+    close(inp["query"].grad, g["g_query"], 2e-3)
+    close(inp["vis"].grad, g["g_vis"], 2e-3)
+    close(inp["text"].grad, g["g_text"], 2e-3)
+    close(inp["boxes"].grad, g["g_boxes"], 2e-3)
+    p = dict(layer.named_parameters())
+    close(p["cross_v.in_proj_weight"].grad, g["g_cross_v_in_proj_weight"], 2e-3)
+    close(p["self_posembed.position_embedding_head.0.weight"].grad, g["g_self_posembed_0_weight"], 2e-3)
+    close(p["ffn.3.weight"].grad, g["g_ffn_3_weight"], 2e-3)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_backbone_golden(mode):
+    from butd_detr_amd.backbone_module import Pointnet2Backbone
+    g = load(f"backbone_4096_{mode}.npz")
+    net = weights.fill_(Pointnet2Backbone(input_feature_dim=3, width=1), seed=13).cuda()
+    net.train(mode == "train")
+    ep = net(backbone_inputs().cuda(), end_points={})
+    for k in ("sa1_inds", "sa2_inds", "fp2_inds"):
+        np.testing.assert_array_equal(ep[k].cpu().numpy(), g[k])
+    np.testing.assert_array_equal(ep["sa1_xyz"].cpu().numpy(), g["sa1_xyz"])
+    np.testing.assert_array_equal(ep["sa4_xyz"].cpu().numpy(), g["sa4_xyz"])
+    close(ep["sa1_features"][:, :, :64], g["sa1_features_head"])
+    close(ep["sa2_features"][:, :, :64], g["sa2_features_head"])
+    close(ep["sa4_features"], g["sa4_features"])
+    close(ep["fp2_features"][0], g["fp2_features_b0"])
+    (ep["fp2_features"] * probe(ep["fp2_features"].shape, 4).cuda()).sum().backward()
+    p = dict(net.named_parameters())
+    # weight gradients through up to 14 batch-norm layers: the GPU reduces the batch statistics in a
+    # different order than the CPU reference run, so the deepest ones get a looser (1e-2) bound
+    gtol = 1e-2 if mode == "train" else 2e-3
+    close(p["sa1.mlp_module.layer0.conv.weight"].grad, g["g_sa1_layer0_conv"], gtol)
+    close(p["sa3.mlp_module.layer2.conv.weight"].grad, g["g_sa3_layer2_conv"], gtol)
+    close(p["sa2.mlp_module.layer1.bn.bn.weight"].grad, g["g_sa2_layer1_bn_weight"], gtol)
+    close(p["fp1.mlp.layer0.conv.weight"].grad, g["g_fp1_layer0_conv"], gtol)
+    close(p["fp2.mlp.layer1.conv.weight"].grad, g["g_fp2_layer1_conv"], gtol)
+
+
+def test_bdetr_golden(backend):
+    import warnings
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    g = load("bdetr_4096_eval.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=32,
+                           num_decoder_layers=2, self_position_embedding="loc_learned",
+                           contrastive_align_loss=True, butd=True, pointnet_ckpt=None, self_attend=True,
+                           text_encoder_factory=text_stub.factory,
+                           class_embeddings_path="/nonexistent/class_embeddings3d.npy")
+    weights.fill_(model, seed=14, skip_prefixes=("text_encoder.",))
+    model.cuda().eval()
+    with torch.no_grad():
+        ep = model(cuda(bdetr_inputs()))
+    assert sorted(ep.keys()) == list(g["end_points_keys"])
+    for k in ("seed_inds", "query_points_sample_inds", "text_attention_mask"):
+        np.testing.assert_array_equal(ep[k].cpu().numpy(), g[k])
+    for k in ("seeds_obj_cls_logits", "text_feats", "text_memory", "proj_tokens", "proposal_center",
+              "proposal_pred_size", "proposal_proj_queries", "0head_center", "last_center",
+              "last_pred_size", "last_sem_cls_scores", "last_proj_queries"):
+        close(ep[k], g[k])
+    close(ep["seed_features"][0], g["seed_features_b0"])
