@@ -1,439 +1,8 @@
-// attention_ops.hip -- fp32 MFMA building blocks of the fused cross-modal attention / FFN path
-// (include/butd_attention.h).  gfx950 only.
-//
-//   gemm_kernel          grouped dense products on v_mfma_f32_16x16x4_f32 (exact fp32, 157 TF peak):
-//                        64x64 output tile per 4-wave workgroup, 32x32 per wave (2x2 MFMA tiles), BK=16,
-//                        both operands staged K-contiguous in LDS so a lane's four k-steps are ONE
-//                        ds_read_b128.  One launch serves up to 4 problems (Q/K/V projections, or the
-//                        three input-gradient products), with bias / scale / ReLU / dropout epilogues,
-//                        operand-add on load (src + pos) and a virtual ones-column for bias gradients.
-//   ln_fwd / ln_bwd      y = LayerNorm(residual + dropout(x)), one wave per row, column partial sums
-//                        for dgamma/dbeta reduced per workgroup before touching global atomics.
-//
-// The k index of a contraction may be permuted freely as long as A and B use the same permutation;
-// MFMA step s of lane-group g = lane>>4 consumes k = 4*g + s of the current 16-wide slab, which makes
-// every operand fragment 16 contiguous bytes.
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include <stdint.h>
-
-#include "../../include/butd_attention.h"
-#include "rng.h"
-
-namespace {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int kBM = 64, kBN = 64, kBK = 16, kLd = kBK + 4;  // LDS row stride 20 floats = 80 B
-constexpr int kGemmThreads = 256;
-constexpr int kMaxProblems = 4;
-
-struct GemmBatch {
-  butd_gemm_problem p[kMaxProblems];
-  int z_begin[kMaxProblems + 1];  // blockIdx.z range of each problem (split_k slices)
-  int count;
-};
-
-// Staging of a (rows x 16) operand slab, split in two so the global loads of slab i+1 are in flight
-// while the MFMAs of slab i run:  fetch_tile() -> 4 floats in registers,  commit_tile() -> LDS as
-// tile[row][k].   element(row, k) = src[row*ld_row + k*ld_k] combined with src2 (see butd_gemm_problem);
-// rows >= nrows and k >= kend read 0, except the virtual ones-row (row == nrows && ones): 1.0.
-__device__ inline float combine(float a, float a2, int mode, float gate_scale) {
-  return mode == 0 ? a + a2 : a * (a2 > 0.f ? gate_scale : 0.f);
-}
-
-struct Frag4 { float v[4]; };
-
-__device__ inline Frag4 fetch_tile(const float *__restrict__ src, const float *__restrict__ src2,
-                                   int mode2, float scale2, long ld_row, long ld_k, int row0,
-                                   int nrows, int k0, int kend, bool ones, int tid) {
-  Frag4 f;
-  f.v[0] = f.v[1] = f.v[2] = f.v[3] = 0.f;
-  if (ld_k == 1) {  // contraction-contiguous: 4 consecutive k of one row
-    const int r = tid >> 2, kq = (tid & 3) * 4;
-    const int gr = row0 + r, gk = k0 + kq;
-    if (gr < nrows) {
-      const long o = (long)gr * ld_row + gk;
-      const bool vec = (gk + 3 < kend) && ((ld_row & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
-      if (vec) {
-        const float4 q = *reinterpret_cast<const float4 *>(src + o);
-        f.v[0] = q.x; f.v[1] = q.y; f.v[2] = q.z; f.v[3] = q.w;
-        if (src2) {
-          const float4 q2 = *reinterpret_cast<const float4 *>(src2 + o);
-          f.v[0] = combine(f.v[0], q2.x, mode2, scale2); f.v[1] = combine(f.v[1], q2.y, mode2, scale2);
-          f.v[2] = combine(f.v[2], q2.z, mode2, scale2); f.v[3] = combine(f.v[3], q2.w, mode2, scale2);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (gk + i < kend)
-            f.v[i] = src2 ? combine(src[o + i], src2[o + i], mode2, scale2) : src[o + i];
-      }
-    } else if (ones && gr == nrows) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f.v[i] = (gk + i < kend) ? 1.f : 0.f;
-    }
-  } else {  // row-contiguous: 4 consecutive rows of one k
-    const int k = tid >> 4, r4 = (tid & 15) * 4;
-    const int gk = k0 + k, gr = row0 + r4;
-    if (gk < kend) {
-      const long o = (long)gk * ld_k + gr;
-      const bool vec = (gr + 3 < nrows) && ((ld_k & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
-      if (vec) {
-        const float4 q = *reinterpret_cast<const float4 *>(src + o);
-        f.v[0] = q.x; f.v[1] = q.y; f.v[2] = q.z; f.v[3] = q.w;
-        if (src2) {
-          const float4 q2 = *reinterpret_cast<const float4 *>(src2 + o);
-          f.v[0] = combine(f.v[0], q2.x, mode2, scale2); f.v[1] = combine(f.v[1], q2.y, mode2, scale2);
-          f.v[2] = combine(f.v[2], q2.z, mode2, scale2); f.v[3] = combine(f.v[3], q2.w, mode2, scale2);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (gr + i < nrows)
-            f.v[i] = src2 ? combine(src[o + i], src2[o + i], mode2, scale2) : src[o + i];
-          else if (ones && gr + i == nrows) f.v[i] = 1.f;
-        }
-      }
-    }
-  }
-  return f;
-}
-
-__device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, long ld_k, int tid) {
-  if (ld_k == 1) {
-    const int r = tid >> 2, kq = (tid & 3) * 4;
-    *reinterpret_cast<float4 *>(&tile[r][kq]) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
-  } else {  // transpose into the K-contiguous LDS image
-    const int k = tid >> 4, r4 = (tid & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) tile[r4 + i][k] = f.v[i];
-  }
-}
-
-__global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
-                                                            const uint64_t *__restrict__ rng_counter) {
-  __shared__ __attribute__((aligned(16))) float As[2][kBM][kLd];
-  __shared__ __attribute__((aligned(16))) float Bs[2][kBN][kLd];
-
-  int pi = 0;
-  while (pi + 1 < batch.count && (int)blockIdx.z >= batch.z_begin[pi + 1]) ++pi;
-  const butd_gemm_problem &P = batch.p[pi];
-  const int slice = blockIdx.z - batch.z_begin[pi];
-  const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
-  const int ncols = P.N + (P.ones_col ? 1 : 0);
-  if (m0 >= P.M || n0 >= ncols) return;
-
-  // contraction range of this split-K slice (multiples of kBK)
-  const int kslab = (P.K + kBK - 1) / kBK;
-  const int per = (kslab + P.split_k - 1) / P.split_k;
-  const int kbeg = slice * per * kBK;
-  const int kend = min(P.K, (slice + 1) * per * kBK);
-  if (kbeg >= kend && slice > 0) return;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int fr = lane & 15, fg = lane >> 4;
-
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // double-buffered LDS, one barrier per slab: slab i+1 travels global -> registers while slab i is
-  // multiplied, then lands in the other buffer
-  const bool ones = P.ones_col != 0;
-  Frag4 fa = fetch_tile(P.a, P.a2, P.a2_mode, P.a2_scale, P.lda_m, P.lda_k, m0, P.M, kbeg, kend, false, tid);
-  Frag4 fb = fetch_tile(P.b, nullptr, 0, 0.f, P.ldb_n, P.ldb_k, n0, P.N, kbeg, kend, ones, tid);
-  commit_tile(As[0], fa, P.lda_k, tid);
-  commit_tile(Bs[0], fb, P.ldb_k, tid);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += kBK) {
-    const bool more = k0 + kBK < kend;
-    if (more) {
-      fa = fetch_tile(P.a, P.a2, P.a2_mode, P.a2_scale, P.lda_m, P.lda_k, m0, P.M, k0 + kBK, kend, false, tid);
-      fb = fetch_tile(P.b, nullptr, 0, 0.f, P.ldb_n, P.ldb_k, n0, P.N, k0 + kBK, kend, ones, tid);
-    }
-    f32x4 af[2], bf[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      af[i] = *reinterpret_cast<const f32x4 *>(&As[cur][wr * 32 + i * 16 + fr][fg * 4]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[cur][wc * 32 + j * 16 + fr][fg * 4]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-    if (more) {
-      commit_tile(As[cur ^ 1], fa, P.lda_k, tid);
-      commit_tile(Bs[cur ^ 1], fb, P.ldb_k, tid);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // epilogue: lane holds C[row = fg*4 + r][col = fr] of each 16x16 tile
-  const bool drop = P.dropout_p > 0.f;
-  const float inv_keep = drop ? 1.f / (1.f - P.dropout_p) : 1.f;
-  const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 32 + j * 16 + fr;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * 32 + i * 16 + fg * 4 + r;
-        if (m >= P.M) continue;
-        float v = acc[i][j][r];
-        if (n < P.N) {
-          if (P.bias && slice == 0) v += P.bias[n];
-          v *= P.scale;
-          if (P.relu) v = fmaxf(v, 0.f);
-          if (drop)
-            v = rng::keep(ctr, P.dropout_site, (uint32_t)((long)m * P.N + n), P.dropout_p)
-                    ? v * inv_keep : 0.f;
-          float *dst = P.c + (long)m * P.ldc + n;
-          if (P.accumulate) atomicAdd(dst, v);
-          else *dst = v;
-        } else if (P.ones_col && n == P.N) {
-          atomicAdd(P.bias_grad + m, v * P.scale);
-        }
-      }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// y = LayerNorm(residual + dropout(x))
-// ------------------------------------------------------------------------------------------------
-constexpr int kLnThreads = 256;
-constexpr int kLnMaxPerLane = 16;  // cols <= 1024
-
-// wave-wide sum on the DPP crossbar: running sums inside each 16-lane row (row_shr 1/2/4/8), then
-// row_bcast:15 / row_bcast:31 carry the row totals; lane 63 holds the total, v_readlane broadcasts it.
-// (__shfl_xor would be six ds_bpermute round trips, ~100 cycles each.)
-__device__ inline float wave_sum(float v) {
-#define BUTD_ADD_DPP(CTRL, RMASK)                                                                  \
-  asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 " CTRL " row_mask:" RMASK " bank_mask:0xf" : "+v"(v))
-  BUTD_ADD_DPP("row_shr:1", "0xf");
-  BUTD_ADD_DPP("row_shr:2", "0xf");
-  BUTD_ADD_DPP("row_shr:4", "0xf");
-  BUTD_ADD_DPP("row_shr:8", "0xf");
-  BUTD_ADD_DPP("row_bcast:15", "0xa");
-  BUTD_ADD_DPP("row_bcast:31", "0xc");
-#undef BUTD_ADD_DPP
-  asm volatile("s_nop 1" ::: "memory");
-  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
-}
-
-template <int PER>
-__global__ __launch_bounds__(kLnThreads) void ln_fwd_kernel(
-    int rows, int cols, const float *__restrict__ x, const float *__restrict__ residual,
-    const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-    float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd, float dropout_p,
-    uint32_t site, const uint64_t *__restrict__ rng_counter) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (kLnThreads / 64) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bool drop = dropout_p > 0.f;
-  const float inv_keep = drop ? 1.f / (1.f - dropout_p) : 1.f;
-  const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
-  float s[PER];
-  float sum = 0.f;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int c = lane + i * 64;
-    float v = 0.f;
-    if (c < cols) {
-      float xv = x[(long)row * cols + c];
-      if (drop) xv = rng::keep(ctr, site, (uint32_t)((long)row * cols + c), dropout_p) ? xv * inv_keep : 0.f;
-      v = xv + (residual ? residual[(long)row * cols + c] : 0.f);
-    }
-    s[i] = v;
-    sum += v;
-  }
-  const float mu = wave_sum(sum) / cols;
-  float sq = 0.f;
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int c = lane + i * 64;
-    const float d = c < cols ? s[i] - mu : 0.f;
-    sq += d * d;
-  }
-  const float rs = rsqrtf(wave_sum(sq) / cols + eps);
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int c = lane + i * 64;
-    if (c < cols) y[(long)row * cols + c] = (s[i] - mu) * rs * gamma[c] + beta[c];
-  }
-  if (lane == 0) {
-    mean[row] = mu;
-    rstd[row] = rs;
-  }
-}
-
-// Each workgroup covers 64 rows (16 waves x 4 rows: short serial chains), keeps dgamma/dbeta partials
-// of its columns in registers, reduces them across its waves through LDS and issues ONE atomic per
-// column.
-constexpr int kLnRowsPerWave = 4;
-constexpr int kLnBwdThreads = 1024;
-template <int PER>
-__global__ __launch_bounds__(kLnBwdThreads) void ln_bwd_kernel(
-    int rows, int cols, const float *__restrict__ dy, const float *__restrict__ x,
-    const float *__restrict__ residual, const float *__restrict__ gamma,
-    const float *__restrict__ mean, const float *__restrict__ rstd, float *__restrict__ dx,
-    float *__restrict__ d_residual, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    float dropout_p, uint32_t site, const uint64_t *__restrict__ rng_counter) {
-  __shared__ float red[2][kLnBwdThreads / 64][64 * PER];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool drop = dropout_p > 0.f;
-  const float inv_keep = drop ? 1.f / (1.f - dropout_p) : 1.f;
-  const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
-  float g[PER], pg[PER], pb[PER];
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    const int c = lane + i * 64;
-    g[i] = c < cols ? gamma[c] : 0.f;
-    pg[i] = 0.f;
-    pb[i] = 0.f;
-  }
-  const int row0 = (blockIdx.x * (kLnBwdThreads / 64) + wave) * kLnRowsPerWave;
-  for (int rr = 0; rr < kLnRowsPerWave; ++rr) {
-    const int row = row0 + rr;
-    if (row >= rows) break;
-    const float mu = mean[row], rs = rstd[row];
-    float xh[PER], gy[PER];
-    bool kp[PER];
-    float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = lane + i * 64;
-      xh[i] = 0.f; gy[i] = 0.f; kp[i] = true;
-      if (c < cols) {
-        const long o = (long)row * cols + c;
-        float xv = x[o];
-        if (drop) {
-          kp[i] = rng::keep(ctr, site, (uint32_t)o, dropout_p);
-          xv = kp[i] ? xv * inv_keep : 0.f;
-        }
-        const float sv = xv + (residual ? residual[o] : 0.f);
-        const float d = dy[o];
-        xh[i] = (sv - mu) * rs;
-        gy[i] = d * g[i];
-        pg[i] += d * xh[i];
-        pb[i] += d;
-        c1 += gy[i];
-        c2 += gy[i] * xh[i];
-      }
-    }
-    c1 = wave_sum(c1) / cols;
-    c2 = wave_sum(c2) / cols;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int c = lane + i * 64;
-      if (c < cols) {
-        const long o = (long)row * cols + c;
-        const float ds = (gy[i] - c1 - xh[i] * c2) * rs;
-        if (d_residual) d_residual[o] = ds;
-        if (dx) dx[o] = kp[i] ? ds * inv_keep : 0.f;
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < PER; ++i) {
-    red[0][wave][lane + i * 64] = pg[i];
-    red[1][wave][lane + i * 64] = pb[i];
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < cols; c += kLnBwdThreads) {
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int w = 0; w < kLnBwdThreads / 64; ++w) {
-      a += red[0][w][c];
-      b += red[1][w][c];
-    }
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
-  }
-}
-
-}  // namespace
-
-extern "C" {
-
-int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64_t *rng_counter,
-                      butd_stream_t stream) {
-  if (count <= 0) return 0;
-  if (count > kMaxProblems) return (int)hipErrorInvalidValue;
-  GemmBatch batch;
-  int gx = 0, gy = 0, z = 0;
-  batch.count = 0;
-  for (int i = 0; i < count; ++i) {
-    butd_gemm_problem p = problems[i];
-    if (p.M <= 0 || p.N <= 0) continue;
-    if (p.split_k < 1) p.split_k = 1;
-    if (p.split_k > 1 && !p.accumulate) return (int)hipErrorInvalidValue;
-    const int ncols = p.N + (p.ones_col ? 1 : 0);
-    gx = max(gx, (ncols + kBN - 1) / kBN);
-    gy = max(gy, (p.M + kBM - 1) / kBM);
-    batch.z_begin[batch.count] = z;
-    batch.p[batch.count++] = p;
-    z += p.split_k;
-  }
-  if (batch.count == 0) return 0;
-  for (int i = batch.count; i <= kMaxProblems; ++i) batch.z_begin[i] = z;
-  hipLaunchKernelGGL(gemm_kernel, dim3(gx, gy, z), dim3(kGemmThreads), 0, (hipStream_t)stream, batch,
-                     rng_counter);
-  return (int)hipGetLastError();
-}
-
-#define LN_DISPATCH_T(THREADS, KERNEL, ...)                                                     \
-  do {                                                                                          \
-    const int per = (cols + 63) / 64;                                                           \
-    if (per <= 4) hipLaunchKernelGGL((KERNEL<4>), grid, dim3(THREADS), 0, s, __VA_ARGS__);      \
-    else if (per <= 5) hipLaunchKernelGGL((KERNEL<5>), grid, dim3(THREADS), 0, s, __VA_ARGS__); \
-    else if (per <= 8) hipLaunchKernelGGL((KERNEL<8>), grid, dim3(THREADS), 0, s, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<16>), grid, dim3(THREADS), 0, s, __VA_ARGS__);              \
-  } while (0)
-#define LN_DISPATCH(KERNEL, ...) LN_DISPATCH_T(kLnThreads, KERNEL, __VA_ARGS__)
-
-int butd_add_dropout_layernorm_fwd(int rows, int cols, const float *x, const float *residual,
-                                   const float *gamma, const float *beta, float eps, float *y,
-                                   float *mean, float *rstd, float dropout_p, uint32_t dropout_site,
-                                   const uint64_t *rng_counter, butd_stream_t stream) {
-  if (rows <= 0) return 0;
-  if (cols <= 0 || cols > 64 * kLnMaxPerLane) return (int)hipErrorInvalidValue;
-  hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((rows + kLnThreads / 64 - 1) / (kLnThreads / 64));
-  LN_DISPATCH(ln_fwd_kernel, rows, cols, x, residual, gamma, beta, eps, y, mean, rstd, dropout_p,
-              dropout_site, rng_counter);
-  return (int)hipGetLastError();
-}
-
-int butd_add_dropout_layernorm_bwd(int rows, int cols, const float *dy, const float *x,
-                                   const float *residual, const float *gamma, const float *mean,
-                                   const float *rstd, float *dx, float *d_residual, float *dgamma,
-                                   float *dbeta, float dropout_p, uint32_t dropout_site,
-                                   const uint64_t *rng_counter, butd_stream_t stream) {
-  if (rows <= 0) return 0;
-  if (cols <= 0 || cols > 64 * kLnMaxPerLane) return (int)hipErrorInvalidValue;
-  hipStream_t s = (hipStream_t)stream;
-  const int rows_per_block = (kLnBwdThreads / 64) * kLnRowsPerWave;
-  const dim3 grid((rows + rows_per_block - 1) / rows_per_block);
-  LN_DISPATCH_T(kLnBwdThreads, ln_bwd_kernel, rows, cols, dy, x, residual, gamma, mean, rstd, dx, d_residual, dgamma,
-              dbeta, dropout_p, dropout_site, rng_counter);
-  return (int)hipGetLastError();
-}
-
-}  // extern "C"
-
-// ================================================================================================
+p='butd_detr_amd/csrc/attention_ops.hip'
+s=open(p).read()
+a=s.index('// ================================================================================================\n// Attention core')
+b=s.index('extern "C" {\n\n#define ATTN_DISPATCH')
+new = r'''// ================================================================================================
 // Attention core (flash-style, fp32 MFMA 16x16x4, head_dim <= 48, head_dim % 4 == 0)
 // ================================================================================================
 // All score tiles are computed TRANSPOSED so that every per-query quantity (running max, running sum,
@@ -964,46 +533,16 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(
 
 }  // namespace
 
-extern "C" {
-
-#define ATTN_DISPATCH(KERNEL, grid, ...)                                                            \
-  do {                                                                                              \
-    if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__);   \
-    else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__); \
-    else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<12, 3>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__);          \
-  } while (0)
-
-int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
-                       const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
-                       float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
-                       butd_stream_t stream) {
-  if (B <= 0 || H <= 0 || Lq <= 0) return 0;
-  if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
+'''
+s=s[:a]+new+s[b:]
+s=s.replace('''  if (D <= 0 || D > 48 || Lk <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid((Lq + 63) / 64, H, B);
-  ATTN_DISPATCH(attn_fwd_kernel, grid, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p,
-                dropout_site, rng_counter);
-  return (int)hipGetLastError();
-}
-
-int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
-                       const float *v, const uint8_t *key_padding_mask, const float *out,
-                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
-                       float *dv, float dropout_p, uint32_t dropout_site,
-                       const uint64_t *rng_counter, butd_stream_t stream) {
-  if (B <= 0 || H <= 0 || Lq <= 0) return 0;
-  if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
+  const dim3 grid((Lq + 63) / 64, H, B);''','''  if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const long total = (long)B * Lq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, H, Lq,
-                     D, total, out, dout, delta);
-  const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
-  ATTN_DISPATCH(attn_bwd_dq_kernel, gq, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta, dq,
-                dropout_p, dropout_site, rng_counter);
-  ATTN_DISPATCH(attn_bwd_dkv_kernel, gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
-                dk, dv, dropout_p, dropout_site, rng_counter);
-  return (int)hipGetLastError();
-}
-
-}  // extern "C"
+  const dim3 grid((Lq + 63) / 64, H, B);''')
+s=s.replace('''  if (D <= 0 || D > 48 || Lk <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)B * Lq * H;''','''  if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const long total = (long)B * Lq * H;''')
+open(p,'w').write(s)
