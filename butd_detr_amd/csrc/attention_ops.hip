@@ -2,7 +2,7 @@
 // (include/butd_attention.h).  gfx950 only.
 //
 //   gemm_kernel          grouped dense products on v_mfma_f32_16x16x4_f32 (exact fp32, 157 TF peak):
-//                        64x64 output tile per 4-wave workgroup, 32x32 per wave (2x2 MFMA tiles), BK=16,
+//                        64x64 output tile per 4-wave workgroup, 32x32 per wave (2x2 MFMA tiles), BK=32,
 //                        both operands staged K-contiguous in LDS so a lane's four k-steps are ONE
 //                        ds_read_b128.  One launch serves up to 4 problems (Q/K/V projections, or the
 //                        three input-gradient products), with bias / scale / ReLU / dropout epilogues,
@@ -24,7 +24,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBM = 64, kBN = 64, kBK = 16, kLd = kBK + 4;  // LDS row stride 20 floats = 80 B
+constexpr int kBM = 64, kBN = 64, kBK = 32, kLd = kBK + 4;  // LDS row stride 68 floats = 17 x 16 B
+constexpr int kSub = kBK / 16;  // 16-wide sub-slabs per staged slab
 constexpr int kGemmThreads = 256;
 constexpr int kMaxProblems = 4;
 
@@ -35,79 +36,90 @@ struct GemmBatch {
 };
 
 // Staging of a (rows x 16) operand slab, split in two so the global loads of slab i+1 are in flight
-// while the MFMAs of slab i run:  fetch_tile() -> 4 floats in registers,  commit_tile() -> LDS as
-// tile[row][k].   element(row, k) = src[row*ld_row + k*ld_k] combined with src2 (see butd_gemm_problem);
-// rows >= nrows and k >= kend read 0, except the virtual ones-row (row == nrows && ones): 1.0.
-__device__ inline float combine(float a, float a2, int mode, float gate_scale) {
-  return mode == 0 ? a + a2 : a * (a2 > 0.f ? gate_scale : 0.f);
+// while the MFMAs of slab i run:  fetch_tile() only ISSUES loads (raw values of the operand and of its
+// optional companion a2 land in registers, nothing consumes them), commit_tile() combines and writes
+// the LDS image tile[row][k].   element(row, k) = src[row*ld_row + k*ld_k]; exactly one of the two
+// strides is 1 and each thread moves the float4 that is contiguous in memory: 4 consecutive k of one
+// row (contraction-contiguous operand) or 4 consecutive rows of one k (row-contiguous operand, which
+// commit_tile transposes).  Rows >= nrows and k >= kend read as 0, except the virtual ones-row.
+struct Frag4 {
+  float4 a, a2;
+};
+
+struct TileIdx {
+  int slow, fast;   // position along the strided / contiguous dimension inside the slab
+  bool kc;          // contraction-contiguous?
+};
+__device__ inline TileIdx tile_idx(long ld_k, int tid) {
+  TileIdx t;
+  t.kc = ld_k == 1;
+  t.slow = t.kc ? (tid >> 2) : (tid >> 4);
+  t.fast = t.kc ? (tid & 3) * 4 : (tid & 15) * 4;
+  return t;
 }
 
-struct Frag4 { float v[4]; };
-
 __device__ inline Frag4 fetch_tile(const float *__restrict__ src, const float *__restrict__ src2,
-                                   int mode2, float scale2, long ld_row, long ld_k, int row0,
-                                   int nrows, int k0, int kend, bool ones, int tid) {
+                                   long ld_row, long ld_k, int row0, int nrows, int k0, int kend,
+                                   int tid) {
+  const TileIdx t = tile_idx(ld_k, tid);
+  const long ld_slow = t.kc ? ld_row : ld_k;
+  const int slow_g = (t.kc ? row0 : k0) + t.slow, fast_g = (t.kc ? k0 : row0) + t.fast;
+  const int slow_lim = t.kc ? nrows : kend, fast_lim = t.kc ? kend : nrows;
   Frag4 f;
-  f.v[0] = f.v[1] = f.v[2] = f.v[3] = 0.f;
-  if (ld_k == 1) {  // contraction-contiguous: 4 consecutive k of one row
-    const int r = tid >> 2, kq = (tid & 3) * 4;
-    const int gr = row0 + r, gk = k0 + kq;
-    if (gr < nrows) {
-      const long o = (long)gr * ld_row + gk;
-      const bool vec = (gk + 3 < kend) && ((ld_row & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
-      if (vec) {
-        const float4 q = *reinterpret_cast<const float4 *>(src + o);
-        f.v[0] = q.x; f.v[1] = q.y; f.v[2] = q.z; f.v[3] = q.w;
-        if (src2) {
-          const float4 q2 = *reinterpret_cast<const float4 *>(src2 + o);
-          f.v[0] = combine(f.v[0], q2.x, mode2, scale2); f.v[1] = combine(f.v[1], q2.y, mode2, scale2);
-          f.v[2] = combine(f.v[2], q2.z, mode2, scale2); f.v[3] = combine(f.v[3], q2.w, mode2, scale2);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (gk + i < kend)
-            f.v[i] = src2 ? combine(src[o + i], src2[o + i], mode2, scale2) : src[o + i];
-      }
-    } else if (ones && gr == nrows) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) f.v[i] = (gk + i < kend) ? 1.f : 0.f;
+  f.a = make_float4(0.f, 0.f, 0.f, 0.f);
+  f.a2 = f.a;
+  if (slow_g < slow_lim && fast_g < fast_lim) {
+    const long o = (long)slow_g * ld_slow + fast_g;
+    const bool vec = (fast_g + 3 < fast_lim) && ((ld_slow & 3) == 0);
+    if (vec && ((((uintptr_t)src) & 15) == 0)) {
+      f.a = *reinterpret_cast<const float4 *>(src + o);
+    } else {
+      f.a.x = src[o];
+      if (fast_g + 1 < fast_lim) f.a.y = src[o + 1];
+      if (fast_g + 2 < fast_lim) f.a.z = src[o + 2];
+      if (fast_g + 3 < fast_lim) f.a.w = src[o + 3];
     }
-  } else {  // row-contiguous: 4 consecutive rows of one k
-    const int k = tid >> 4, r4 = (tid & 15) * 4;
-    const int gk = k0 + k, gr = row0 + r4;
-    if (gk < kend) {
-      const long o = (long)gk * ld_k + gr;
-      const bool vec = (gr + 3 < nrows) && ((ld_k & 3) == 0) && ((((uintptr_t)src) & 15) == 0);
-      if (vec) {
-        const float4 q = *reinterpret_cast<const float4 *>(src + o);
-        f.v[0] = q.x; f.v[1] = q.y; f.v[2] = q.z; f.v[3] = q.w;
-        if (src2) {
-          const float4 q2 = *reinterpret_cast<const float4 *>(src2 + o);
-          f.v[0] = combine(f.v[0], q2.x, mode2, scale2); f.v[1] = combine(f.v[1], q2.y, mode2, scale2);
-          f.v[2] = combine(f.v[2], q2.z, mode2, scale2); f.v[3] = combine(f.v[3], q2.w, mode2, scale2);
-        }
+    if (src2) {
+      if (vec && ((((uintptr_t)src2) & 15) == 0)) {
+        f.a2 = *reinterpret_cast<const float4 *>(src2 + o);
       } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (gr + i < nrows)
-            f.v[i] = src2 ? combine(src[o + i], src2[o + i], mode2, scale2) : src[o + i];
-          else if (ones && gr + i == nrows) f.v[i] = 1.f;
-        }
+        f.a2.x = src2[o];
+        if (fast_g + 1 < fast_lim) f.a2.y = src2[o + 1];
+        if (fast_g + 2 < fast_lim) f.a2.z = src2[o + 2];
+        if (fast_g + 3 < fast_lim) f.a2.w = src2[o + 3];
       }
     }
   }
   return f;
 }
 
-__device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, long ld_k, int tid) {
-  if (ld_k == 1) {
-    const int r = tid >> 2, kq = (tid & 3) * 4;
-    *reinterpret_cast<float4 *>(&tile[r][kq]) = make_float4(f.v[0], f.v[1], f.v[2], f.v[3]);
-  } else {  // transpose into the K-contiguous LDS image
-    const int k = tid >> 4, r4 = (tid & 15) * 4;
+__device__ inline float combine(float a, float a2, int mode, float gate_scale) {
+  return mode == 0 ? a + a2 : a * (a2 > 0.f ? gate_scale : 0.f);
+}
+
+__device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, bool has2, int mode2,
+                                   float scale2, long ld_k, int row0, int nrows, int k0, int kend,
+                                   bool ones, int koff, int tid) {
+  const TileIdx t = tile_idx(ld_k, tid);
+  float v[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
+  if (has2) {
+    v[0] = combine(v[0], f.a2.x, mode2, scale2); v[1] = combine(v[1], f.a2.y, mode2, scale2);
+    v[2] = combine(v[2], f.a2.z, mode2, scale2); v[3] = combine(v[3], f.a2.w, mode2, scale2);
+  }
+  if (t.kc) {
+    if (ones && row0 + t.slow == nrows) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tile[r4 + i][k] = f.v[i];
+      for (int i = 0; i < 4; ++i) v[i] = (k0 + t.fast + i < kend) ? 1.f : 0.f;
+    }
+    *reinterpret_cast<float4 *>(&tile[t.slow][koff + t.fast]) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {  // transpose into the K-contiguous LDS image
+    if (ones && k0 + t.slow < kend) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (row0 + t.fast + i == nrows) v[i] = 1.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[t.fast + i][koff + t.slow] = v[i];
   }
 }
 
@@ -144,44 +156,73 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
   // double-buffered LDS, one barrier per slab: slab i+1 travels global -> registers while slab i is
   // multiplied, then lands in the other buffer
   const bool ones = P.ones_col != 0;
-  Frag4 fa = fetch_tile(P.a, P.a2, P.a2_mode, P.a2_scale, P.lda_m, P.lda_k, m0, P.M, kbeg, kend, false, tid);
-  Frag4 fb = fetch_tile(P.b, nullptr, 0, 0.f, P.ldb_n, P.ldb_k, n0, P.N, kbeg, kend, ones, tid);
-  commit_tile(As[0], fa, P.lda_k, tid);
-  commit_tile(Bs[0], fb, P.ldb_k, tid);
+  Frag4 fa[kSub], fb[kSub];
+  int kfetched = kbeg;
+  auto fetch = [&](int k0) {
+    kfetched = k0;
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+      fa[u] = fetch_tile(P.a, P.a2, P.lda_m, P.lda_k, m0, P.M, k0 + u * 16, kend, tid);
+      fb[u] = fetch_tile(P.b, nullptr, P.ldb_n, P.ldb_k, n0, P.N, k0 + u * 16, kend, tid);
+    }
+  };
+  auto commit = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < kSub; ++u) {
+      commit_tile(As[buf], fa[u], P.a2 != nullptr, P.a2_mode, P.a2_scale, P.lda_k, m0, P.M,
+                  kfetched + u * 16, kend, false, u * 16, tid);
+      commit_tile(Bs[buf], fb[u], false, 0, 0.f, P.ldb_k, n0, P.N, kfetched + u * 16, kend, ones,
+                  u * 16, tid);
+    }
+  };
+  fetch(kbeg);
+  commit(0);
   __syncthreads();
   int cur = 0;
   for (int k0 = kbeg; k0 < kend; k0 += kBK) {
     const bool more = k0 + kBK < kend;
-    if (more) {
-      fa = fetch_tile(P.a, P.a2, P.a2_mode, P.a2_scale, P.lda_m, P.lda_k, m0, P.M, k0 + kBK, kend, false, tid);
-      fb = fetch_tile(P.b, nullptr, 0, 0.f, P.ldb_n, P.ldb_k, n0, P.N, k0 + kBK, kend, ones, tid);
-    }
-    f32x4 af[2], bf[2];
+    if (more) fetch(k0 + kBK);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-      af[i] = *reinterpret_cast<const f32x4 *>(&As[cur][wr * 32 + i * 16 + fr][fg * 4]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[cur][wc * 32 + j * 16 + fr][fg * 4]);
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int u = 0; u < kSub; ++u) {
+      f32x4 af[2], bf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const f32x4 *>(&As[cur][wr * 32 + i * 16 + fr][u * 16 + fg * 4]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
-    if (more) {
-      commit_tile(As[cur ^ 1], fa, P.lda_k, tid);
-      commit_tile(Bs[cur ^ 1], fb, P.ldb_k, tid);
+      for (int j = 0; j < 2; ++j)
+        bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[cur][wc * 32 + j * 16 + fr][u * 16 + fg * 4]);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
+    if (more) commit(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 
-  // epilogue: lane holds C[row = fg*4 + r][col = fr] of each 16x16 tile
+  // epilogue: lane holds C[row = fg*4 + r][col = fr] of each 16x16 tile.  Everything that is LOADED
+  // (bias, RNG counter) is fetched before the first store: the output may alias nothing here, but the
+  // compiler cannot know, and a load issued after a store waits for it (16 serialized L2 round trips
+  // made the epilogue cost more than the whole K loop).
   const bool drop = P.dropout_p > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - P.dropout_p) : 1.f;
   const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
+  float *const cptr = P.c;
+  float *const bgrad = P.bias_grad;
+  const int pM = P.M, pN = P.N, relu = P.relu, accumulate = P.accumulate, ones_col = P.ones_col;
+  const long ldc = P.ldc;
+  const float scale = P.scale, p_drop = P.dropout_p;
+  const uint32_t site = P.dropout_site;
+  float bias_v[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + wc * 32 + j * 16 + fr;
+    bias_v[j] = (P.bias && slice == 0 && n < pN) ? P.bias[n] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -190,20 +231,18 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wr * 32 + i * 16 + fg * 4 + r;
-        if (m >= P.M) continue;
+        if (m >= pM) continue;
         float v = acc[i][j][r];
-        if (n < P.N) {
-          if (P.bias && slice == 0) v += P.bias[n];
-          v *= P.scale;
-          if (P.relu) v = fmaxf(v, 0.f);
+        if (n < pN) {
+          v = (v + bias_v[j]) * scale;
+          if (relu) v = fmaxf(v, 0.f);
           if (drop)
-            v = rng::keep(ctr, P.dropout_site, (uint32_t)((long)m * P.N + n), P.dropout_p)
-                    ? v * inv_keep : 0.f;
-          float *dst = P.c + (long)m * P.ldc + n;
-          if (P.accumulate) atomicAdd(dst, v);
+            v = rng::keep(ctr, site, (uint32_t)((long)m * pN + n), p_drop) ? v * inv_keep : 0.f;
+          float *dst = cptr + (long)m * ldc + n;
+          if (accumulate) atomicAdd(dst, v);
           else *dst = v;
-        } else if (P.ones_col && n == P.N) {
-          atomicAdd(P.bias_grad + m, v * P.scale);
+        } else if (ones_col && n == pN) {
+          atomicAdd(bgrad + m, v * scale);
         }
       }
     }
