@@ -44,7 +44,9 @@ class GemmProblem(ctypes.Structure):
                 ("ldc", _c_long),
                 ("scale", _c_float), ("a2_mode", _c_int), ("a2_scale", _c_float),
                 ("relu", _c_int), ("accumulate", _c_int), ("ones_col", _c_int), ("split_k", _c_int),
-                ("dropout_p", _c_float), ("dropout_site", _c_u32)]
+                ("dropout_p", _c_float), ("dropout_site", _c_u32),
+                ("a_chan_scale", _c_void_p), ("a_chan_shift", _c_void_p),
+                ("b_chan_scale", _c_void_p), ("b_chan_shift", _c_void_p)]
 
 
 ATTENTION_SYMBOLS = {
@@ -57,8 +59,23 @@ ATTENTION_SYMBOLS = {
                                        + [_c_float, _c_u32, _c_void_p, _c_void_p]),
 }
 
+_P = _c_void_p
+SA_SYMBOLS = {
+    "butd_sa_group": (_c_int, [_c_int] * 5 + [_P, _P, _P, _c_long, _P, _c_float, _c_int, _P, _P]),
+    "butd_sa_colstats": (_c_int, [_c_long, _c_int, _P, _P, _P, _c_int, _P, _P, _P, _P, _P]),
+    "butd_sa_bn_finalize": (_c_int, [_c_int, _c_long, _P, _P, _P, _P, _c_float, _c_float, _c_int]
+                            + [_P] * 7 + [_P]),
+    "butd_sa_pool_finalize": (_c_int, [_c_int] * 3 + [_P] * 10 + [_P]),
+    "butd_sa_pool_bwd_stats": (_c_int, [_c_int] * 3 + [_P] * 8 + [_P]),
+    "butd_sa_dz_last": (_c_int, [_c_int] * 4 + [_P] * 11 + [_c_int, _P]),
+    "butd_sa_mask_stats": (_c_int, [_c_long, _c_int] + [_P] * 8 + [_P]),
+    "butd_sa_dz_mid": (_c_int, [_c_long, _c_int] + [_P] * 8 + [_c_int, _P]),
+    "butd_sa_scatter_rows": (_c_int, [_c_int] * 5 + [_P] * 3 + [_P]),
+}
+
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
 ALL_SYMBOLS.update(ATTENTION_SYMBOLS)
+ALL_SYMBOLS.update(SA_SYMBOLS)
 
 _lib = None
 

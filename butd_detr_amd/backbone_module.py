@@ -37,8 +37,12 @@ class Pointnet2Backbone(nn.Module):
         """pointcloud (B, N, 3 + input_feature_dim) -> end_points dict."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
+        # point-major hand-over between levels (used by the fused gfx950 SA pipeline, ignored otherwise)
+        feats_pm, off = (pointcloud.contiguous(), 3) if features is not None else (None, 0)
         for level in (1, 2, 3, 4):
-            xyz, features, inds = getattr(self, f"sa{level}")(xyz, features)
+            sa = getattr(self, f"sa{level}")
+            xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off)
+            feats_pm, off = sa.last_features_pm, 0
             if level <= 2:  # the reference only records inds of the first two levels (:127,:132)
                 end_points[f"sa{level}_inds"] = inds
             end_points[f"sa{level}_xyz"] = xyz

@@ -97,14 +97,27 @@ __device__ inline float combine(float a, float a2, int mode, float gate_scale) {
   return mode == 0 ? a + a2 : a * (a2 > 0.f ? gate_scale : 0.f);
 }
 
+// chan_is_k: the affine's channel index is the contraction index (A operand) or the row index (B)
 __device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, bool has2, int mode2,
-                                   float scale2, long ld_k, int row0, int nrows, int k0, int kend,
-                                   bool ones, int koff, int tid) {
+                                   float scale2, const float *__restrict__ csc,
+                                   const float *__restrict__ csh, bool chan_is_k, long ld_k, int row0,
+                                   int nrows, int k0, int kend, bool ones, int koff, int tid) {
   const TileIdx t = tile_idx(ld_k, tid);
   float v[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
   if (has2) {
     v[0] = combine(v[0], f.a2.x, mode2, scale2); v[1] = combine(v[1], f.a2.y, mode2, scale2);
     v[2] = combine(v[2], f.a2.z, mode2, scale2); v[3] = combine(v[3], f.a2.w, mode2, scale2);
+  }
+  if (csc) {  // relu(v * scale[chan] + shift[chan]); out-of-range elements stay 0
+    const int rbase = row0 + (t.kc ? t.slow : t.fast), kbase = k0 + (t.kc ? t.fast : t.slow);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = rbase + (t.kc ? 0 : i), k = kbase + (t.kc ? i : 0);
+      if (r < nrows && k < kend) {
+        const int ch = chan_is_k ? k : r;
+        v[i] = fmaxf(v[i] * csc[ch] + csh[ch], 0.f);
+      }
+    }
   }
   if (t.kc) {
     if (ones && row0 + t.slow == nrows) {
@@ -169,10 +182,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
   auto commit = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < kSub; ++u) {
-      commit_tile(As[buf], fa[u], P.a2 != nullptr, P.a2_mode, P.a2_scale, P.lda_k, m0, P.M,
-                  kfetched + u * 16, kend, false, u * 16, tid);
-      commit_tile(Bs[buf], fb[u], false, 0, 0.f, P.ldb_k, n0, P.N, kfetched + u * 16, kend, ones,
-                  u * 16, tid);
+      commit_tile(As[buf], fa[u], P.a2 != nullptr, P.a2_mode, P.a2_scale, P.a_chan_scale,
+                  P.a_chan_shift, true, P.lda_k, m0, P.M, kfetched + u * 16, kend, false, u * 16, tid);
+      commit_tile(Bs[buf], fb[u], false, 0, 0.f, P.b_chan_scale, P.b_chan_shift, false, P.ldb_k, n0,
+                  P.N, kfetched + u * 16, kend, ones, u * 16, tid);
     }
   };
   fetch(kbeg);

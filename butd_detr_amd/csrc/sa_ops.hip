@@ -1,0 +1,397 @@
+// sa_ops.hip -- streaming kernels of the set-abstraction shared-MLP pipeline (include/butd_sa.h).
+//
+// The 1x1 convolutions themselves are butd_gemm_grouped launches (attention_ops.hip) over
+// position-major activations, with the producer's BatchNorm+ReLU folded into the operand load; what
+// lives here is everything around them: the grouping gather, the BatchNorm statistics (double
+// accumulators: E[z^2]-E[z]^2 over 10^6 rows in fp32 would lose the variance), the max-pool with
+// first-occurrence arg-max, and the element-wise halves of the backward.  All are HBM-streaming
+// kernels: coalesced float4 rows, one pass per tensor.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/butd_sa.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// ---------------------------------------------------------------------------------------- grouping
+__global__ __launch_bounds__(kThreads) void sa_group_kernel(int N, int np, int ns, int C,
+                                                            const float *__restrict__ xyz,
+                                                            const float *__restrict__ new_xyz,
+                                                            const float *__restrict__ feats,
+                                                            long feat_stride,
+                                                            const int *__restrict__ idx, float radius,
+                                                            int normalize, float *__restrict__ X,
+                                                            long total) {
+  const int Cin = 3 + C;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+    const long p = e / Cin;
+    const int c = (int)(e - p * Cin);
+    const long g = p / ns;           // (b, j)
+    const long b = g / np;
+    const int src = idx[p];
+    float v;
+    if (c < 3) {
+      v = xyz[(b * N + src) * 3 + c] - new_xyz[g * 3 + c];
+      if (normalize) v = v / radius;
+    } else {
+      v = feats[(b * N + src) * feat_stride + (c - 3)];
+    }
+    X[e] = v;
+  }
+}
+
+// ------------------------------------------------------------------------- column stats (+ pooling)
+// Workgroup = 256 threads over a chunk of rows x all C columns.  With TPC = 256 / C threads per column,
+// thread (col, sub) owns every TPC-th GROUP of the chunk (groups = pool_ns rows, or single rows when
+// not pooling), so the pooling needs no cross-thread step; the sums are reduced across `sub` in LDS and
+// leave the block as ONE double atomic per column.
+constexpr int kChunkRows = 512;
+
+__global__ __launch_bounds__(kThreads) void sa_colstats_kernel(
+    long P, int C, const float *__restrict__ Z, double *__restrict__ sum, double *__restrict__ sumsq,
+    int pool_ns, float *__restrict__ zmax, float *__restrict__ zmin, uint8_t *__restrict__ amax,
+    uint8_t *__restrict__ amin) {
+  __shared__ float red[2][kThreads];
+  const int tpc = kThreads / C;           // C in {64,128,256} -> 4,2,1 ; other C: see host
+  const int col = threadIdx.x % C, sub = threadIdx.x / C;
+  const bool active = sub < tpc;
+  const int gs = pool_ns > 0 ? pool_ns : 1;
+  const long row0 = (long)blockIdx.x * kChunkRows;
+  const long rows = min((long)kChunkRows, P - row0);
+  const long ngroups = rows / gs;
+  float s = 0.f, q = 0.f;
+  if (active) {
+    for (long g = sub; g < ngroups; g += tpc) {
+      const float *z = Z + (row0 + g * gs) * C + col;
+      float mx = -INFINITY, mn = INFINITY;
+      int ax = 0, an = 0;
+      for (int k = 0; k < gs; ++k) {
+        const float v = z[(long)k * C];
+        s += v;
+        q += v * v;
+        if (v > mx) { mx = v; ax = k; }
+        if (v < mn) { mn = v; an = k; }
+      }
+      if (pool_ns > 0) {
+        const long o = ((row0 / gs) + g) * C + col;
+        zmax[o] = mx; zmin[o] = mn;
+        amax[o] = (uint8_t)ax; amin[o] = (uint8_t)an;
+      }
+    }
+  }
+  red[0][threadIdx.x] = s;
+  red[1][threadIdx.x] = q;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < tpc; ++t) {
+      a += (double)red[0][threadIdx.x + t * C];
+      b += (double)red[1][threadIdx.x + t * C];
+    }
+    atomicAdd(sum + threadIdx.x, a);
+    atomicAdd(sumsq + threadIdx.x, b);
+  }
+}
+
+__global__ void sa_bn_finalize_kernel(int C, long count, const double *__restrict__ sum,
+                                      const double *__restrict__ sumsq, const float *__restrict__ gamma,
+                                      const float *__restrict__ beta, float eps, float momentum,
+                                      int training, float *__restrict__ running_mean,
+                                      float *__restrict__ running_var, int64_t *__restrict__ nbt,
+                                      float *__restrict__ mean, float *__restrict__ rstd,
+                                      float *__restrict__ scale, float *__restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && training && nbt) *nbt += 1;
+  if (c >= C) return;
+  float mu, var;
+  if (training) {
+    const double m = sum[c] / (double)count;
+    double v = sumsq[c] / (double)count - m * m;
+    if (v < 0.0) v = 0.0;
+    mu = (float)m;
+    var = (float)v;
+    const double unbiased = count > 1 ? v * (double)count / (double)(count - 1) : v;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  } else {
+    mu = running_mean[c];
+    var = running_var[c];
+  }
+  const float rs = 1.0f / sqrtf(var + eps);
+  mean[c] = mu;
+  rstd[c] = rs;
+  scale[c] = gamma[c] * rs;
+  shift[c] = beta[c] - mu * gamma[c] * rs;
+}
+
+__global__ __launch_bounds__(kThreads) void sa_pool_finalize_kernel(
+    int np, int C, long total, const float *__restrict__ zmax, const float *__restrict__ zmin,
+    const uint8_t *__restrict__ amax, const uint8_t *__restrict__ amin, const float *__restrict__ scale,
+    const float *__restrict__ shift, float *__restrict__ out_cm, float *__restrict__ out_pm,
+    float *__restrict__ zsel, uint8_t *__restrict__ asel) {
+  const long e = (long)blockIdx.x * kThreads + threadIdx.x;  // over (g, c), c fastest
+  if (e >= total) return;
+  const int c = (int)(e % C);
+  const long g = e / C;
+  const long b = g / np;
+  const int j = (int)(g - b * np);
+  const float sc = scale[c];
+  const bool up = sc >= 0.f;
+  const float z = up ? zmax[e] : zmin[e];
+  const float y = fmaxf(sc * z + shift[c], 0.f);
+  zsel[e] = z;
+  asel[e] = up ? amax[e] : amin[e];
+  out_pm[e] = y;
+  out_cm[(b * C + c) * np + j] = y;
+}
+
+// ---------------------------------------------------------------------------------------- backward
+__global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(
+    int np, int C, long G, const float *__restrict__ d_out_cm, const float *__restrict__ zsel,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ rstd, double *__restrict__ S1, double *__restrict__ S2) {
+  // block = 256 groups x all channels: thread t owns column (t % C), groups sub, sub+tpc, ...
+  __shared__ float red[2][kThreads];
+  const int tpc = kThreads / C;
+  const int col = threadIdx.x % C, sub = threadIdx.x / C;
+  const long g0 = (long)blockIdx.x * 256;
+  const long ng = min((long)256, G - g0);
+  float s1 = 0.f, s2 = 0.f;
+  if (sub < tpc) {
+    const float sc = scale[col], sh = shift[col], mu = mean[col], rs = rstd[col];
+    for (long gi = sub; gi < ng; gi += tpc) {
+      const long g = g0 + gi;
+      const long b = g / np;
+      const int j = (int)(g - b * np);
+      const float z = zsel[g * C + col];
+      if (sc * z + sh > 0.f) {
+        const float dy = d_out_cm[(b * C + col) * np + j];
+        s1 += dy;
+        s2 += dy * (z - mu) * rs;
+      }
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0, b2 = 0.0;
+    for (int t = 0; t < tpc; ++t) {
+      a += (double)red[0][threadIdx.x + t * C];
+      b2 += (double)red[1][threadIdx.x + t * C];
+    }
+    atomicAdd(S1 + threadIdx.x, a);
+    atomicAdd(S2 + threadIdx.x, b2);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
+    int np, int ns, int C, long total, float *__restrict__ Z, const float *__restrict__ d_out_cm,
+    const float *__restrict__ zsel, const uint8_t *__restrict__ asel, const float *__restrict__ gamma,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const double *__restrict__ S1, const double *__restrict__ S2,
+    int training) {
+  const double invP = 1.0 / (double)(total / C);
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+    const int c = (int)(e % C);
+    const long p = e / C;
+    const long g = p / ns;
+    const int k = (int)(p - g * ns);
+    const long b = g / np;
+    const int j = (int)(g - b * np);
+    const float sc = scale[c];
+    float dy = 0.f;
+    if ((int)asel[g * C + c] == k && sc * zsel[g * C + c] + shift[c] > 0.f)
+      dy = d_out_cm[(b * C + c) * np + j];
+    float dz;
+    if (training) {
+      const float zh = (Z[e] - mean[c]) * rstd[c];
+      dz = gamma[c] * rstd[c] * (dy - (float)(S1[c] * invP) - zh * (float)(S2[c] * invP));
+    } else {
+      dz = sc * dy;
+    }
+    Z[e] = dz;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
+    long P, int C, float *__restrict__ dH, const float *__restrict__ Z, const float *__restrict__ scale,
+    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
+    double *__restrict__ S1, double *__restrict__ S2) {
+  __shared__ float red[2][kThreads];
+  const int tpc = kThreads / C;
+  const int col = threadIdx.x % C, sub = threadIdx.x / C;
+  const long row0 = (long)blockIdx.x * kChunkRows;
+  const long rows = min((long)kChunkRows, P - row0);
+  float s1 = 0.f, s2 = 0.f;
+  if (sub < tpc) {
+    const float sc = scale[col], sh = shift[col], mu = mean[col], rs = rstd[col];
+    for (long r = sub; r < rows; r += tpc) {
+      const long o = (row0 + r) * C + col;
+      const float z = Z[o];
+      float g = dH[o];
+      if (!(sc * z + sh > 0.f)) g = 0.f;
+      dH[o] = g;
+      s1 += g;
+      s2 += g * (z - mu) * rs;
+    }
+  }
+  red[0][threadIdx.x] = s1;
+  red[1][threadIdx.x] = s2;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < tpc; ++t) {
+      a += (double)red[0][threadIdx.x + t * C];
+      b += (double)red[1][threadIdx.x + t * C];
+    }
+    atomicAdd(S1 + threadIdx.x, a);
+    atomicAdd(S2 + threadIdx.x, b);
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void sa_dz_mid_kernel(
+    long total, int C, float *__restrict__ g, const float *__restrict__ Z, const float *__restrict__ gamma,
+    const float *__restrict__ scale, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const double *__restrict__ S1, const double *__restrict__ S2, int training) {
+  const double invP = 1.0 / (double)(total / C);
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+    const int c = (int)(e % C);
+    float dz;
+    if (training) {
+      const float zh = (Z[e] - mean[c]) * rstd[c];
+      dz = gamma[c] * rstd[c] * (g[e] - (float)(S1[c] * invP) - zh * (float)(S2[c] * invP));
+    } else {
+      dz = scale[c] * g[e];
+    }
+    g[e] = dz;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void sa_scatter_rows_kernel(int N, int np, int ns, int C,
+                                                                   const float *__restrict__ dX,
+                                                                   const int *__restrict__ idx,
+                                                                   float *__restrict__ d_feats,
+                                                                   long total) {
+  const int Cin = 3 + C;
+  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
+    const long p = e / C;
+    const int c = (int)(e - p * C);
+    const long b = p / ((long)np * ns);
+    atomicAdd(d_feats + (b * N + idx[p]) * C + c, dX[p * Cin + 3 + c]);
+  }
+}
+
+inline unsigned blocks_for(long total, int cap = 16384) {
+  long b = (total + kThreads - 1) / kThreads;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+inline bool cols_ok(int C) { return C > 0 && C <= kThreads && kThreads % C == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const float *new_xyz,
+                  const float *feats, long feat_stride, const int *idx, float radius, int normalize,
+                  float *X, butd_stream_t stream) {
+  const long total = (long)B * np * ns * (3 + C);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(sa_group_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
+                     N, np, ns, C, xyz, new_xyz, feats, feat_stride, idx, radius, normalize, X, total);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_colstats(long P, int C, const float *Z, double *sum, double *sumsq, int pool_ns,
+                     float *zmax, float *zmin, uint8_t *amax, uint8_t *amin, butd_stream_t stream) {
+  if (P <= 0) return 0;
+  if (!cols_ok(C) || (pool_ns > 0 && (kChunkRows % pool_ns || P % pool_ns)))
+    return (int)hipErrorInvalidValue;
+  const unsigned blocks = (unsigned)((P + kChunkRows - 1) / kChunkRows);
+  hipLaunchKernelGGL(sa_colstats_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, P, C, Z,
+                     sum, sumsq, pool_ns, zmax, zmin, amax, amin);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_bn_finalize(int C, long count, const double *sum, const double *sumsq, const float *gamma,
+                        const float *beta, float eps, float momentum, int training, float *running_mean,
+                        float *running_var, int64_t *num_batches_tracked, float *mean, float *rstd,
+                        float *scale, float *shift, butd_stream_t stream) {
+  if (C <= 0) return 0;
+  hipLaunchKernelGGL(sa_bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C,
+                     count, sum, sumsq, gamma, beta, eps, momentum, training, running_mean, running_var,
+                     num_batches_tracked, mean, rstd, scale, shift);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_pool_finalize(int B, int np, int C, const float *zmax, const float *zmin,
+                          const uint8_t *amax, const uint8_t *amin, const float *scale,
+                          const float *shift, float *out_cm, float *out_pm, float *zsel, uint8_t *asel,
+                          butd_stream_t stream) {
+  const long total = (long)B * np * C;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(sa_pool_finalize_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads)),
+                     dim3(kThreads), 0, (hipStream_t)stream, np, C, total, zmax, zmin, amax, amin, scale,
+                     shift, out_cm, out_pm, zsel, asel);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_pool_bwd_stats(int B, int np, int C, const float *d_out_cm, const float *zsel,
+                           const float *scale, const float *shift, const float *mean,
+                           const float *rstd, double *S1, double *S2, butd_stream_t stream) {
+  const long G = (long)B * np;
+  if (G <= 0) return 0;
+  if (!cols_ok(C)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3((unsigned)((G + 255) / 256)), dim3(kThreads), 0,
+                     (hipStream_t)stream, np, C, G, d_out_cm, zsel, scale, shift, mean, rstd, S1, S2);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_cm, const float *zsel,
+                    const uint8_t *asel, const float *gamma, const float *scale, const float *shift,
+                    const float *mean, const float *rstd, const double *S1, const double *S2,
+                    int training, butd_stream_t stream) {
+  const long total = (long)B * np * ns * C;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(sa_dz_last_kernel, dim3(blocks_for(total, 65536)), dim3(kThreads), 0,
+                     (hipStream_t)stream, np, ns, C, total, Z, d_out_cm, zsel, asel, gamma, scale, shift,
+                     mean, rstd, S1, S2, training);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_mask_stats(long P, int C, float *dH, const float *Z, const float *scale,
+                       const float *shift, const float *mean, const float *rstd, double *S1,
+                       double *S2, butd_stream_t stream) {
+  if (P <= 0) return 0;
+  if (!cols_ok(C)) return (int)hipErrorInvalidValue;
+  const unsigned blocks = (unsigned)((P + kChunkRows - 1) / kChunkRows);
+  hipLaunchKernelGGL(sa_mask_stats_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, P, C,
+                     dH, Z, scale, shift, mean, rstd, S1, S2);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, const float *scale,
+                   const float *mean, const float *rstd, const double *S1, const double *S2,
+                   int training, butd_stream_t stream) {
+  const long total = P * C;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(sa_dz_mid_kernel, dim3(blocks_for(total, 65536)), dim3(kThreads), 0,
+                     (hipStream_t)stream, total, C, g, Z, gamma, scale, mean, rstd, S1, S2, training);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, const int *idx,
+                         float *d_feats_pm, butd_stream_t stream) {
+  const long total = (long)B * np * ns * C;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(sa_scatter_rows_kernel, dim3(blocks_for(total, 65536)), dim3(kThreads), 0,
+                     (hipStream_t)stream, N, np, ns, C, dX, idx, d_feats_pm, total);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -55,10 +55,13 @@ def _ptr(t):
 
 def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.0, bias=None,
              bias_grad=None, scale=1.0, relu=False, accumulate=False, ones_col=False, split_k=1,
-             dropout_p=0.0, site=0):
+             dropout_p=0.0, site=0, a_affine=None, b_affine=None):
+    asc, ash = a_affine if a_affine is not None else (None, None)
+    bsc, bsh = b_affine if b_affine is not None else (None, None)
     return GemmProblem(_ptr(a), _ptr(a2), _ptr(b), _ptr(bias), _ptr(c), _ptr(bias_grad), M, N, K,
                        lda[0], lda[1], ldb[0], ldb[1], ldc, scale, a2_mode, a2_scale, int(relu),
-                       int(accumulate), int(ones_col), split_k, dropout_p, site)
+                       int(accumulate), int(ones_col), split_k, dropout_p, site,
+                       _ptr(asc), _ptr(ash), _ptr(bsc), _ptr(bsh))
 
 
 def _gemm(problems, ref):
@@ -81,7 +84,7 @@ def _dgrad(dy, w, dx, M, N, K, **kw):
 
 def _wgrad(dy, x, dw, db, M, N, K, **kw):
     """dw[N,K] += dy[M,N]^T @ x[M,K], db[N] += column sums of dy: contraction over M (split-K)."""
-    split = max(1, min(32, M // 256))
+    split = max(1, min(256, M // 512)) if M >= 16384 else max(1, min(32, M // 256))
     return _problem(dy, x, dw, N, K, M, (1, N), (1, K), K, bias_grad=db, ones_col=db is not None,
                     accumulate=True, split_k=split, **kw)
 

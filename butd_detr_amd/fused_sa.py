@@ -1,0 +1,195 @@
+"""Set-abstraction shared MLP on the gfx950 pipeline of include/butd_sa.h.
+
+``sa_mlp_pool`` = QueryAndGroup's gather/normalise + 3 x [1x1 conv -> BatchNorm2d -> ReLU] + max-pool
+over nsample (pointnet2_modules.py:243-257), forward AND backward, in training (batch statistics,
+running-stat update) or eval (running statistics) mode.  Activations are position-major (P, C)
+matrices; each 1x1 conv is one MFMA GEMM launch whose operand load applies the previous layer's
+BatchNorm+ReLU, so no NCHW tensor, transpose, BN-apply or ReLU pass ever touches HBM.
+"""
+import torch
+
+from . import _hiplib
+from .fused_attention import _dgrad, _fwd, _gemm, _wgrad
+
+_lib = _hiplib.load()
+
+
+def _s(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _call(name, ref, *args):
+    with torch.cuda.device(ref.device):
+        err = getattr(_lib, name)(*args, _s(ref))
+    _hiplib.check(err, name)
+
+
+class _SAMlpPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, feats_pm, new_xyz, idx, radius, normalize, training, momentum,
+                w1, g1, b1, rm1, rv1, nbt1, eps1,
+                w2, g2, b2, rm2, rv2, nbt2, eps2,
+                w3, g3, b3, rm3, rv3, nbt3, eps3,
+                feat_ptr_offset, feat_stride):
+        B, N, _ = xyz.shape
+        np_, ns = idx.shape[1], idx.shape[2]
+        C = 0 if feats_pm is None else (feats_pm.shape[-1] - feat_ptr_offset)
+        Cin = 3 + C
+        P = B * np_ * ns
+        dev = xyz.device
+        ws = [w.reshape(w.shape[0], -1) for w in (w1, w2, w3)]
+        C1, C2, C3 = (w.shape[0] for w in ws)
+        assert ws[0].shape[1] == Cin and ws[1].shape[1] == C1 and ws[2].shape[1] == C2
+
+        X = torch.empty((P, Cin), device=dev)
+        fptr = None if feats_pm is None else feats_pm.data_ptr() + 4 * feat_ptr_offset
+        _call("butd_sa_group", xyz, B, N, np_, ns, C, xyz.data_ptr(), new_xyz.data_ptr(), fptr,
+              feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr())
+
+        stats = torch.zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
+        aff = torch.empty((3, 4, max(C1, C2, C3)), device=dev)  # per layer: mean, rstd, scale, shift
+        layers = ((g1, b1, rm1, rv1, nbt1, eps1), (g2, b2, rm2, rv2, nbt2, eps2),
+                  (g3, b3, rm3, rv3, nbt3, eps3))
+        Zs, inp, prev_aff = [], X, None
+        G = B * np_
+        zmax = zmin = amax = amin = None
+        for li, (Cl, w) in enumerate(zip((C1, C2, C3), ws)):
+            Z = torch.empty((P, Cl), device=dev)
+            _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff)], xyz)
+            last = li == 2
+            if last:
+                zmax = torch.empty((G, Cl), device=dev)
+                zmin = torch.empty((G, Cl), device=dev)
+                amax = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
+                amin = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
+            if training or last:
+                _call("butd_sa_colstats", xyz, P, Cl, Z.data_ptr(), stats[li, 0].data_ptr(),
+                      stats[li, 1].data_ptr(), ns if last else 0, _p(zmax), _p(zmin), _p(amax), _p(amin))
+            g, b, rm, rv, nbt, eps = layers[li]
+            _call("butd_sa_bn_finalize", xyz, Cl, P, stats[li, 0].data_ptr(), stats[li, 1].data_ptr(),
+                  g.data_ptr(), b.data_ptr(), float(eps), float(momentum), int(training), rm.data_ptr(),
+                  rv.data_ptr(), _p(nbt), aff[li, 0].data_ptr(), aff[li, 1].data_ptr(),
+                  aff[li, 2].data_ptr(), aff[li, 3].data_ptr())
+            prev_aff = (aff[li, 2], aff[li, 3])
+            Zs.append(Z)
+            inp = Z
+        out_cm = torch.empty((B, C3, np_), device=dev)
+        out_pm = torch.empty((B, np_, C3), device=dev)
+        zsel = torch.empty((G, C3), device=dev)
+        asel = torch.empty((G, C3), dtype=torch.uint8, device=dev)
+        _call("butd_sa_pool_finalize", xyz, B, np_, C3, zmax.data_ptr(), zmin.data_ptr(), amax.data_ptr(),
+              amin.data_ptr(), aff[2, 2].data_ptr(), aff[2, 3].data_ptr(), out_cm.data_ptr(),
+              out_pm.data_ptr(), zsel.data_ptr(), asel.data_ptr())
+        ctx.save_for_backward(X, Zs[0], Zs[1], Zs[2], idx, aff, zsel, asel, ws[0], ws[1], ws[2], g1, g2, g3)
+        ctx.cfg = (B, N, np_, ns, C, bool(training), feats_pm is not None and feats_pm.requires_grad,
+                   w1.shape, w2.shape, w3.shape)
+        return out_cm, out_pm
+
+    @staticmethod
+    def backward(ctx, d_cm, d_pm):
+        X, Z1, Z2, Z3, idx, aff, zsel, asel, w1, w2, w3, g1, g2, g3 = ctx.saved_tensors
+        B, N, np_, ns, C, training, need_dfeat, s1, s2, s3 = ctx.cfg
+        dev = X.device
+        P, Cin = X.shape
+        C1, C2, C3 = w1.shape[0], w2.shape[0], w3.shape[0]
+        if d_cm is None:
+            d_out = d_pm.transpose(1, 2).contiguous()
+        elif d_pm is None:
+            d_out = d_cm.contiguous()
+        else:
+            d_out = d_cm + d_pm.transpose(1, 2)
+        tr = int(training)
+        S = torch.zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
+        dW = torch.zeros(C3 * C2 + C2 * C1 + C1 * Cin, device=dev)
+        dW3 = dW[:C3 * C2].view(C3, C2)
+        dW2 = dW[C3 * C2:C3 * C2 + C2 * C1].view(C2, C1)
+        dW1 = dW[C3 * C2 + C2 * C1:].view(C1, Cin)
+        mean = lambda l: aff[l, 0]
+        rstd = lambda l: aff[l, 1]
+        scale = lambda l: aff[l, 2]
+        shift = lambda l: aff[l, 3]
+        # ---- layer 3: max-pool + ReLU + BN
+        _call("butd_sa_pool_bwd_stats", X, B, np_, C3, d_out.data_ptr(), zsel.data_ptr(), scale(2).data_ptr(),
+              shift(2).data_ptr(), mean(2).data_ptr(), rstd(2).data_ptr(), S[2, 0].data_ptr(),
+              S[2, 1].data_ptr())
+        _call("butd_sa_dz_last", X, B, np_, ns, C3, Z3.data_ptr(), d_out.data_ptr(), zsel.data_ptr(),
+              asel.data_ptr(), g3.data_ptr(), scale(2).data_ptr(), shift(2).data_ptr(), mean(2).data_ptr(),
+              rstd(2).data_ptr(), S[2, 0].data_ptr(), S[2, 1].data_ptr(), tr)
+        dZ3 = Z3                                        # overwritten in place
+        dH2 = torch.empty((P, C2), device=dev)
+        _gemm([_wgrad(dZ3, Z2, dW3, None, P, C3, C2, b_affine=(scale(1), shift(1))),
+               _dgrad(dZ3, w3, dH2, P, C3, C2)], X)
+        # ---- layer 2
+        _call("butd_sa_mask_stats", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), scale(1).data_ptr(),
+              shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(),
+              S[1, 1].data_ptr())
+        _call("butd_sa_dz_mid", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), g2.data_ptr(), scale(1).data_ptr(),
+              mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
+        dZ2 = dH2
+        dH1 = torch.empty((P, C1), device=dev)
+        _gemm([_wgrad(dZ2, Z1, dW2, None, P, C2, C1, b_affine=(scale(0), shift(0))),
+               _dgrad(dZ2, w2, dH1, P, C2, C1)], X)
+        # ---- layer 1
+        _call("butd_sa_mask_stats", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), scale(0).data_ptr(),
+              shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
+              S[0, 1].data_ptr())
+        _call("butd_sa_dz_mid", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), g1.data_ptr(), scale(0).data_ptr(),
+              mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), tr)
+        dZ1 = dH1
+        d_feats = None
+        if need_dfeat:
+            dX = torch.empty((P, Cin), device=dev)
+            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Cin), _dgrad(dZ1, w1, dX, P, C1, Cin)], X)
+            d_feats = torch.zeros((B, N, C), device=dev)
+            _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), idx.data_ptr(),
+                  d_feats.data_ptr())
+        else:
+            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Cin)], X)
+        Sf = S.float()
+        dgs = [Sf[l, 1, :c].contiguous() if training else None for l, c in ((0, C1), (1, C2), (2, C3))]
+        dbs = [Sf[l, 0, :c].contiguous() if training else None for l, c in ((0, C1), (1, C2), (2, C3))]
+        if not training:   # eval-mode BN: y = gamma*(z-rm)*rs+beta -> parameter grads not produced here
+            dgs = dbs = [None, None, None]
+        return (None, d_feats, None, None, None, None, None, None,
+                dW1.view(s1), dgs[0], dbs[0], None, None, None, None,
+                dW2.view(s2), dgs[1], dbs[1], None, None, None, None,
+                dW3.view(s3), dgs[2], dbs[2], None, None, None, None,
+                None, None)
+
+
+def supported(module, xyz, features_pm):
+    """The fused pipeline covers the backbone's configuration: 3-layer BN MLP, max-pool, use_xyz."""
+    from torch import nn
+    mlp = module.mlp_module
+    if not (xyz.is_cuda and module.pooling == "max" and module.use_xyz and module.npoint is not None
+            and len(mlp) == 3 and not module.ret_unique_cnt):
+        return False
+    for layer in mlp:
+        if not (hasattr(layer, "bn") and layer.conv.bias is None):
+            return False
+        c = layer.conv.out_channels
+        if c > 256 or 256 % c:
+            return False
+    return 256 % module.nsample == 0 or module.nsample in (16, 32, 64)
+
+
+def sa_mlp_pool(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0):
+    """-> (new_features (B,C,npoint), new_features_pm (B,npoint,C)).  ``features_pm``: point-major
+    (B,N,offset+C) tensor whose last C columns are the per-point features (for SA1 the raw point cloud
+    with offset 3)."""
+    layers = list(module.mlp_module)
+    bns = [l.bn.bn for l in layers]
+    training = module.training
+    momentum = bns[0].momentum if bns[0].momentum is not None else 0.1
+    args = []
+    for l, bn in zip(layers, bns):
+        args += [l.conv.weight, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                 bn.num_batches_tracked, bn.eps]
+    stride = 0 if features_pm is None else features_pm.shape[-1]
+    return _SAMlpPool.apply(xyz.contiguous(), None if features_pm is None else features_pm.contiguous(),
+                            new_xyz.contiguous(), idx, module.radius, module.normalize_xyz, training,
+                            momentum, *args, feat_offset, stride)

@@ -51,7 +51,11 @@ class PointnetSAModuleVotes(nn.Module):
             return (feats * rbf.unsqueeze(1)).sum(-1) / float(self.nsample)
         raise ValueError(self.pooling)
 
-    def forward(self, xyz, features=None, inds=None):
+    def forward(self, xyz, features=None, inds=None, features_pm=None, feat_offset=0):
+        """``features_pm`` (optional, not in the reference signature): the same features point-major,
+        (B, N, feat_offset + C); lets consecutive levels hand activations over without a transpose.
+        After the call ``self.last_features_pm`` holds this level's output point-major (or None)."""
+        self.last_features_pm = None
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
@@ -60,6 +64,14 @@ class PointnetSAModuleVotes(nn.Module):
         if self.npoint is not None:
             new_xyz = pointnet2_utils.gather_operation(
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        from . import attention_blocks, fused_sa
+        if attention_blocks.get_backend() == "hip" and fused_sa.supported(self, xyz, features_pm):
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            if features_pm is None and features is not None:
+                features_pm, feat_offset = features.transpose(1, 2).contiguous(), 0
+            new_features, self.last_features_pm = fused_sa.sa_mlp_pool(
+                self, xyz, new_xyz, idx, features_pm, feat_offset)
+            return new_xyz, new_features, inds
         grouped = self.grouper(xyz, new_xyz, features)
         if self.ret_unique_cnt:
             grouped_features, grouped_xyz, unique_cnt = grouped

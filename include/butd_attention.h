@@ -39,6 +39,11 @@ typedef struct {
   int relu, accumulate, ones_col, split_k;
   float dropout_p;        /* 0 = off */
   uint32_t dropout_site;  /* stream id of the counter-based RNG */
+  /* Optional per-channel affine + ReLU applied to an operand while it is staged (folds
+   * BatchNorm + ReLU of the producing layer into the consumer GEMM):
+   *   A(m,k) <- relu(A(m,k) * a_chan_scale[k] + a_chan_shift[k])   (channel = contraction index)
+   *   B(n,k) <- relu(B(n,k) * b_chan_scale[n] + b_chan_shift[n])   (channel = output column)   */
+  const float *a_chan_scale, *a_chan_shift, *b_chan_scale, *b_chan_shift;
 } butd_gemm_problem;
 
 /* Launches up to 4 independent problems in ONE grid (blockIdx.z selects the problem).

@@ -1,0 +1,91 @@
+/*
+ * butd_sa.h -- C ABI of the set-abstraction shared-MLP pipeline (gfx950).
+ *
+ * Replaces, for PointnetSAModuleVotes (pointnet2/pointnet2_modules.py:210-272), the op chain
+ *   QueryAndGroup (pointnet2_utils.py:317-376) -> SharedMLP = 3 x [Conv2d 1x1 -> BatchNorm2d -> ReLU]
+ *   (pytorch_utils.py:11-36) -> max_pool2d over nsample (pointnet2_modules.py:251-257)
+ * and its backward.  Activations live position-major: row p = (b*npoint + j)*nsample + k, columns =
+ * channels, so every 1x1 convolution is a plain row-major GEMM (butd_gemm_grouped, with the previous
+ * layer's BatchNorm+ReLU folded into its operand load) and nothing is ever transposed to NCHW.
+ * All pointers are device pointers, fp32 unless stated; calls are asynchronous launches on `stream`
+ * (hipGraph-capturable); return 0 or a hipError_t.
+ */
+#ifndef BUTD_SA_H
+#define BUTD_SA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *butd_stream_t;
+
+/* X[p, 0:3] = (xyz[b, idx[p]] - new_xyz[b, j]) (/ radius if normalize), X[p, 3:3+C] = feats[b, idx[p], :]
+ * xyz (B,N,3); new_xyz (B,np,3); feats point-major with row stride feat_stride floats (may be NULL,
+ * C = 0); idx (B,np,ns) int32; X (B*np*ns, 3+C). */
+int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const float *new_xyz,
+                  const float *feats, long feat_stride, const int *idx, float radius, int normalize,
+                  float *X, butd_stream_t stream);
+
+/* Column statistics of Z (P x C): sum[c] += sum_p z, sumsq[c] += sum_p z^2 (double, atomically
+ * accumulated: caller zero-fills).  If pool_ns > 0 also the per-group (pool_ns consecutive rows)
+ * extrema of every column: zmax/zmin (P/pool_ns x C) and the row offset inside the group of their
+ * FIRST occurrence amax/amin (uint8).  C <= 256. */
+int butd_sa_colstats(long P, int C, const float *Z, double *sum, double *sumsq, int pool_ns,
+                     float *zmax, float *zmin, uint8_t *amax, uint8_t *amin, butd_stream_t stream);
+
+/* BatchNorm bookkeeping of one layer (training): from sum/sumsq over `count` rows ->
+ * mean[c], rstd[c] = 1/sqrt(var_biased+eps), scale[c] = gamma*rstd, shift[c] = beta - mean*scale;
+ * running_mean/var <- (1-momentum)*running + momentum*(mean / var_unbiased); num_batches_tracked += 1.
+ * training == 0: scale/shift from the running statistics, nothing updated. */
+int butd_sa_bn_finalize(int C, long count, const double *sum, const double *sumsq, const float *gamma,
+                        const float *beta, float eps, float momentum, int training, float *running_mean,
+                        float *running_var, int64_t *num_batches_tracked, float *mean, float *rstd,
+                        float *scale, float *shift, butd_stream_t stream);
+
+/* Pooled output of the last layer: for group g=(b,j) and channel c the max over the group of
+ * relu(scale*z+shift) is relu(scale*zsel+shift) with zsel = zmax if scale >= 0 else zmin.
+ * Writes out_cm (B,C,np) [the module's (B,C,npoint) output], out_pm (B,np,C) [point-major copy for the
+ * next level], zsel (G x C) and asel (G x C, uint8). */
+int butd_sa_pool_finalize(int B, int np, int C, const float *zmax, const float *zmin,
+                          const uint8_t *amax, const uint8_t *amin, const float *scale,
+                          const float *shift, float *out_cm, float *out_pm, float *zsel, uint8_t *asel,
+                          butd_stream_t stream);
+
+/* Backward through max-pool + ReLU + BatchNorm(train) of the last layer, part 1: per channel
+ * S1[c] = sum_g dy, S2[c] = sum_g dy * zhat_sel over the groups whose pooled activation is > 0
+ * (dy = d_out_cm[b,c,j]); S1 = dbeta, S2 = dgamma.  Caller zero-fills S1/S2 (double). */
+int butd_sa_pool_bwd_stats(int B, int np, int C, const float *d_out_cm, const float *zsel,
+                           const float *scale, const float *shift, const float *mean,
+                           const float *rstd, double *S1, double *S2, butd_stream_t stream);
+
+/* part 2, in place on Z (P x C) -> dZ:  dZ[p,c] = gamma*rstd * (dy3[p,c] - S1/P - zhat[p,c]*S2/P),
+ * dy3[p,c] = d_out_cm[b,c,j] if k(p) == asel[g,c] and the pooled activation is > 0, else 0.
+ * training == 0 (BN uses running statistics): dZ = scale * dy3. */
+int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_cm, const float *zsel,
+                    const uint8_t *asel, const float *gamma, const float *scale, const float *shift,
+                    const float *mean, const float *rstd, const double *S1, const double *S2,
+                    int training, butd_stream_t stream);
+
+/* Hidden layers, part 1, in place on dH (P x C): g = dH * [scale*z+shift > 0];
+ * S1[c] += sum_p g, S2[c] += sum_p g*zhat (double, caller zero-fills). */
+int butd_sa_mask_stats(long P, int C, float *dH, const float *Z, const float *scale,
+                       const float *shift, const float *mean, const float *rstd, double *S1,
+                       double *S2, butd_stream_t stream);
+
+/* part 2, in place on g -> dZ = gamma*rstd*(g - S1/P - zhat*S2/P)   (training == 0: dZ = scale*g). */
+int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, const float *scale,
+                   const float *mean, const float *rstd, const double *S1, const double *S2,
+                   int training, butd_stream_t stream);
+
+/* d_feats_pm[b, idx[p], c] += dX[p, 3 + c]  (dX (P, 3+C) row-major, d_feats_pm (B,N,C) point-major,
+ * caller zero-fills). */
+int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, const int *idx,
+                         float *d_feats_pm, butd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BUTD_SA_H */

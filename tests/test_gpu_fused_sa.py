@@ -1,0 +1,72 @@
+"""-m gpu: the fused set-abstraction pipeline (grouping gather + 3 x conv/BN/ReLU as MFMA GEMMs with
+folded BatchNorm + max-pool, forward and backward) vs the stock-torch module path, train and eval."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=1e-3, frac=0.0):
+    a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+    scale = max(np.abs(b).max(), 1e-6)
+    bad = np.abs(a - b) / scale > tol
+    assert bad.mean() <= frac, f"{bad.sum()}/{bad.size} beyond {tol}; max {np.abs(a - b).max() / scale:.3e}"
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=4096, C=3, npoint=512, radius=0.4, nsample=64, mlp=[3, 64, 64, 128]),     # SA1-like
+    dict(N=2048, C=128, npoint=1024, radius=0.6, nsample=32, mlp=[128, 128, 128, 256]),  # SA2
+    dict(N=1024, C=256, npoint=512, radius=0.9, nsample=16, mlp=[256, 128, 128, 256]),   # SA3
+])
+@pytest.mark.parametrize("train", [True, False])
+def test_sa_module_fused_matches_torch(cfg, train):
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(cfg["N"] + train)
+    B = 2
+    ref = PointnetSAModuleVotes(npoint=cfg["npoint"], radius=cfg["radius"], nsample=cfg["nsample"],
+                                mlp=list(cfg["mlp"]), use_xyz=True, normalize_xyz=True).cuda()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.1, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+        ref.mlp_module.layer1.bn.bn.weight[:5] *= -1.0      # negative scale -> min-pool branch
+    fused = copy.deepcopy(ref)
+    ref.train(train)
+    fused.train(train)
+    xyz = torch.rand(B, cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(B, cfg["C"], cfg["N"], device="cuda")
+    f1 = feats.clone().requires_grad_(True)
+    f2 = feats.clone().requires_grad_(True)
+    probe = torch.randn(B, cfg["mlp"][-1], cfg["npoint"], device="cuda")
+
+    attention_blocks.set_backend("torch")
+    x1, y1, i1 = ref(xyz, f1)
+    (y1 * probe).sum().backward()
+    attention_blocks.set_backend("hip")
+    try:
+        x2, y2, i2 = fused(xyz, f2)
+        assert fused.last_features_pm is not None, "fused path not taken"
+        (y2 * probe).sum().backward()
+    finally:
+        attention_blocks.set_backend("torch")
+    assert torch.equal(i1, i2) and torch.equal(x1, x2)
+    _close(y2, y1)
+    _close(fused.last_features_pm.transpose(1, 2), y1)
+    # max-pool arg-max flips between near-equal candidates reroute a few entries: allow 0.1 % outliers
+    _close(f2.grad, f1.grad, 2e-3, 1e-3)
+    for (n, p1), (_, p2) in zip(ref.named_parameters(), fused.named_parameters()):
+        if train or "bn" not in n:
+            _close(p2.grad, p1.grad, 1e-2, 1e-3)  # sums over up to 10^6 positions, fp32 reassociation
+    if train:
+        for (n, b1), (_, b2) in zip(ref.named_buffers(), fused.named_buffers()):
+            if "num_batches" in n:
+                assert int(b1) == int(b2) == 1
+            else:
+                _close(b2, b1, 1e-4)
