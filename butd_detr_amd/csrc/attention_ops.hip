@@ -59,6 +59,7 @@ __device__ inline TileIdx tile_idx(long ld_k, int tid) {
   return t;
 }
 
+template <bool WITH_A2 = true>
 __device__ inline Frag4 fetch_tile(const float *__restrict__ src, const float *__restrict__ src2,
                                    long ld_row, long ld_k, int row0, int nrows, int k0, int kend,
                                    int tid) {
@@ -80,7 +81,7 @@ __device__ inline Frag4 fetch_tile(const float *__restrict__ src, const float *_
       if (fast_g + 2 < fast_lim) f.a.z = src[o + 2];
       if (fast_g + 3 < fast_lim) f.a.w = src[o + 3];
     }
-    if (src2) {
+    if (WITH_A2 && src2) {
       if (vec && ((((uintptr_t)src2) & 15) == 0)) {
         f.a2 = *reinterpret_cast<const float4 *>(src2 + o);
       } else {
@@ -171,44 +172,17 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // double-buffered LDS, one barrier per slab: slab i+1 travels global -> registers while slab i is
-  // multiplied, then lands in the other buffer
   const bool ones = P.ones_col != 0;
-  Frag4 fa[kSub], fb[kSub];
-  int kfetched = kbeg;
-  auto fetch = [&](int k0) {
-    kfetched = k0;
-#pragma unroll
-    for (int u = 0; u < kSub; ++u) {
-      fa[u] = fetch_tile(P.a, P.a2, P.lda_m, P.lda_k, m0, P.M, k0 + u * 16, kend, tid);
-      fb[u] = fetch_tile(P.b, nullptr, P.ldb_n, P.ldb_k, n0, P.N, k0 + u * 16, kend, tid);
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int u = 0; u < kSub; ++u) {
-      commit_tile(As[buf], fa[u], P.a2 != nullptr, P.a2_mode, P.a2_scale, P.a_chan_scale,
-                  P.a_chan_shift, true, P.lda_k, m0, P.M, kfetched + u * 16, kend, false, u * 16, tid);
-      commit_tile(Bs[buf], fb[u], false, 0, 0.f, P.b_chan_scale, P.b_chan_shift, false, P.ldb_k, n0,
-                  P.N, kfetched + u * 16, kend, ones, u * 16, tid);
-    }
-  };
-  fetch(kbeg);
-  commit(0);
-  __syncthreads();
-  int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += kBK) {
-    const bool more = k0 + kBK < kend;
-    if (more) fetch(k0 + kBK);
+  auto mfma_slab = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < kSub; ++u) {
       f32x4 af[2], bf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const f32x4 *>(&As[cur][wr * 32 + i * 16 + fr][u * 16 + fg * 4]);
+        af[i] = *reinterpret_cast<const f32x4 *>(&As[buf][wr * 32 + i * 16 + fr][u * 16 + fg * 4]);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[cur][wc * 32 + j * 16 + fr][u * 16 + fg * 4]);
+        bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wc * 32 + j * 16 + fr][u * 16 + fg * 4]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -217,9 +191,129 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
-    if (more) commit(cur ^ 1);
+  };
+  // Fast path (interior tiles, the common case): every address is  base + slab * step  with the
+  // per-thread bases computed once; a slab costs each thread 2*kSub float4 loads, 2*kSub LDS writes and
+  // the MFMAs -- no bounds checks, no index arithmetic.  Edge tiles take the generic path below.
+  const bool a_kc = P.lda_k == 1, b_kc = P.ldb_k == 1;
+  const bool fast =
+      P.a2 == nullptr && !ones && ((kend - kbeg) % kBK) == 0 &&
+      (a_kc || (P.M & 3) == 0) && (b_kc || (P.N & 3) == 0) &&   // partial tiles: whole float4 in or out
+      ((a_kc ? P.lda_m : P.lda_k) & 3) == 0 && ((b_kc ? P.ldb_n : P.ldb_k) & 3) == 0 &&
+      ((((uintptr_t)P.a) | ((uintptr_t)P.b)) & 15) == 0 && (kbeg & 3) == 0;
+  if (fast) {
+    const int a_slow = a_kc ? (tid >> 2) : (tid >> 4), a_fast = a_kc ? (tid & 3) * 4 : (tid & 15) * 4;
+    const int b_slow = b_kc ? (tid >> 2) : (tid >> 4), b_fast = b_kc ? (tid & 3) * 4 : (tid & 15) * 4;
+    const float *pa = a_kc ? P.a + (long)(m0 + a_slow) * P.lda_m + kbeg + a_fast
+                           : P.a + (long)(kbeg + a_slow) * P.lda_k + m0 + a_fast;
+    const float *pb = b_kc ? P.b + (long)(n0 + b_slow) * P.ldb_n + kbeg + b_fast
+                           : P.b + (long)(kbeg + b_slow) * P.ldb_k + n0 + b_fast;
+    const long sa16 = a_kc ? 16 : 16 * P.lda_k, sb16 = b_kc ? 16 : 16 * P.ldb_k;  // per 16 k
+    // rows of this thread inside the matrix?  (loop-invariant; rows outside a partial tile read 0)
+    const bool a_ok = m0 + (a_kc ? a_slow : a_fast) < P.M;
+    const bool b_ok = n0 + (b_kc ? b_slow : b_fast) < P.N;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float *asc = P.a_chan_scale, *ash = P.a_chan_shift;   // channel = k (varies per slab)
+    float4 bsc4 = make_float4(1.f, 1.f, 1.f, 1.f), bsh4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool b_aff = P.b_chan_scale != nullptr;
+    if (b_aff && !b_kc) {  // channel = B row = 4 consecutive rows of this thread: loop-invariant
+      if (b_ok) {
+        bsc4 = *reinterpret_cast<const float4 *>(P.b_chan_scale + n0 + b_fast);
+        bsh4 = *reinterpret_cast<const float4 *>(P.b_chan_shift + n0 + b_fast);
+      }
+    } else if (b_aff && b_ok) {
+      const float sc = P.b_chan_scale[n0 + b_slow], sh = P.b_chan_shift[n0 + b_slow];
+      bsc4 = make_float4(sc, sc, sc, sc);
+      bsh4 = make_float4(sh, sh, sh, sh);
+    }
+    float4 ra[kSub], rb[kSub], rsc[kSub], rsh[kSub];
+    auto fetch_fast = [&](int slab) {
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        ra[u] = a_ok ? *reinterpret_cast<const float4 *>(pa + (long)(slab * kSub + u) * sa16) : zero4;
+        rb[u] = b_ok ? *reinterpret_cast<const float4 *>(pb + (long)(slab * kSub + u) * sb16) : zero4;
+        if (asc) {
+          const int kk = kbeg + (slab * kSub + u) * 16 + (a_kc ? a_fast : a_slow);
+          if (a_kc) {
+            rsc[u] = *reinterpret_cast<const float4 *>(asc + kk);
+            rsh[u] = *reinterpret_cast<const float4 *>(ash + kk);
+          } else {
+            const float sc = asc[kk], sh = ash[kk];
+            rsc[u] = make_float4(sc, sc, sc, sc);
+            rsh[u] = make_float4(sh, sh, sh, sh);
+          }
+        }
+      }
+    };
+    auto put = [&](float (*tile)[kLd], bool kc, int slow, int fst, int koff, float4 v) {
+      if (kc) {
+        *reinterpret_cast<float4 *>(&tile[slow][koff + fst]) = v;
+      } else {
+        tile[fst + 0][koff + slow] = v.x; tile[fst + 1][koff + slow] = v.y;
+        tile[fst + 2][koff + slow] = v.z; tile[fst + 3][koff + slow] = v.w;
+      }
+    };
+    auto commit_fast = [&](int buf) {
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        float4 va = ra[u], vb = rb[u];
+        if (asc && a_ok) {
+          va.x = fmaxf(va.x * rsc[u].x + rsh[u].x, 0.f); va.y = fmaxf(va.y * rsc[u].y + rsh[u].y, 0.f);
+          va.z = fmaxf(va.z * rsc[u].z + rsh[u].z, 0.f); va.w = fmaxf(va.w * rsc[u].w + rsh[u].w, 0.f);
+        }
+        if (b_aff && b_ok) {
+          vb.x = fmaxf(vb.x * bsc4.x + bsh4.x, 0.f); vb.y = fmaxf(vb.y * bsc4.y + bsh4.y, 0.f);
+          vb.z = fmaxf(vb.z * bsc4.z + bsh4.z, 0.f); vb.w = fmaxf(vb.w * bsc4.w + bsh4.w, 0.f);
+        }
+        put(As[buf], a_kc, a_slow, a_fast, u * 16, va);
+        put(Bs[buf], b_kc, b_slow, b_fast, u * 16, vb);
+      }
+    };
+    const int nslab = (kend - kbeg) / kBK;
+    fetch_fast(0);
+    commit_fast(0);
     __syncthreads();
-    cur ^= 1;
+    for (int sl = 0; sl < nslab; ++sl) {
+      const bool more = sl + 1 < nslab;
+      if (more) fetch_fast(sl + 1);
+      mfma_slab(sl & 1);
+      if (more) commit_fast((sl + 1) & 1);
+      __syncthreads();
+    }
+  } else {
+    // streaming: double-buffered LDS, one barrier per slab: slab i+1 travels global -> registers while
+    // slab i is multiplied, then lands in the other buffer
+    Frag4 fa[kSub], fb[kSub];
+    int kfetched = kbeg;
+    auto fetch = [&](int k0) {
+      kfetched = k0;
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        fa[u] = fetch_tile(P.a, P.a2, P.lda_m, P.lda_k, m0, P.M, k0 + u * 16, kend, tid);
+        fb[u] = fetch_tile<false>(P.b, nullptr, P.ldb_n, P.ldb_k, n0, P.N, k0 + u * 16, kend, tid);
+      }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+      for (int u = 0; u < kSub; ++u) {
+        commit_tile(As[buf], fa[u], P.a2 != nullptr, P.a2_mode, P.a2_scale, P.a_chan_scale,
+                    P.a_chan_shift, true, P.lda_k, m0, P.M, kfetched + u * 16, kend, false, u * 16, tid);
+        commit_tile(Bs[buf], fb[u], false, 0, 0.f, P.b_chan_scale, P.b_chan_shift, false, P.ldb_k, n0,
+                    P.N, kfetched + u * 16, kend, ones, u * 16, tid);
+      }
+    };
+    fetch(kbeg);
+    commit(0);
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += kBK) {
+      const bool more = k0 + kBK < kend;
+      if (more) fetch(k0 + kBK);
+      mfma_slab(cur);
+      if (more) commit(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   // epilogue: lane holds C[row = fg*4 + r][col = fr] of each 16x16 tile.  Everything that is LOADED
@@ -235,6 +329,55 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
   const long ldc = P.ldc;
   const float scale = P.scale, p_drop = P.dropout_p;
   const uint32_t site = P.dropout_site;
+  if (!accumulate && !ones_col) {
+    // Plain stores: stage the 64x64 tile through LDS (the operand buffers are free after the last
+    // barrier) so every thread writes whole float4 row segments -- the MFMA C-layout would otherwise
+    // emit sixteen 4-byte stores per lane, 64 contiguous bytes per wave-instruction.
+    float(*Cs)[kBN + 4] = reinterpret_cast<float(*)[kBN + 4]>(&As[0][0][0]);
+    static_assert(sizeof(As) >= sizeof(float) * kBM * (kBN + 4), "C tile must fit the A buffers");
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Cs[wr * 32 + i * 16 + fg * 4 + r][wc * 32 + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const int c4 = (tid & 15) * 4;
+    const int n = n0 + c4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (P.bias && slice == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < pN) bv[e] = P.bias[n + e];
+    }
+    const bool vec_ok = (n + 3 < pN) && ((ldc & 3) == 0) && ((((uintptr_t)cptr) & 15) == 0);
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int row = (tid >> 4) + qq * 16;
+      const int m = m0 + row;
+      if (m >= pM || n >= pN) continue;
+      const float4 cv = *reinterpret_cast<const float4 *>(&Cs[row][c4]);
+      float v[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = (v[e] + bv[e]) * scale;
+        if (relu) v[e] = fmaxf(v[e], 0.f);
+        if (drop)
+          v[e] = rng::keep(ctr, site, (uint32_t)((long)m * pN + n + e), p_drop) ? v[e] * inv_keep : 0.f;
+      }
+      float *dst = cptr + (long)m * ldc + n;
+      if (vec_ok) {
+        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < pN) dst[e] = v[e];
+      }
+    }
+    return;
+  }
+  // accumulate / bias-gradient path: element-wise atomics straight from the accumulators
   float bias_v[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -256,9 +399,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
           if (relu) v = fmaxf(v, 0.f);
           if (drop)
             v = rng::keep(ctr, site, (uint32_t)((long)m * pN + n), p_drop) ? v * inv_keep : 0.f;
-          float *dst = cptr + (long)m * ldc + n;
-          if (accumulate) atomicAdd(dst, v);
-          else *dst = v;
+          atomicAdd(cptr + (long)m * ldc + n, v);
         } else if (ones_col && n == pN) {
           atomicAdd(bgrad + m, v * scale);
         }
