@@ -1,0 +1,75 @@
+"""CPU, world_size 2, gloo: the data-parallel path of the training step.
+
+(1) ``DistributedDataParallel`` around the drop-in model exactly as main_utils.py:310-313 wraps the
+reference (no find_unused_parameters, broadcast_buffers=False): every trainable parameter must receive a
+gradient and the ranks must end up with identical averaged gradients.  (2) The bench's flat-gradient
+exchange (one all-reduce of the packed buffer) must produce the same gradients as DDP.
+The point operators have no CPU implementation, so -- in this test only -- the oracle stands in for them.
+"""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, init_file, out_dir):
+    sys.path.insert(0, ROOT)
+    import warnings
+    from butd_detr_amd import pointnet2_utils
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from butd_detr_amd.train_step import (FlatGradients, make_optimizer, surrogate_loss,
+                                          synthetic_batch, wrap_data_parallel)
+    from oracle import ext_adapter
+    from tests.golden import text_stub, weights
+    pointnet2_utils._ext = ext_adapter          # test-only stand-in (see module docstring)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_queries=16, num_decoder_layers=1, text_encoder_factory=text_stub.factory,
+                           class_embeddings_path=None)
+    weights.fill_(model, seed=3, skip_prefixes=("text_encoder.",))
+    model.eval()        # deterministic forward (no dropout); BN uses running stats -> ranks comparable
+    dev = torch.device("cpu")
+    inputs, targets = synthetic_batch(1, dev, n_points=2304, tokens=10, rank=rank)
+
+    # (1) DDP
+    ddp = wrap_data_parallel(model, dev)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    loss = surrogate_loss(ddp(inputs), targets)
+    loss.backward()
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    assert all(p.grad is not None for _, p in named), [n for n, p in named if p.grad is None]
+    ddp_grads = [p.grad.clone() for _, p in named]
+
+    # (2) flat-gradient exchange on the bare model
+    for _, p in named:
+        p.grad = None
+    loss2 = surrogate_loss(model(inputs), targets)
+    loss2.backward()
+    flat = FlatGradients([p for _, p in named])
+    flat.gather([p.grad for p in flat.params])
+    flat.all_reduce_mean()
+    flat.attach()
+    worst = max(float((p.grad - g).abs().max() / (g.abs().max() + 1e-12)) for (_, p), g in zip(named, ddp_grads))
+    torch.save({"worst": worst, "grad0": ddp_grads[0], "loss": float(loss)}, os.path.join(out_dir, f"r{rank}.pt"))
+    opt = make_optimizer(model)
+    opt.step()
+    dist.destroy_process_group()
+
+
+def test_ddp_and_flat_allreduce_agree_world2():
+    with tempfile.TemporaryDirectory() as d:
+        init = os.path.join(d, "init")
+        mp.spawn(_worker, args=(2, init, d), nprocs=2, join=True)
+        r0 = torch.load(os.path.join(d, "r0.pt"))
+        r1 = torch.load(os.path.join(d, "r1.pt"))
+    assert r0["worst"] < 1e-5 and r1["worst"] < 1e-5           # flat exchange == DDP
+    assert torch.allclose(r0["grad0"], r1["grad0"])            # ranks hold the same averaged grads
+    assert r0["loss"] != r1["loss"]                            # ... computed from different scenes
