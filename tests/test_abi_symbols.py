@@ -68,3 +68,26 @@ def test_product_package_never_imports_the_oracle():
     for path in glob.glob(os.path.join(ROOT, "butd_detr_amd", "**", "*.py"), recursive=True):
         src = open(path).read()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+
+
+def test_dropin_registers_reference_module_names(libpath, monkeypatch):
+    import sys
+    for k in [k for k in sys.modules if k == "models" or k.startswith(("models.", "pointnet2"))]:
+        monkeypatch.delitem(sys.modules, k)
+    from butd_detr_amd import attention_blocks, dropin
+    prev = attention_blocks.get_backend()
+    try:
+        dropin.install(attention_backend="torch")
+        import pointnet2._ext as _ext
+        import pointnet2_utils
+        from models import BeaUTyDETR
+        from pointnet2.pointnet2_utils import gather_operation   # models/modules.py:16
+        assert {"gather_points", "gather_points_grad", "furthest_point_sampling", "three_nn",
+                "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
+                "group_points_grad"} <= set(dir(_ext))           # bindings.cpp:11-24
+        for n in ("furthest_point_sample", "gather_operation", "three_nn", "three_interpolate",
+                  "grouping_operation", "ball_query", "QueryAndGroup", "GroupAll"):
+            assert hasattr(pointnet2_utils, n)
+        assert BeaUTyDETR.__name__ == "BeaUTyDETR" and callable(gather_operation)
+    finally:
+        attention_blocks.set_backend(prev)
