@@ -212,7 +212,8 @@ def main():
         def train_step(_m, _o, i, t):
             return eager_step(ddp, opt, i, t)
     else:
-        opt = make_optimizer(model, capturable=True)
+        from butd_detr_amd.train_step import FlatAdamW
+        opt = FlatAdamW(model)
         graphed = GraphedTrainStep(model, opt)
         ddp = model
 
@@ -248,7 +249,7 @@ def main():
                                    f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "
                                    "3 encoder + 6 decoder layers, fwd+loss+bwd+clip+AdamW, train mode",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "attention_backend": backend, "launch": "eager+DDP" if args.eager else "hipGraph replay + flat-gradient all-reduce", "final_loss": round(float(loss), 4)},
+                       "attention_backend": backend, "launch": "eager+DDP+torch AdamW" if args.eager else "hipGraph replay + flat-gradient all-reduce + flat AdamW", "final_loss": round(float(loss), 4)},
         }
         if backend == "hip":
             out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, targets))

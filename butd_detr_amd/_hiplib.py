@@ -73,9 +73,14 @@ SA_SYMBOLS = {
     "butd_sa_scatter_rows": (_c_int, [_c_int] * 5 + [_P] * 3 + [_P]),
 }
 
+OPTIM_SYMBOLS = {
+    "butd_adamw_flat": (_c_int, [_P] * 4 + [_c_long, _c_long] + [_c_float] * 5 + [_P, _P, _P]),
+}
+
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
 ALL_SYMBOLS.update(ATTENTION_SYMBOLS)
 ALL_SYMBOLS.update(SA_SYMBOLS)
+ALL_SYMBOLS.update(OPTIM_SYMBOLS)
 
 _lib = None
 

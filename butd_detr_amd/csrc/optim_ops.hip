@@ -1,0 +1,51 @@
+// optim_ops.hip -- flat AdamW update (include/butd_optim.h): one float4 stream over p, g, m, v.
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "../../include/butd_optim.h"
+
+namespace {
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, const float *__restrict__ g,
+                                                         float *__restrict__ m, float *__restrict__ v,
+                                                         long begin, long end, float lr, float b1, float b2,
+                                                         float eps, float wd, const float *__restrict__ step,
+                                                         const float *__restrict__ grad_scale) {
+  const float t = *step;
+  const float gs = grad_scale ? *grad_scale : 1.f;
+  const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+  const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2), decay = 1.f - lr * wd;
+  const long n4 = (end - begin) >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long o = begin + i * 4;
+    float4 pp = *reinterpret_cast<float4 *>(p + o), mm = *reinterpret_cast<float4 *>(m + o),
+           vv = *reinterpret_cast<float4 *>(v + o);
+    const float4 gg = *reinterpret_cast<const float4 *>(g + o);
+    float pe[4] = {pp.x, pp.y, pp.z, pp.w}, me[4] = {mm.x, mm.y, mm.z, mm.w},
+          ve[4] = {vv.x, vv.y, vv.z, vv.w};
+    const float ge[4] = {gg.x * gs, gg.y * gs, gg.z * gs, gg.w * gs};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pe[e] *= decay;
+      me[e] = b1 * me[e] + (1.f - b1) * ge[e];
+      ve[e] = b2 * ve[e] + (1.f - b2) * ge[e] * ge[e];
+      pe[e] -= step_size * me[e] / (sqrtf(ve[e]) * inv_sqrt_bc2 + eps);
+    }
+    *reinterpret_cast<float4 *>(p + o) = make_float4(pe[0], pe[1], pe[2], pe[3]);
+    *reinterpret_cast<float4 *>(m + o) = make_float4(me[0], me[1], me[2], me[3]);
+    *reinterpret_cast<float4 *>(v + o) = make_float4(ve[0], ve[1], ve[2], ve[3]);
+  }
+}
+}  // namespace
+
+extern "C" int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, long end, float lr,
+                               float beta1, float beta2, float eps, float weight_decay, const float *step,
+                               const float *grad_scale, butd_stream_t stream) {
+  if (end <= begin) return 0;
+  if ((begin & 3) || (end & 3)) return (int)hipErrorInvalidValue;  // segments are padded to 4 floats
+  const long n4 = (end - begin) >> 2;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
+                     begin, end, lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+  return (int)hipGetLastError();
+}

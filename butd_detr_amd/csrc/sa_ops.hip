@@ -44,52 +44,62 @@ __global__ __launch_bounds__(kThreads) void sa_group_kernel(int N, int np, int n
 }
 
 // ------------------------------------------------------------------------- column stats (+ pooling)
-// Workgroup = 256 threads over a chunk of rows x all C columns.  With TPC = 256 / C threads per column,
-// thread (col, sub) owns every TPC-th GROUP of the chunk (groups = pool_ns rows, or single rows when
-// not pooling), so the pooling needs no cross-thread step; the sums are reduced across `sub` in LDS and
-// leave the block as ONE double atomic per column.
-constexpr int kChunkRows = 512;
+// Workgroup = 256 threads over a chunk of kChunkRows rows x all C columns.  A thread owns FOUR adjacent
+// columns (one float4 per row) and every TPG-th GROUP of the chunk, TPG = 256 / (C/4) (groups =
+// pool_ns rows, or single rows when not pooling), so the pooling needs no cross-thread step and every
+// load is a coalesced 16-byte access; sums are reduced across the TPG row-phases in LDS and leave the
+// block as ONE double atomic per column.
+constexpr int kChunkRows = 256;
 
 __global__ __launch_bounds__(kThreads) void sa_colstats_kernel(
     long P, int C, const float *__restrict__ Z, double *__restrict__ sum, double *__restrict__ sumsq,
     int pool_ns, float *__restrict__ zmax, float *__restrict__ zmin, uint8_t *__restrict__ amax,
     uint8_t *__restrict__ amin) {
-  __shared__ float red[2][kThreads];
-  const int tpc = kThreads / C;           // C in {64,128,256} -> 4,2,1 ; other C: see host
-  const int col = threadIdx.x % C, sub = threadIdx.x / C;
-  const bool active = sub < tpc;
+  __shared__ float red[2][kThreads][4];
+  const int c4n = C >> 2;                 // float4 columns (16, 32 or 64)
+  const int tpg = kThreads / c4n;         // row phases (16, 8 or 4)
+  const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
   const int gs = pool_ns > 0 ? pool_ns : 1;
   const long row0 = (long)blockIdx.x * kChunkRows;
   const long rows = min((long)kChunkRows, P - row0);
   const long ngroups = rows / gs;
-  float s = 0.f, q = 0.f;
-  if (active) {
-    for (long g = sub; g < ngroups; g += tpc) {
-      const float *z = Z + (row0 + g * gs) * C + col;
-      float mx = -INFINITY, mn = INFINITY;
-      int ax = 0, an = 0;
-      for (int k = 0; k < gs; ++k) {
-        const float v = z[(long)k * C];
-        s += v;
-        q += v * v;
-        if (v > mx) { mx = v; ax = k; }
-        if (v < mn) { mn = v; an = k; }
-      }
-      if (pool_ns > 0) {
-        const long o = ((row0 / gs) + g) * C + col;
-        zmax[o] = mx; zmin[o] = mn;
-        amax[o] = (uint8_t)ax; amin[o] = (uint8_t)an;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long g = sub; g < ngroups; g += tpg) {
+    const float *z = Z + (row0 + g * gs) * C + cq * 4;
+    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float mn[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    int ax[4] = {0, 0, 0, 0}, an[4] = {0, 0, 0, 0};
+    for (int k = 0; k < gs; ++k) {
+      const float4 v4 = *reinterpret_cast<const float4 *>(z + (long)k * C);
+      const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s[e] += v[e];
+        q[e] += v[e] * v[e];
+        if (v[e] > mx[e]) { mx[e] = v[e]; ax[e] = k; }
+        if (v[e] < mn[e]) { mn[e] = v[e]; an[e] = k; }
       }
     }
+    if (pool_ns > 0) {
+      const long o = ((row0 / gs) + g) * C + cq * 4;
+      *reinterpret_cast<float4 *>(zmax + o) = make_float4(mx[0], mx[1], mx[2], mx[3]);
+      *reinterpret_cast<float4 *>(zmin + o) = make_float4(mn[0], mn[1], mn[2], mn[3]);
+      *reinterpret_cast<uchar4 *>(amax + o) = make_uchar4(ax[0], ax[1], ax[2], ax[3]);
+      *reinterpret_cast<uchar4 *>(amin + o) = make_uchar4(an[0], an[1], an[2], an[3]);
+    }
   }
-  red[0][threadIdx.x] = s;
-  red[1][threadIdx.x] = q;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][threadIdx.x][e] = s[e];
+    red[1][threadIdx.x][e] = q[e];
+  }
   __syncthreads();
   if (threadIdx.x < C) {
+    const int cq2 = threadIdx.x >> 2, e = threadIdx.x & 3;
     double a = 0.0, b = 0.0;
-    for (int t = 0; t < tpc; ++t) {
-      a += (double)red[0][threadIdx.x + t * C];
-      b += (double)red[1][threadIdx.x + t * C];
+    for (int t = 0; t < tpg; ++t) {
+      a += (double)red[0][cq2 + t * c4n][e];
+      b += (double)red[1][cq2 + t * c4n][e];
     }
     atomicAdd(sum + threadIdx.x, a);
     atomicAdd(sumsq + threadIdx.x, b);
@@ -153,12 +163,12 @@ __global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(
     int np, int C, long G, const float *__restrict__ d_out_cm, const float *__restrict__ zsel,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, double *__restrict__ S1, double *__restrict__ S2) {
-  // block = 256 groups x all channels: thread t owns column (t % C), groups sub, sub+tpc, ...
+  // block = 32 groups x all channels: thread t owns column (t % C), groups sub, sub+tpc, ...
   __shared__ float red[2][kThreads];
   const int tpc = kThreads / C;
   const int col = threadIdx.x % C, sub = threadIdx.x / C;
-  const long g0 = (long)blockIdx.x * 256;
-  const long ng = min((long)256, G - g0);
+  const long g0 = (long)blockIdx.x * 32;
+  const long ng = min((long)32, G - g0);
   float s1 = 0.f, s2 = 0.f;
   if (sub < tpc) {
     const float sc = scale[col], sh = shift[col], mu = mean[col], rs = rstd[col];
@@ -188,32 +198,47 @@ __global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(
   }
 }
 
+// dZ of the last layer, in place on Z: workgroup = kChunkRows rows x all columns, a thread owns one
+// float4 column group and every TPG-th row (same decomposition as the statistics kernels).
 __global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
-    int np, int ns, int C, long total, float *__restrict__ Z, const float *__restrict__ d_out_cm,
+    int np, int ns, int C, long P, float *__restrict__ Z, const float *__restrict__ d_out_cm,
     const float *__restrict__ zsel, const uint8_t *__restrict__ asel, const float *__restrict__ gamma,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, const double *__restrict__ S1, const double *__restrict__ S2,
     int training) {
-  const double invP = 1.0 / (double)(total / C);
-  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
-    const int c = (int)(e % C);
-    const long p = e / C;
+  const int c4n = C >> 2, tpg = kThreads / c4n;
+  const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
+  const long row0 = (long)blockIdx.x * kChunkRows;
+  const long rows = min((long)kChunkRows, P - row0);
+  const double invP = 1.0 / (double)P;
+  float sc[4], sh[4], mu[4], rs[4], ga[4], a1[4], a2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = cq * 4 + e;
+    sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; rs[e] = rstd[c]; ga[e] = gamma[c];
+    a1[e] = (float)(S1[c] * invP);
+    a2[e] = (float)(S2[c] * invP);
+  }
+  for (long r = sub; r < rows; r += tpg) {
+    const long p = row0 + r;
     const long g = p / ns;
     const int k = (int)(p - g * ns);
     const long b = g / np;
     const int j = (int)(g - b * np);
-    const float sc = scale[c];
-    float dy = 0.f;
-    if ((int)asel[g * C + c] == k && sc * zsel[g * C + c] + shift[c] > 0.f)
-      dy = d_out_cm[(b * C + c) * np + j];
-    float dz;
-    if (training) {
-      const float zh = (Z[e] - mean[c]) * rstd[c];
-      dz = gamma[c] * rstd[c] * (dy - (float)(S1[c] * invP) - zh * (float)(S2[c] * invP));
-    } else {
-      dz = sc * dy;
+    const long o = p * C + cq * 4;
+    const float4 z4 = *reinterpret_cast<const float4 *>(Z + o);
+    const float4 zs4 = *reinterpret_cast<const float4 *>(zsel + g * C + cq * 4);
+    const uchar4 as4 = *reinterpret_cast<const uchar4 *>(asel + g * C + cq * 4);
+    const float z[4] = {z4.x, z4.y, z4.z, z4.w}, zs[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
+    const int as[4] = {as4.x, as4.y, as4.z, as4.w};
+    float out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float dy = 0.f;
+      if (as[e] == k && sc[e] * zs[e] + sh[e] > 0.f) dy = d_out_cm[(b * C + cq * 4 + e) * np + j];
+      out[e] = training ? ga[e] * rs[e] * (dy - a1[e] - (z[e] - mu[e]) * rs[e] * a2[e]) : sc[e] * dy;
     }
-    Z[e] = dz;
+    *reinterpret_cast<float4 *>(Z + o) = make_float4(out[0], out[1], out[2], out[3]);
   }
 }
 
@@ -221,32 +246,44 @@ __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
     long P, int C, float *__restrict__ dH, const float *__restrict__ Z, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
     double *__restrict__ S1, double *__restrict__ S2) {
-  __shared__ float red[2][kThreads];
-  const int tpc = kThreads / C;
-  const int col = threadIdx.x % C, sub = threadIdx.x / C;
+  __shared__ float red[2][kThreads][4];
+  const int c4n = C >> 2, tpg = kThreads / c4n;
+  const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
   const long row0 = (long)blockIdx.x * kChunkRows;
   const long rows = min((long)kChunkRows, P - row0);
-  float s1 = 0.f, s2 = 0.f;
-  if (sub < tpc) {
-    const float sc = scale[col], sh = shift[col], mu = mean[col], rs = rstd[col];
-    for (long r = sub; r < rows; r += tpc) {
-      const long o = (row0 + r) * C + col;
-      const float z = Z[o];
-      float g = dH[o];
-      if (!(sc * z + sh > 0.f)) g = 0.f;
-      dH[o] = g;
-      s1 += g;
-      s2 += g * (z - mu) * rs;
+  const float4 sc4 = *reinterpret_cast<const float4 *>(scale + cq * 4);
+  const float4 sh4 = *reinterpret_cast<const float4 *>(shift + cq * 4);
+  const float4 mu4 = *reinterpret_cast<const float4 *>(mean + cq * 4);
+  const float4 rs4 = *reinterpret_cast<const float4 *>(rstd + cq * 4);
+  const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+  const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, rs[4] = {rs4.x, rs4.y, rs4.z, rs4.w};
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long r = sub; r < rows; r += tpg) {
+    const long o = (row0 + r) * C + cq * 4;
+    const float4 z4 = *reinterpret_cast<const float4 *>(Z + o);
+    float4 g4 = *reinterpret_cast<const float4 *>(dH + o);
+    const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+    float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!(sc[e] * z[e] + sh[e] > 0.f)) g[e] = 0.f;
+      s1[e] += g[e];
+      s2[e] += g[e] * (z[e] - mu[e]) * rs[e];
     }
+    *reinterpret_cast<float4 *>(dH + o) = make_float4(g[0], g[1], g[2], g[3]);
   }
-  red[0][threadIdx.x] = s1;
-  red[1][threadIdx.x] = s2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][threadIdx.x][e] = s1[e];
+    red[1][threadIdx.x][e] = s2[e];
+  }
   __syncthreads();
   if (threadIdx.x < C) {
+    const int cq2 = threadIdx.x >> 2, e = threadIdx.x & 3;
     double a = 0.0, b = 0.0;
-    for (int t = 0; t < tpc; ++t) {
-      a += (double)red[0][threadIdx.x + t * C];
-      b += (double)red[1][threadIdx.x + t * C];
+    for (int t = 0; t < tpg; ++t) {
+      a += (double)red[0][cq2 + t * c4n][e];
+      b += (double)red[1][cq2 + t * c4n][e];
     }
     atomicAdd(S1 + threadIdx.x, a);
     atomicAdd(S2 + threadIdx.x, b);
@@ -254,20 +291,32 @@ __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
 }
 
 __global__ __launch_bounds__(kThreads) void sa_dz_mid_kernel(
-    long total, int C, float *__restrict__ g, const float *__restrict__ Z, const float *__restrict__ gamma,
+    long P, int C, float *__restrict__ g, const float *__restrict__ Z, const float *__restrict__ gamma,
     const float *__restrict__ scale, const float *__restrict__ mean, const float *__restrict__ rstd,
     const double *__restrict__ S1, const double *__restrict__ S2, int training) {
-  const double invP = 1.0 / (double)(total / C);
-  for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
-    const int c = (int)(e % C);
-    float dz;
-    if (training) {
-      const float zh = (Z[e] - mean[c]) * rstd[c];
-      dz = gamma[c] * rstd[c] * (g[e] - (float)(S1[c] * invP) - zh * (float)(S2[c] * invP));
-    } else {
-      dz = scale[c] * g[e];
-    }
-    g[e] = dz;
+  const int c4n = C >> 2, tpg = kThreads / c4n;
+  const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
+  const long row0 = (long)blockIdx.x * kChunkRows;
+  const long rows = min((long)kChunkRows, P - row0);
+  const double invP = 1.0 / (double)P;
+  float sc[4], mu[4], rs[4], ga[4], a1[4], a2[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = cq * 4 + e;
+    sc[e] = scale[c]; mu[e] = mean[c]; rs[e] = rstd[c]; ga[e] = gamma[c];
+    a1[e] = (float)(S1[c] * invP);
+    a2[e] = (float)(S2[c] * invP);
+  }
+  for (long r = sub; r < rows; r += tpg) {
+    const long o = (row0 + r) * C + cq * 4;
+    const float4 z4 = *reinterpret_cast<const float4 *>(Z + o);
+    const float4 g4 = *reinterpret_cast<const float4 *>(g + o);
+    const float z[4] = {z4.x, z4.y, z4.z, z4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    float out[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      out[e] = training ? ga[e] * rs[e] * (gv[e] - a1[e] - (z[e] - mu[e]) * rs[e] * a2[e]) : sc[e] * gv[e];
+    *reinterpret_cast<float4 *>(g + o) = make_float4(out[0], out[1], out[2], out[3]);
   }
 }
 
@@ -291,7 +340,7 @@ inline unsigned blocks_for(long total, int cap = 16384) {
   if (b < 1) b = 1;
   return (unsigned)b;
 }
-inline bool cols_ok(int C) { return C > 0 && C <= kThreads && kThreads % C == 0; }
+inline bool cols_ok(int C) { return C >= 16 && C <= kThreads && kThreads % C == 0; }
 
 }  // namespace
 
@@ -347,7 +396,7 @@ int butd_sa_pool_bwd_stats(int B, int np, int C, const float *d_out_cm, const fl
   const long G = (long)B * np;
   if (G <= 0) return 0;
   if (!cols_ok(C)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3((unsigned)((G + 255) / 256)), dim3(kThreads), 0,
+  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3((unsigned)((G + 31) / 32)), dim3(kThreads), 0,
                      (hipStream_t)stream, np, C, G, d_out_cm, zsel, scale, shift, mean, rstd, S1, S2);
   return (int)hipGetLastError();
 }
@@ -356,11 +405,12 @@ int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_c
                     const uint8_t *asel, const float *gamma, const float *scale, const float *shift,
                     const float *mean, const float *rstd, const double *S1, const double *S2,
                     int training, butd_stream_t stream) {
-  const long total = (long)B * np * ns * C;
-  if (total <= 0) return 0;
-  hipLaunchKernelGGL(sa_dz_last_kernel, dim3(blocks_for(total, 65536)), dim3(kThreads), 0,
-                     (hipStream_t)stream, np, ns, C, total, Z, d_out_cm, zsel, asel, gamma, scale, shift,
-                     mean, rstd, S1, S2, training);
+  const long P = (long)B * np * ns;
+  if (P <= 0) return 0;
+  if (!cols_ok(C)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sa_dz_last_kernel, dim3((unsigned)((P + kChunkRows - 1) / kChunkRows)),
+                     dim3(kThreads), 0, (hipStream_t)stream, np, ns, C, P, Z, d_out_cm, zsel, asel, gamma,
+                     scale, shift, mean, rstd, S1, S2, training);
   return (int)hipGetLastError();
 }
 
@@ -378,10 +428,11 @@ int butd_sa_mask_stats(long P, int C, float *dH, const float *Z, const float *sc
 int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, const float *scale,
                    const float *mean, const float *rstd, const double *S1, const double *S2,
                    int training, butd_stream_t stream) {
-  const long total = P * C;
-  if (total <= 0) return 0;
-  hipLaunchKernelGGL(sa_dz_mid_kernel, dim3(blocks_for(total, 65536)), dim3(kThreads), 0,
-                     (hipStream_t)stream, total, C, g, Z, gamma, scale, mean, rstd, S1, S2, training);
+  if (P <= 0) return 0;
+  if (!cols_ok(C)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sa_dz_mid_kernel, dim3((unsigned)((P + kChunkRows - 1) / kChunkRows)),
+                     dim3(kThreads), 0, (hipStream_t)stream, P, C, g, Z, gamma, scale, mean, rstd, S1, S2,
+                     training);
   return (int)hipGetLastError();
 }
 

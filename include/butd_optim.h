@@ -1,0 +1,28 @@
+/*
+ * butd_optim.h -- C ABI of the flat AdamW update (gfx950).
+ *
+ * The reference optimises with torch.optim.AdamW over three parameter groups (main_utils.py:258-283)
+ * after clip_grad_norm_(0.1) (main_utils.py:432-436).  With all parameters, gradients and moments
+ * packed into contiguous fp32 buffers the whole update is ONE streaming kernel (28 B/parameter) instead
+ * of the multi-tensor path's 18 launches at a tenth of the HBM rate.
+ */
+#ifndef BUTD_OPTIM_H
+#define BUTD_OPTIM_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef void *butd_stream_t;
+
+/* AdamW (decoupled weight decay, torch semantics) on p[begin:end) of the packed buffers:
+ *   g' = g * *grad_scale (device scalar: the clip coefficient, NULL = 1)
+ *   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = *step (device scalar, float, >= 1). */
+int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, long end, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, const float *step,
+                    const float *grad_scale, butd_stream_t stream);
+#ifdef __cplusplus
+}
+#endif
+#endif
