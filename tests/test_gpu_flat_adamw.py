@@ -46,4 +46,4 @@ def test_flat_adamw_matches_torch_adamw():
     # such entries by a fraction of lr), so compare the bulk
     for (n, a), (_, b) in zip(ref.named_parameters(), mine.named_parameters()):
         d = (a - b).abs().detach().cpu().numpy()
-        assert (d < 2e-6).mean() > 0.75 and d.max() < 1e-3, (n, d.max())
+        assert (d < 1e-5).mean() > 0.9 and d.max() < 1e-3, (n, d.max())
