@@ -46,7 +46,10 @@ class GemmProblem(ctypes.Structure):
                 ("relu", _c_int), ("accumulate", _c_int), ("ones_col", _c_int), ("split_k", _c_int),
                 ("dropout_p", _c_float), ("dropout_site", _c_u32),
                 ("a_chan_scale", _c_void_p), ("a_chan_shift", _c_void_p),
-                ("b_chan_scale", _c_void_p), ("b_chan_shift", _c_void_p)]
+                ("b_chan_scale", _c_void_p), ("b_chan_shift", _c_void_p),
+                ("a_drop_p", _c_float), ("a_drop_site", _c_u32),
+                ("b_drop_p", _c_float), ("b_drop_site", _c_u32),
+                ("col_sum", _c_void_p), ("col_sumsq", _c_void_p)]
 
 
 ATTENTION_SYMBOLS = {
@@ -77,10 +80,27 @@ OPTIM_SYMBOLS = {
     "butd_adamw_flat": (_c_int, [_P] * 4 + [_c_long, _c_long] + [_c_float] * 5 + [_P, _P, _P]),
 }
 
+MLP_MAX_SEGMENTS = 8  # BUTD_MLP_MAX_SEGMENTS
+
+
+class BnSegment(ctypes.Structure):
+    """ctypes mirror of ``butd_bn_segment`` (include/butd_mlp.h)."""
+    _fields_ = [("gamma", _c_void_p), ("beta", _c_void_p), ("running_mean", _c_void_p),
+                ("running_var", _c_void_p), ("num_batches_tracked", _c_void_p)]
+
+
+MLP_SYMBOLS = {
+    "butd_mlp_bn_finalize": (_c_int, [_c_int, _c_int, _c_long, _P, _P, ctypes.POINTER(BnSegment), _c_float,
+                                      _c_float, _c_int, _P, _P, _P, _P, _P]),
+    "butd_mlp_mask_stats": (_c_int, [_c_long, _c_int, _c_long] + [_P] * 6 + [_c_float, _c_u32, _c_int, _P, _P, _P, _P]),
+    "butd_mlp_dz": (_c_int, [_c_long, _c_int, _c_long] + [_P] * 7 + [_c_int, _P]),
+}
+
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
 ALL_SYMBOLS.update(ATTENTION_SYMBOLS)
 ALL_SYMBOLS.update(SA_SYMBOLS)
 ALL_SYMBOLS.update(OPTIM_SYMBOLS)
+ALL_SYMBOLS.update(MLP_SYMBOLS)
 
 _lib = None
 

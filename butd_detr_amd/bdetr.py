@@ -157,8 +157,8 @@ class BeaUTyDETR(nn.Module):
         end_points.update(text_out)
         return end_points
 
-    def _generate_queries(self, xyz, features, end_points):
-        logits = self.points_obj_cls(features)
+    def _generate_queries(self, xyz, features, end_points, features_pm=None):
+        logits = self.points_obj_cls(features, features_pm=features_pm)
         end_points["seeds_obj_cls_logits"] = logits
         sample_inds = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int()
         xyz, features, sample_inds = self.gsample_module(xyz, features, sample_inds)
@@ -208,7 +208,7 @@ class BeaUTyDETR(nn.Module):
             end_points["proj_tokens"] = F.normalize(
                 self.contrastive_align_projection_text(text_feats), p=2, dim=-1)
 
-        end_points = self._generate_queries(points_xyz, points_features, end_points)
+        end_points = self._generate_queries(points_xyz, points_features, end_points, features_pm=vis)
         cluster_feature = end_points["query_points_feature"]     # (B, d, Q)
         cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
         query = self.decoder_query_proj(cluster_feature).transpose(1, 2).contiguous()
@@ -234,8 +234,8 @@ class BeaUTyDETR(nn.Module):
                           detected_mask=detected_mask if self.butd else None)
             if self.contrastive_align_loss:
                 end_points[f"{prefix}proj_queries"] = self._normalized_proj(query)
-            center, size = head(query.transpose(1, 2).contiguous(), base_xyz=cluster_xyz,
-                                end_points=end_points, prefix=prefix)
+            center, size = head(query.transpose(1, 2), base_xyz=cluster_xyz,
+                                end_points=end_points, prefix=prefix, features_pm=query)
             base_xyz, base_size = center.detach().clone(), size.detach().clone()
         return end_points
 

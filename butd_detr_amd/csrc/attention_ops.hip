@@ -27,7 +27,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBM = 64, kBN = 64, kBK = 32, kLd = kBK + 4;  // LDS row stride 68 floats = 17 x 16 B
 constexpr int kSub = kBK / 16;  // 16-wide sub-slabs per staged slab
 constexpr int kGemmThreads = 256;
-constexpr int kMaxProblems = 4;
+constexpr int kMaxProblems = 8;
+
+// Loads that must be emitted as global_load_*: a FLAT load also counts against lgkmcnt, so the
+// s_waitcnt lgkmcnt(0) in front of the MFMAs (for the LDS fragment reads) would wait for the prefetch
+// of the NEXT slab as well and serialize HBM latency with the matrix pipe.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4_t *global_f4_ptr;
+__device__ inline float4 ldg4(const float *p) {
+  const f32x4_t v = *reinterpret_cast<global_f4_ptr>(reinterpret_cast<uintptr_t>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+constexpr int kAffK = 320;  // contraction range whose A-operand affine is staged in LDS (fast path)
 
 struct GemmBatch {
   butd_gemm_problem p[kMaxProblems];
@@ -99,25 +110,37 @@ __device__ inline float combine(float a, float a2, int mode, float gate_scale) {
   return mode == 0 ? a + a2 : a * (a2 > 0.f ? gate_scale : 0.f);
 }
 
+// Everything commit_tile() applies to a staged operand besides the plain copy.
 // chan_is_k: the affine's channel index is the contraction index (A operand) or the row index (B)
-__device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, bool has2, int mode2,
-                                   float scale2, const float *__restrict__ csc,
-                                   const float *__restrict__ csh, bool chan_is_k, long ld_k, int row0,
-                                   int nrows, int k0, int kend, bool ones, int koff, int tid) {
+struct OperandFx {
+  bool has2; int mode2; float scale2;          // companion operand a2
+  const float *csc, *csh; bool chan_is_k;      // per-channel affine + ReLU
+  float drop_p, drop_inv; uint32_t drop_key;   // dropout keyed by the element's memory offset
+  long ld_row;
+};
+
+__device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, const OperandFx &fx, long ld_k,
+                                   int row0, int nrows, int k0, int kend, bool ones, int koff, int tid) {
   const TileIdx t = tile_idx(ld_k, tid);
   float v[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
-  if (has2) {
-    v[0] = combine(v[0], f.a2.x, mode2, scale2); v[1] = combine(v[1], f.a2.y, mode2, scale2);
-    v[2] = combine(v[2], f.a2.z, mode2, scale2); v[3] = combine(v[3], f.a2.w, mode2, scale2);
+  if (fx.has2) {
+    v[0] = combine(v[0], f.a2.x, fx.mode2, fx.scale2); v[1] = combine(v[1], f.a2.y, fx.mode2, fx.scale2);
+    v[2] = combine(v[2], f.a2.z, fx.mode2, fx.scale2); v[3] = combine(v[3], f.a2.w, fx.mode2, fx.scale2);
   }
-  if (csc) {  // relu(v * scale[chan] + shift[chan]); out-of-range elements stay 0
+  if (fx.csc || fx.drop_p > 0.f) {  // relu(v * scale[chan] + shift[chan]), dropout; out-of-range stays 0
     const int rbase = row0 + (t.kc ? t.slow : t.fast), kbase = k0 + (t.kc ? t.fast : t.slow);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = rbase + (t.kc ? 0 : i), k = kbase + (t.kc ? i : 0);
       if (r < nrows && k < kend) {
-        const int ch = chan_is_k ? k : r;
-        v[i] = fmaxf(v[i] * csc[ch] + csh[ch], 0.f);
+        if (fx.csc) {
+          const int ch = fx.chan_is_k ? k : r;
+          v[i] = fmaxf(v[i] * fx.csc[ch] + fx.csh[ch], 0.f);
+        }
+        if (fx.drop_p > 0.f) {
+          const uint32_t off = (uint32_t)((long)r * fx.ld_row + (long)k * ld_k);
+          v[i] = rng::keep_keyed(fx.drop_key, off, fx.drop_p) ? v[i] * fx.drop_inv : 0.f;
+        }
       }
     }
   }
@@ -142,6 +165,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
                                                             const uint64_t *__restrict__ rng_counter) {
   __shared__ __attribute__((aligned(16))) float As[2][kBM][kLd];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBN][kLd];
+  __shared__ __attribute__((aligned(16))) float Asc[kAffK], Ash[kAffK];
 
   // 1-D grid: every problem owns exactly tiles_n x tiles_m x split_k consecutive workgroups
   int pi = 0;
@@ -173,6 +197,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
     for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool ones = P.ones_col != 0;
+  // operand dropout: the (step, site) halves of the hash are kernel-invariant
+  const bool a_dropout = P.a_drop_p > 0.f, b_dropout = P.b_drop_p > 0.f;
+  const uint64_t step_ctr = ((a_dropout || b_dropout || P.dropout_p > 0.f) && rng_counter) ? *rng_counter : 0ull;
+  const uint32_t a_key = rng::site_key(step_ctr, P.a_drop_site), b_key = rng::site_key(step_ctr, P.b_drop_site);
+  const float a_inv = a_dropout ? 1.f / (1.f - P.a_drop_p) : 1.f, b_inv = b_dropout ? 1.f / (1.f - P.b_drop_p) : 1.f;
   auto mfma_slab = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < kSub; ++u) {
@@ -200,7 +229,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
       P.a2 == nullptr && !ones && ((kend - kbeg) % kBK) == 0 &&
       (a_kc || (P.M & 3) == 0) && (b_kc || (P.N & 3) == 0) &&   // partial tiles: whole float4 in or out
       ((a_kc ? P.lda_m : P.lda_k) & 3) == 0 && ((b_kc ? P.ldb_n : P.ldb_k) & 3) == 0 &&
-      ((((uintptr_t)P.a) | ((uintptr_t)P.b)) & 15) == 0 && (kbeg & 3) == 0;
+      ((((uintptr_t)P.a) | ((uintptr_t)P.b)) & 15) == 0 && (kbeg & 3) == 0 &&
+      (P.a_chan_scale == nullptr || kend - kbeg <= kAffK);
   if (fast) {
     const int a_slow = a_kc ? (tid >> 2) : (tid >> 4), a_fast = a_kc ? (tid & 3) * 4 : (tid & 15) * 4;
     const int b_slow = b_kc ? (tid >> 2) : (tid >> 4), b_fast = b_kc ? (tid & 3) * 4 : (tid & 15) * 4;
@@ -208,12 +238,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
                            : P.a + (long)(kbeg + a_slow) * P.lda_k + m0 + a_fast;
     const float *pb = b_kc ? P.b + (long)(n0 + b_slow) * P.ldb_n + kbeg + b_fast
                            : P.b + (long)(kbeg + b_slow) * P.ldb_k + n0 + b_fast;
-    const long sa16 = a_kc ? 16 : 16 * P.lda_k, sb16 = b_kc ? 16 : 16 * P.ldb_k;  // per 16 k
-    // rows of this thread inside the matrix?  (loop-invariant; rows outside a partial tile read 0)
+    // rows of this thread inside the matrix?  (loop-invariant; rows outside a partial tile read 0:
+    // their loads are redirected to the operand base with stride 0 and discarded at commit time, so
+    // every load stays an unconditional global_load)
     const bool a_ok = m0 + (a_kc ? a_slow : a_fast) < P.M;
     const bool b_ok = n0 + (b_kc ? b_slow : b_fast) < P.N;
+    const long sa16 = !a_ok ? 0 : (a_kc ? 16 : 16 * P.lda_k);   // per 16 k
+    const long sb16 = !b_ok ? 0 : (b_kc ? 16 : 16 * P.ldb_k);
+    if (!a_ok) pa = P.a;
+    if (!b_ok) pb = P.b;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *asc = P.a_chan_scale, *ash = P.a_chan_shift;   // channel = k (varies per slab)
+    const bool a_aff = P.a_chan_scale != nullptr;   // channel = k (varies per slab): staged in LDS
+    if (a_aff) {
+      for (int k = tid; k < kend - kbeg; k += kGemmThreads) {
+        Asc[k] = P.a_chan_scale[kbeg + k];
+        Ash[k] = P.a_chan_shift[kbeg + k];
+      }
+    }
     float4 bsc4 = make_float4(1.f, 1.f, 1.f, 1.f), bsh4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool b_aff = P.b_chan_scale != nullptr;
     if (b_aff && !b_kc) {  // channel = B row = 4 consecutive rows of this thread: loop-invariant
@@ -226,23 +267,23 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
       bsc4 = make_float4(sc, sc, sc, sc);
       bsh4 = make_float4(sh, sh, sh, sh);
     }
-    float4 ra[kSub], rb[kSub], rsc[kSub], rsh[kSub];
+    if (a_aff) __syncthreads();
+    float4 ra[kSub], rb[kSub];
+    int kslab0 = 0;   // k offset (relative to kbeg) of the slab held in ra/rb
+    const long offa0 = pa - P.a, offb0 = pb - P.b;   // element offsets of this thread's first float4
+    auto drop4 = [](float4 v, uint32_t key, uint32_t off, float p, float inv) {
+      v.x = rng::keep_keyed(key, off + 0, p) ? v.x * inv : 0.f;
+      v.y = rng::keep_keyed(key, off + 1, p) ? v.y * inv : 0.f;
+      v.z = rng::keep_keyed(key, off + 2, p) ? v.z * inv : 0.f;
+      v.w = rng::keep_keyed(key, off + 3, p) ? v.w * inv : 0.f;
+      return v;
+    };
     auto fetch_fast = [&](int slab) {
+      kslab0 = slab * kBK;
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        ra[u] = a_ok ? *reinterpret_cast<const float4 *>(pa + (long)(slab * kSub + u) * sa16) : zero4;
-        rb[u] = b_ok ? *reinterpret_cast<const float4 *>(pb + (long)(slab * kSub + u) * sb16) : zero4;
-        if (asc) {
-          const int kk = kbeg + (slab * kSub + u) * 16 + (a_kc ? a_fast : a_slow);
-          if (a_kc) {
-            rsc[u] = *reinterpret_cast<const float4 *>(asc + kk);
-            rsh[u] = *reinterpret_cast<const float4 *>(ash + kk);
-          } else {
-            const float sc = asc[kk], sh = ash[kk];
-            rsc[u] = make_float4(sc, sc, sc, sc);
-            rsh[u] = make_float4(sh, sh, sh, sh);
-          }
-        }
+        ra[u] = ldg4(pa + (long)(slab * kSub + u) * sa16);
+        rb[u] = ldg4(pb + (long)(slab * kSub + u) * sb16);
       }
     };
     auto put = [&](float (*tile)[kLd], bool kc, int slow, int fst, int koff, float4 v) {
@@ -256,15 +297,28 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
     auto commit_fast = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        float4 va = ra[u], vb = rb[u];
-        if (asc && a_ok) {
-          va.x = fmaxf(va.x * rsc[u].x + rsh[u].x, 0.f); va.y = fmaxf(va.y * rsc[u].y + rsh[u].y, 0.f);
-          va.z = fmaxf(va.z * rsc[u].z + rsh[u].z, 0.f); va.w = fmaxf(va.w * rsc[u].w + rsh[u].w, 0.f);
+        float4 va = a_ok ? ra[u] : zero4, vb = b_ok ? rb[u] : zero4;
+        if (a_aff && a_ok) {
+          float4 sc, sh;
+          if (a_kc) {
+            sc = *reinterpret_cast<const float4 *>(&Asc[kslab0 + u * 16 + a_fast]);
+            sh = *reinterpret_cast<const float4 *>(&Ash[kslab0 + u * 16 + a_fast]);
+          } else {
+            const float s1 = Asc[kslab0 + u * 16 + a_slow], h1 = Ash[kslab0 + u * 16 + a_slow];
+            sc = make_float4(s1, s1, s1, s1);
+            sh = make_float4(h1, h1, h1, h1);
+          }
+          va.x = fmaxf(va.x * sc.x + sh.x, 0.f); va.y = fmaxf(va.y * sc.y + sh.y, 0.f);
+          va.z = fmaxf(va.z * sc.z + sh.z, 0.f); va.w = fmaxf(va.w * sc.w + sh.w, 0.f);
         }
         if (b_aff && b_ok) {
           vb.x = fmaxf(vb.x * bsc4.x + bsh4.x, 0.f); vb.y = fmaxf(vb.y * bsc4.y + bsh4.y, 0.f);
           vb.z = fmaxf(vb.z * bsc4.z + bsh4.z, 0.f); vb.w = fmaxf(vb.w * bsc4.w + bsh4.w, 0.f);
         }
+        if (a_dropout && a_ok)
+          va = drop4(va, a_key, (uint32_t)(offa0 + (long)(kslab0 / 16 + u) * sa16), P.a_drop_p, a_inv);
+        if (b_dropout && b_ok)
+          vb = drop4(vb, b_key, (uint32_t)(offb0 + (long)(kslab0 / 16 + u) * sb16), P.b_drop_p, b_inv);
         put(As[buf], a_kc, a_slow, a_fast, u * 16, va);
         put(Bs[buf], b_kc, b_slow, b_fast, u * 16, vb);
       }
@@ -285,6 +339,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
     // slab i is multiplied, then lands in the other buffer
     Frag4 fa[kSub], fb[kSub];
     int kfetched = kbeg;
+    const OperandFx fxa = {P.a2 != nullptr, P.a2_mode, P.a2_scale, P.a_chan_scale, P.a_chan_shift, true,
+                           P.a_drop_p, a_inv, a_key, P.lda_m};
+    const OperandFx fxb = {false, 0, 0.f, P.b_chan_scale, P.b_chan_shift, false,
+                           P.b_drop_p, b_inv, b_key, P.ldb_n};
     auto fetch = [&](int k0) {
       kfetched = k0;
 #pragma unroll
@@ -296,10 +354,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
     auto commit = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        commit_tile(As[buf], fa[u], P.a2 != nullptr, P.a2_mode, P.a2_scale, P.a_chan_scale,
-                    P.a_chan_shift, true, P.lda_k, m0, P.M, kfetched + u * 16, kend, false, u * 16, tid);
-        commit_tile(Bs[buf], fb[u], false, 0, 0.f, P.b_chan_scale, P.b_chan_shift, false, P.ldb_k, n0,
-                    P.N, kfetched + u * 16, kend, ones, u * 16, tid);
+        commit_tile(As[buf], fa[u], fxa, P.lda_k, m0, P.M, kfetched + u * 16, kend, false, u * 16, tid);
+        commit_tile(Bs[buf], fb[u], fxb, P.ldb_k, n0, P.N, kfetched + u * 16, kend, ones, u * 16, tid);
       }
     };
     fetch(kbeg);
@@ -322,7 +378,7 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
   // made the epilogue cost more than the whole K loop).
   const bool drop = P.dropout_p > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - P.dropout_p) : 1.f;
-  const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
+  const uint64_t ctr = step_ctr;
   float *const cptr = P.c;
   float *const bgrad = P.bias_grad;
   const int pM = P.M, pN = P.N, relu = P.relu, accumulate = P.accumulate, ones_col = P.ones_col;
@@ -352,6 +408,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
         if (n + e < pN) bv[e] = P.bias[n + e];
     }
     const bool vec_ok = (n + 3 < pN) && ((ldc & 3) == 0) && ((((uintptr_t)cptr) & 15) == 0);
+    double *const col_sum = P.col_sum, *const col_sumsq = P.col_sumsq;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
       const int row = (tid >> 4) + qq * 16;
@@ -365,6 +423,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
         if (relu) v[e] = fmaxf(v[e], 0.f);
         if (drop)
           v[e] = rng::keep(ctr, site, (uint32_t)((long)m * pN + n + e), p_drop) ? v[e] * inv_keep : 0.f;
+        if (n + e < pN) {
+          cs[e] += v[e];
+          cq[e] += v[e] * v[e];
+        }
       }
       float *dst = cptr + (long)m * ldc + n;
       if (vec_ok) {
@@ -373,6 +435,25 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (n + e < pN) dst[e] = v[e];
+      }
+    }
+    if (col_sum) {
+      // column sums of the tile: 16 row-phase partials per column through LDS (the B buffers are free
+      // after the last barrier of the K loop), then one double atomic per column and statistic
+      float *red = &Bs[0][0][0];
+      static_assert(sizeof(Bs) >= sizeof(float) * 2 * 16 * kBN, "statistics scratch must fit the B buffers");
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[(0 * 16 + (tid >> 4)) * kBN + c4 + e] = cs[e];
+        red[(1 * 16 + (tid >> 4)) * kBN + c4 + e] = cq[e];
+      }
+      __syncthreads();
+      if (tid < 2 * kBN) {
+        const int which = tid >> 6, col = tid & 63;
+        double acc = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc += (double)red[(which * 16 + r) * kBN + col];
+        if (n0 + col < pN) atomicAdd((which ? col_sumsq : col_sum) + n0 + col, acc);
       }
     }
     return;

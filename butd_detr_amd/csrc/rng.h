@@ -17,11 +17,18 @@ __host__ __device__ inline uint32_t mix32(uint32_t x) {  // "lowbias32" finalise
   return x;
 }
 
-__host__ __device__ inline bool keep(uint64_t counter, uint32_t site, uint32_t index, float p) {
-  const uint32_t key = mix32((uint32_t)counter * 0x9E3779B9u + site * 0x85EBCA6Bu +
-                             (uint32_t)(counter >> 32));
+// the (step, site) half of the hash: loop-invariant for a kernel that draws many elements of one site
+__host__ __device__ inline uint32_t site_key(uint64_t counter, uint32_t site) {
+  return mix32((uint32_t)counter * 0x9E3779B9u + site * 0x85EBCA6Bu + (uint32_t)(counter >> 32));
+}
+
+__host__ __device__ inline bool keep_keyed(uint32_t key, uint32_t index, float p) {
   const uint32_t h = mix32(index ^ key);
   return (float)(h >> 8) * (1.0f / 16777216.0f) >= p;
+}
+
+__host__ __device__ inline bool keep(uint64_t counter, uint32_t site, uint32_t index, float p) {
+  return keep_keyed(site_key(counter, site), index, p);
 }
 
 }  // namespace rng

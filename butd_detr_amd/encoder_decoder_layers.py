@@ -35,6 +35,13 @@ class PositionEmbeddingLearned(nn.Module):
             nn.Conv1d(num_pos_feats, num_pos_feats, kernel_size=1))
 
     def forward(self, xyz):
+        if ab.get_backend() == "hip" and xyz.is_cuda:
+            from .fused_mlp import mlp_chains
+            head = self.position_embedding_head
+            b, n, k = xyz.shape
+            out = mlp_chains(xyz.reshape(b * n, k), [([(head[0], head[1])], head[3], 0.0)],
+                             self.training)[0]
+            return out.view(b, n, -1).transpose(1, 2)     # (B,F,N) view of the position-major result
         return self.position_embedding_head(xyz.transpose(1, 2).contiguous())
 
 

@@ -1,0 +1,215 @@
+"""Conv1d(k=1) + BatchNorm1d + ReLU (+ Dropout) chains on the gfx950 kernels of include/butd_mlp.h.
+
+``mlp_chains`` runs G parallel chains that share one input -- the three ``ThreeLayerMLP`` of a
+``ClsAgnosticPredictHead`` (models/modules.py:89-180), or G = 1 for ``PointsObjClsModule`` (:19-49) and
+``PositionEmbeddingLearned`` (:52-67) -- forward AND backward, in training (batch statistics,
+running-stat update, dropout) or eval mode.  Activations are position-major ``(P = B*L, C)`` matrices;
+the hidden activations of the G chains sit side by side in one ``(P, G*H)`` matrix.  Every layer is ONE
+grouped MFMA GEMM launch whose epilogue accumulates the BatchNorm column sums and whose operand staging
+applies the previous layer's BatchNorm + ReLU + Dropout, plus one tiny bookkeeping launch: a 3-chain
+predict head is 5 launches forward and 10 backward, where the stock chain is ~33 + ~60 (Conv1d via
+MIOpen with NCHW transposes, BatchNorm, ReLU, Dropout kernels and their backward).
+"""
+import torch
+
+from . import _hiplib
+from ._hiplib import BnSegment
+from .fused_attention import _gemm, _problem, _stream, rng_counter, _site
+
+_lib = _hiplib.load()
+
+
+def _call(name, ref, *args):
+    with torch.cuda.device(ref.device):
+        err = getattr(_lib, name)(*args, _stream(ref))
+    _hiplib.check(err, name)
+
+
+def _split(M):
+    return max(1, min(32, M // 256))
+
+
+class ChainSpec:
+    """Static description of G chains: hidden widths, output widths, buffers, flags (not tensors that
+    need gradients: those go through ``_MlpChains.apply`` positionally)."""
+
+    def __init__(self, G, nh, H, outs, bn_buffers, eps, momentum, p_drop, training, site0):
+        self.G, self.nh, self.H, self.outs = G, nh, H, outs
+        self.bn_buffers = bn_buffers        # [chain][layer] -> (running_mean, running_var, nbt)
+        self.eps, self.momentum, self.p_drop = eps, momentum, p_drop
+        self.training, self.site0 = training, site0
+
+
+class _MlpChains(torch.autograd.Function):
+    """params: per chain, per hidden layer (w, bias|None, gamma, beta), then (w_out, b_out|None)."""
+
+    @staticmethod
+    def forward(ctx, x, spec, *params):
+        G, nh, H = spec.G, spec.nh, spec.H
+        P, Cin = x.shape
+        GH = G * H
+        dev = x.device
+        per = 4 * nh + 2
+        hidden = [[params[i * per + 4 * l:i * per + 4 * l + 4] for l in range(nh)] for i in range(G)]
+        outp = [params[i * per + 4 * nh:i * per + 4 * nh + 2] for i in range(G)]
+        p = spec.p_drop if spec.training else 0.0
+        Z = [torch.empty((P, GH), device=dev) for _ in range(nh)]
+        stats = torch.zeros((nh, 2, GH), dtype=torch.float64, device=dev)
+        aff = torch.empty((nh, 4, GH), device=dev)       # per layer: mean, rstd, scale, shift
+        sl = lambda i: slice(i * H, (i + 1) * H)
+
+        def operand(l, i):
+            """Input of layer l (l == nh: the output layer) of chain i: tensor, row stride, prologue."""
+            if l == 0:
+                return x, Cin, None, (0.0, 0)
+            return (Z[l - 1][:, sl(i)], GH, (aff[l - 1, 2, sl(i)], aff[l - 1, 3, sl(i)]),
+                    (p, spec.site0 + (l - 1) * G + i))
+
+        for l in range(nh):
+            probs = []
+            for i in range(G):
+                w, b = hidden[i][l][0], hidden[i][l][1]
+                a, lda, a_aff, a_drop = operand(l, i)
+                K = Cin if l == 0 else H
+                probs.append(_problem(a, w, Z[l][:, sl(i)], P, H, K, (lda, 1), (K, 1), GH, bias=b,
+                                      a_affine=a_aff, a_drop=a_drop,
+                                      col_stats=(stats[l, 0, sl(i)], stats[l, 1, sl(i)])))
+            _gemm(probs, x)
+            segs = (BnSegment * _hiplib.MLP_MAX_SEGMENTS)()
+            for i in range(G):
+                rm, rv, nbt = spec.bn_buffers[i][l]
+                segs[i] = BnSegment(hidden[i][l][2].data_ptr(), hidden[i][l][3].data_ptr(), rm.data_ptr(),
+                                    rv.data_ptr(), None if nbt is None else nbt.data_ptr())
+            _call("butd_mlp_bn_finalize", x, G, H, P, stats[l, 0].data_ptr(), stats[l, 1].data_ptr(), segs,
+                  float(spec.eps), float(spec.momentum), int(spec.training), aff[l, 0].data_ptr(),
+                  aff[l, 1].data_ptr(), aff[l, 2].data_ptr(), aff[l, 3].data_ptr())
+        outs, probs = [], []
+        for i in range(G):
+            w, b = outp[i]
+            a, lda, a_aff, a_drop = operand(nh, i)
+            o = torch.empty((P, spec.outs[i]), device=dev)
+            probs.append(_problem(a, w, o, P, spec.outs[i], H, (lda, 1), (H, 1), spec.outs[i], bias=b,
+                                  a_affine=a_aff, a_drop=a_drop))
+            outs.append(o)
+        _gemm(probs, x)
+        ctx.save_for_backward(x, aff, *Z, *params)
+        ctx.spec, ctx.p = spec, p
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        spec, p = ctx.spec, ctx.p
+        G, nh, H = spec.G, spec.nh, spec.H
+        saved = ctx.saved_tensors
+        x, aff = saved[0], saved[1]
+        Z = saved[2:2 + nh]
+        params = saved[2 + nh:]
+        P, Cin = x.shape
+        GH = G * H
+        dev = x.device
+        per = 4 * nh + 2
+        hidden = [[params[i * per + 4 * l:i * per + 4 * l + 4] for l in range(nh)] for i in range(G)]
+        outp = [params[i * per + 4 * nh:i * per + 4 * nh + 2] for i in range(G)]
+        sl = lambda i: slice(i * H, (i + 1) * H)
+        d_outs = [torch.zeros((P, spec.outs[i]), device=dev) if d is None else d.contiguous()
+                  for i, d in enumerate(d_outs)]
+        # one zero-filled slab for every weight / bias gradient (accumulated with atomics)
+        sizes = []
+        for i in range(G):
+            for l in range(nh):
+                w, b = hidden[i][l][0], hidden[i][l][1]
+                sizes += [w.numel(), 0 if b is None else b.numel()]
+            sizes += [outp[i][0].numel(), 0 if outp[i][1] is None else outp[i][1].numel()]
+        slab = torch.zeros(sum(sizes), device=dev)
+        views, o = [], 0
+        for n in sizes:
+            views.append(slab[o:o + n] if n else None)
+            o += n
+        dW = [[(views[i * (2 * nh + 2) + 2 * l], views[i * (2 * nh + 2) + 2 * l + 1]) for l in range(nh)]
+              for i in range(G)]
+        dWo = [(views[i * (2 * nh + 2) + 2 * nh], views[i * (2 * nh + 2) + 2 * nh + 1]) for i in range(G)]
+        S = torch.zeros((nh, 2, GH), dtype=torch.float64, device=dev)
+
+        def operand(l, i):
+            if l == 0:
+                return x, Cin, None, (0.0, 0)
+            return (Z[l - 1][:, sl(i)], GH, (aff[l - 1, 2, sl(i)], aff[l - 1, 3, sl(i)]),
+                    (p, spec.site0 + (l - 1) * G + i))
+
+        def wgrad(dy, ldy, N, l, i, dw, db):
+            """dw[N,K] += dy[P,N]^T @ input_of_layer_l[P,K]  (+ db = column sums of dy)."""
+            a, lda, b_aff, b_drop = operand(l, i)
+            K = Cin if l == 0 else H
+            return _problem(dy, a, dw, N, K, P, (1, ldy), (1, lda), K, bias_grad=db,
+                            ones_col=db is not None, accumulate=True, split_k=_split(P),
+                            b_affine=b_aff, b_drop=b_drop)
+
+        dH = torch.empty((P, GH), device=dev)
+        probs = []
+        for i in range(G):
+            n_out = spec.outs[i]
+            probs.append(wgrad(d_outs[i], n_out, n_out, nh, i, dWo[i][0], dWo[i][1]))
+            probs.append(_problem(d_outs[i], outp[i][0], dH[:, sl(i)], P, H, n_out, (n_out, 1), (1, H), GH))
+        _gemm(probs, x)
+        need_dx = ctx.needs_input_grad[0]
+        dx = None
+        for l in reversed(range(nh)):
+            _call("butd_mlp_mask_stats", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
+                  aff[l, 3].data_ptr(), aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), float(p),
+                  spec.site0 + l * G, H, rng_counter(dev).data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr())
+            _call("butd_mlp_dz", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
+                  aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr(),
+                  int(spec.training))
+            dZ = dH
+            if l > 0:
+                dH = torch.empty((P, GH), device=dev)
+            elif need_dx:
+                dx = torch.zeros((P, Cin), device=dev) if G > 1 else torch.empty((P, Cin), device=dev)
+            probs = []
+            for i in range(G):
+                w = hidden[i][l][0]
+                probs.append(wgrad(dZ[:, sl(i)], GH, H, l, i, dW[i][l][0], dW[i][l][1]))
+                if l > 0:
+                    probs.append(_problem(dZ[:, sl(i)], w, dH[:, sl(i)], P, H, H, (GH, 1), (1, H), GH))
+                elif need_dx:
+                    probs.append(_problem(dZ[:, sl(i)], w, dx, P, Cin, H, (GH, 1), (1, Cin), Cin,
+                                          accumulate=G > 1))
+            _gemm(probs, x)
+        Sf = S.float()
+        grads = []
+        for i in range(G):
+            for l in range(nh):
+                w, b = hidden[i][l][0], hidden[i][l][1]
+                grads += [dW[i][l][0].view(w.shape), None if b is None else dW[i][l][1],
+                          Sf[l, 1, sl(i)], Sf[l, 0, sl(i)]]
+            grads += [dWo[i][0].view(outp[i][0].shape), dWo[i][1]]
+        return (dx, None, *grads)
+
+
+def mlp_chains(x_pm, chains, training):
+    """x_pm (P, Cin) fp32 contiguous; ``chains``: list of (hidden, out, p_drop) with
+    hidden = [(conv, bn), ...] (Conv1d k=1 / BatchNorm1d modules), out = Conv1d.  All chains share the
+    hidden width and depth.  -> list of (P, out_channels) tensors."""
+    G = len(chains)
+    nh = len(chains[0][0])
+    H = chains[0][0][0][0].out_channels
+    p_drop = chains[0][2]
+    bn0 = chains[0][0][0][1]
+    params, buffers, outs = [], [], []
+    for hidden, out, p in chains:
+        assert len(hidden) == nh and p == p_drop
+        bufs = []
+        for conv, bn in hidden:
+            assert conv.out_channels == H and conv.kernel_size == (1,) and bn.eps == bn0.eps
+            assert bn.momentum == bn0.momentum and bn.affine and bn.track_running_stats
+            params += [conv.weight, conv.bias, bn.weight, bn.bias]
+            bufs.append((bn.running_mean, bn.running_var, bn.num_batches_tracked))
+        buffers.append(bufs)
+        params += [out.weight, out.bias]
+        outs.append(out.out_channels)
+    assert G <= _hiplib.MLP_MAX_SEGMENTS and 2 * G <= 8 and H % 4 == 0
+    site0 = _site[0] + 1
+    _site[0] += G * nh
+    momentum = 0.1 if bn0.momentum is None else bn0.momentum
+    spec = ChainSpec(G, nh, H, outs, buffers, bn0.eps, momentum, p_drop, bool(training), site0)
+    return list(_MlpChains.apply(x_pm.contiguous(), spec, *params))

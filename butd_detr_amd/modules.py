@@ -2,15 +2,27 @@
 
 ``PointsObjClsModule`` (:19-49), ``GeneralSamplingModule`` (:70-86), ``ThreeLayerMLP`` (:89-108) and
 ``ClsAgnosticPredictHead`` (:111-180); ``PositionEmbeddingLearned`` is shared with the
-encoder/decoder file.  Small Conv1d+BN1d stacks: stock torch ops (SURVEY.md section 8(f)-2 ranks their
-fusion as "next").
+encoder/decoder file.  The Conv1d+BN1d+ReLU(+Dropout) stacks run as stock torch ops on the "torch"
+backend and through the grouped-GEMM pipeline of include/butd_mlp.h (``fused_mlp.mlp_chains``) on the
+"hip" backend: same parameters, same outputs, no NCHW round trips.
 """
 import numpy as np
 import torch.nn.functional as F
 from torch import nn
 
+from . import attention_blocks
 from .encoder_decoder_layers import PositionEmbeddingLearned  # noqa: F401  (re-export, modules.py:52)
 from .pointnet2_utils import gather_operation
+
+
+def _fused(x):
+    return attention_blocks.get_backend() == "hip" and x.is_cuda
+
+
+def _position_major(features):
+    """(B, C, L) -> (B*L, C) contiguous."""
+    b, c, l = features.shape
+    return features.transpose(1, 2).reshape(b * l, c)
 
 
 class PointsObjClsModule(nn.Module):
@@ -25,7 +37,15 @@ class PointsObjClsModule(nn.Module):
         self.bn2 = nn.BatchNorm1d(self.in_dim)
         self.conv3 = nn.Conv1d(self.in_dim, 1, 1)
 
-    def forward(self, seed_features):
+    def forward(self, seed_features, features_pm=None):
+        """``features_pm``: optional (B, K, C) copy of the same features (skips one transpose)."""
+        if _fused(seed_features):
+            from .fused_mlp import mlp_chains
+            b, _, k = seed_features.shape
+            x = features_pm.reshape(b * k, -1) if features_pm is not None else _position_major(seed_features)
+            out = mlp_chains(x, [([(self.conv1, self.bn1), (self.conv2, self.bn2)], self.conv3, 0.0)],
+                             self.training)[0]
+            return out.view(b, k, 1).transpose(1, 2)
         net = F.relu(self.bn1(self.conv1(seed_features)))
         net = F.relu(self.bn2(self.conv2(net)))
         return self.conv3(net)
@@ -51,7 +71,16 @@ class ThreeLayerMLP(nn.Module):
             nn.Conv1d(dim, dim, 1, bias=False), nn.BatchNorm1d(dim), nn.ReLU(), nn.Dropout(0.3),
             nn.Conv1d(dim, out_dim, 1))
 
+    def chain(self):
+        net = self.net
+        return [(net[0], net[1]), (net[4], net[5])], net[8], net[3].p
+
     def forward(self, x):
+        if _fused(x):
+            from .fused_mlp import mlp_chains
+            b, _, l = x.shape
+            out = mlp_chains(_position_major(x), [self.chain()], self.training)[0]
+            return out.view(b, l, -1).transpose(1, 2)
         return self.net(x)
 
 
@@ -78,9 +107,12 @@ class ClsAgnosticPredictHead(nn.Module):
         if compute_sem_scores:
             self.sem_cls_scores_head = ThreeLayerMLP(seed_feat_dim, self.num_class)
 
-    def forward(self, features, base_xyz, end_points, prefix=""):
-        """features (B, C, Q), base_xyz (B, Q, 3) -> (center (B,Q,3), pred_size (B,Q,3))."""
+    def forward(self, features, base_xyz, end_points, prefix="", features_pm=None):
+        """features (B, C, Q), base_xyz (B, Q, 3) -> (center (B,Q,3), pred_size (B,Q,3)).
+        ``features_pm``: optional (B, Q, C) copy of the same features (the decoder's own layout)."""
         batch_size, num_proposal = features.shape[0], features.shape[-1]
+        if _fused(features) and not self.heading:
+            return self._forward_fused(features, base_xyz, end_points, prefix, features_pm)
         if self.objectness:
             scores = self.objectness_scores_head(features).transpose(2, 1)
             end_points[f"{prefix}objectness_scores"] = scores.squeeze(-1)
@@ -99,4 +131,24 @@ class ClsAgnosticPredictHead(nn.Module):
         if self.compute_sem_scores:
             end_points[f"{prefix}sem_cls_scores"] = self.sem_cls_scores_head(
                 features).transpose(2, 1)
+        return center, pred_size
+
+    def _forward_fused(self, features, base_xyz, end_points, prefix, features_pm):
+        """All ThreeLayerMLPs of the head as ONE group of chains on the position-major features."""
+        from .fused_mlp import mlp_chains
+        b, _, q = features.shape
+        x = features_pm.reshape(b * q, -1) if features_pm is not None else _position_major(features)
+        heads = ([self.objectness_scores_head] if self.objectness else []) + \
+            [self.center_residual_head, self.size_pred_head] + \
+            ([self.sem_cls_scores_head] if self.compute_sem_scores else [])
+        outs = [o.view(b, q, -1) for o in mlp_chains(x, [h.chain() for h in heads], self.training)]
+        if self.objectness:
+            end_points[f"{prefix}objectness_scores"] = outs.pop(0).squeeze(-1)
+        center = base_xyz + outs[0]
+        pred_size = outs[1]
+        end_points[f"{prefix}base_xyz"] = base_xyz
+        end_points[f"{prefix}center"] = center
+        end_points[f"{prefix}pred_size"] = pred_size
+        if self.compute_sem_scores:
+            end_points[f"{prefix}sem_cls_scores"] = outs[2]
         return center, pred_size

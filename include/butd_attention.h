@@ -44,9 +44,23 @@ typedef struct {
    *   A(m,k) <- relu(A(m,k) * a_chan_scale[k] + a_chan_shift[k])   (channel = contraction index)
    *   B(n,k) <- relu(B(n,k) * b_chan_scale[n] + b_chan_shift[n])   (channel = output column)   */
   const float *a_chan_scale, *a_chan_shift, *b_chan_scale, *b_chan_shift;
+  /* Optional operand dropout, applied after the affine+ReLU (folds ``Dropout(ReLU(BatchNorm(z)))`` of
+   * the producing layer, models/modules.py:92-108, into the consumer):
+   *   X <- keep(step counter, site, i) ? X / (1-p) : 0,   i = offset (in floats) of the element from the
+   * operand's base pointer `a` / `b` -- so a forward product, the weight-gradient product that re-reads
+   * the same activation through different strides, and butd_mlp_mask_stats (include/butd_mlp.h) all
+   * regenerate the same mask when they are handed the same base pointer and site. */
+  float a_drop_p;
+  uint32_t a_drop_site;
+  float b_drop_p;
+  uint32_t b_drop_site;
+  /* Optional column statistics of the stored result (plain-store problems only: accumulate == 0,
+   * split_k == 1): col_sum[n] += sum_m C[m,n], col_sumsq[n] += sum_m C[m,n]^2 in double (atomics, the
+   * caller zero-fills) -- the BatchNorm batch statistics of a 1x1 convolution, in the same pass. */
+  double *col_sum, *col_sumsq;
 } butd_gemm_problem;
 
-/* Launches up to 4 independent problems in ONE grid (blockIdx.z selects the problem).
+/* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).
  * rng_counter: device pointer to a uint64 step counter (may be NULL when no problem uses dropout). */
 int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64_t *rng_counter,
                       butd_stream_t stream);

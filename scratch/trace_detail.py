@@ -2,7 +2,7 @@ import csv, sys, collections
 path, marker, pat = sys.argv[1], sys.argv[2], sys.argv[3]
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]][:-1]
+marks = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]][:-7]
 win = rows[marks[-2]:marks[-1]]
 agg = collections.defaultdict(lambda: [0, 0])
 for r in win:
