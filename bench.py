@@ -218,7 +218,7 @@ def main():
         ddp = model
 
         def train_step(_m, _o, i, t):
-            return graphed(i, t)
+            return graphed(i, t, next_inputs=i)
 
     for _ in range(args.warmup):
         train_step(ddp, opt, inputs, targets)

@@ -10,7 +10,7 @@ import torch  # noqa: F401  -- MUST precede the dlopen below: torch ships its ow
               # ours first would bring up a second HIP runtime that does not see torch's context.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbutd_detr_hip.so")
+LIB_PATH = os.environ.get("BUTD_HIP_LIB") or os.path.join(_HERE, "lib", "libbutd_detr_hip.so")  # env: debug hook
 
 _c_int, _c_float, _c_void_p, _c_size_t = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 

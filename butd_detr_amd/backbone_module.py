@@ -4,8 +4,10 @@ Four set-abstraction levels (2048/0.2/64, 1024/0.4/32, 512/0.8/16, 256/1.2/16; a
 ``use_xyz`` and radius-normalised local xyz) and two feature-propagation levels back up to the
 1024 seed points; emits the ``sa{1..4}_*`` and ``fp2_*`` entries of ``end_points``.
 """
+import torch
 from torch import nn
 
+from . import pointnet2_utils
 from .pointnet2_modules import PointnetFPModule, PointnetSAModuleVotes
 
 # (npoint, radius, nsample, hidden width, output width) per level -- backbone_module.py:53-87
@@ -33,15 +35,34 @@ class Pointnet2Backbone(nn.Module):
         features = pc[..., 3:].transpose(1, 2).contiguous() if pc.size(-1) > 3 else None
         return xyz, features
 
-    def forward(self, pointcloud, end_points=None):
-        """pointcloud (B, N, 3 + input_feature_dim) -> end_points dict."""
+    @torch.no_grad()
+    def sample(self, pointcloud):
+        """The furthest-point-sampling chain of the four levels on its own: [inds1 (B,2048), inds2
+        (B,1024), inds3 (B,512), inds4 (B,256)] int32.  It depends on the coordinates only -- not on any
+        parameter -- so a training loop can run it for batch k+1 (a long serial kernel on 8 CUs) while
+        batch k trains, and hand the result to ``forward(..., sample_inds=...)``."""
+        xyz = pointcloud[..., 0:3].contiguous()
+        out = []
+        for level in (1, 2, 3, 4):
+            sa = getattr(self, f"sa{level}")
+            inds = pointnet2_utils.furthest_point_sample(xyz, sa.npoint)
+            out.append(inds)
+            xyz = pointnet2_utils.gather_operation(
+                xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+        return out
+
+    def forward(self, pointcloud, end_points=None, sample_inds=None):
+        """pointcloud (B, N, 3 + input_feature_dim) -> end_points dict.  ``sample_inds``: optional
+        precomputed result of ``sample(pointcloud)`` (the modules' own ``inds`` argument,
+        pointnet2_modules.py:210-241)."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
         # point-major hand-over between levels (used by the fused gfx950 SA pipeline, ignored otherwise)
         feats_pm, off = (pointcloud.contiguous(), 3) if features is not None else (None, 0)
         for level in (1, 2, 3, 4):
             sa = getattr(self, f"sa{level}")
-            xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off)
+            xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off,
+                                     inds=None if sample_inds is None else sample_inds[level - 1])
             feats_pm, off = sa.last_features_pm, 0
             if level <= 2:  # the reference only records inds of the first two levels (:127,:132)
                 end_points[f"sa{level}_inds"] = inds

@@ -144,12 +144,12 @@ class BeaUTyDETR(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._run_text_tower(tokenized, text_out)
-            end_points = self.backbone_net(pc, end_points={})
+            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
             main.wait_stream(side)
             for v in (text_out["text_feats"], text_out["text_attention_mask"]):
                 v.record_stream(main)
         else:
-            end_points = self.backbone_net(pc, end_points={})
+            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
             self._run_text_tower(tokenized, text_out)
         end_points["seed_inds"] = end_points["fp2_inds"]
         end_points["seed_xyz"] = end_points["fp2_xyz"]

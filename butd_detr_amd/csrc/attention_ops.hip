@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/butd_attention.h"
 #include "rng.h"
@@ -25,8 +26,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kBM = 64, kBN = 64, kBK = 32, kLd = kBK + 4;  // LDS row stride 68 floats = 17 x 16 B
-constexpr int kSub = kBK / 16;  // 16-wide sub-slabs per staged slab
-constexpr int kGemmThreads = 256;
+// The kernel is instantiated for 256 threads (4 waves, wave tile 32x32) and 512 threads (8 waves, wave
+// tile 32x16: half the MFMA chain per wave and twice the waves per SIMD for small grids).  One staging
+// step moves ONE float4 per thread and operand: a (64 rows x SW k) sub-slab, SW = THREADS/16.
 constexpr int kMaxProblems = 8;
 
 // Loads that must be emitted as global_load_*: a FLAT load also counts against lgkmcnt, so the
@@ -62,19 +64,20 @@ struct TileIdx {
   int slow, fast;   // position along the strided / contiguous dimension inside the slab
   bool kc;          // contraction-contiguous?
 };
+template <int SW>
 __device__ inline TileIdx tile_idx(long ld_k, int tid) {
   TileIdx t;
   t.kc = ld_k == 1;
-  t.slow = t.kc ? (tid >> 2) : (tid >> 4);
-  t.fast = t.kc ? (tid & 3) * 4 : (tid & 15) * 4;
+  t.slow = t.kc ? (tid / (SW / 4)) : (tid >> 4);
+  t.fast = t.kc ? (tid % (SW / 4)) * 4 : (tid & 15) * 4;
   return t;
 }
 
-template <bool WITH_A2 = true>
+template <int SW, bool WITH_A2 = true>
 __device__ inline Frag4 fetch_tile(const float *__restrict__ src, const float *__restrict__ src2,
                                    long ld_row, long ld_k, int row0, int nrows, int k0, int kend,
                                    int tid) {
-  const TileIdx t = tile_idx(ld_k, tid);
+  const TileIdx t = tile_idx<SW>(ld_k, tid);
   const long ld_slow = t.kc ? ld_row : ld_k;
   const int slow_g = (t.kc ? row0 : k0) + t.slow, fast_g = (t.kc ? k0 : row0) + t.fast;
   const int slow_lim = t.kc ? nrows : kend, fast_lim = t.kc ? kend : nrows;
@@ -119,9 +122,10 @@ struct OperandFx {
   long ld_row;
 };
 
+template <int SW>
 __device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, const OperandFx &fx, long ld_k,
                                    int row0, int nrows, int k0, int kend, bool ones, int koff, int tid) {
-  const TileIdx t = tile_idx(ld_k, tid);
+  const TileIdx t = tile_idx<SW>(ld_k, tid);
   float v[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
   if (fx.has2) {
     v[0] = combine(v[0], f.a2.x, fx.mode2, fx.scale2); v[1] = combine(v[1], f.a2.y, fx.mode2, fx.scale2);
@@ -161,8 +165,18 @@ __device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, const Ope
   }
 }
 
-__global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
-                                                            const uint64_t *__restrict__ rng_counter) {
+// FAST: every problem of the launch satisfies fast_eligible() (host side): interior tiles stream whole
+// float4s with addresses  base + slab * step  and no bounds checks; the generic instantiation handles
+// ragged K, unaligned operands and the a2 companion.  Two kernels instead of one runtime branch: with
+// both paths in one body the compiler merged their MFMA blocks and serialized loads behind them.
+template <int THREADS, bool FAST>
+__global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
+                                                       const uint64_t *__restrict__ rng_counter) {
+  constexpr int kSW = THREADS / 16;        // k-width of one staging step
+  constexpr int kSub = kBK / kSW;          // staging steps per slab
+  constexpr int kWavesN = THREADS / 128;   // wave grid 2 x kWavesN
+  constexpr int kNJ = 4 / kWavesN;         // 16-column fragments per wave
+  constexpr int kRowPhases = THREADS / 16; // rows written per epilogue pass
   __shared__ __attribute__((aligned(16))) float As[2][kBM][kLd];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBN][kLd];
   __shared__ __attribute__((aligned(16))) float Asc[kAffK], Ash[kAffK];
@@ -187,14 +201,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
   if (kbeg >= kend && slice > 0) return;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / kWavesN, wc = wave % kWavesN;
   const int fr = lane & 15, fg = lane >> 4;
 
-  f32x4 acc[2][2];
+  f32x4 acc[2][kNJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < kNJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const bool ones = P.ones_col != 0;
   // operand dropout: the (step, site) halves of the hash are kernel-invariant
@@ -204,20 +218,20 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
   const float a_inv = a_dropout ? 1.f / (1.f - P.a_drop_p) : 1.f, b_inv = b_dropout ? 1.f / (1.f - P.b_drop_p) : 1.f;
   auto mfma_slab = [&](int buf) {
 #pragma unroll
-    for (int u = 0; u < kSub; ++u) {
-      f32x4 af[2], bf[2];
+    for (int u = 0; u < kBK / 16; ++u) {
+      f32x4 af[2], bf[kNJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
         af[i] = *reinterpret_cast<const f32x4 *>(&As[buf][wr * 32 + i * 16 + fr][u * 16 + fg * 4]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-        bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wc * 32 + j * 16 + fr][u * 16 + fg * 4]);
+      for (int j = 0; j < kNJ; ++j)
+        bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wc * (16 * kNJ) + j * 16 + fr][u * 16 + fg * 4]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < kNJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
     }
   };
@@ -225,15 +239,11 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
   // per-thread bases computed once; a slab costs each thread 2*kSub float4 loads, 2*kSub LDS writes and
   // the MFMAs -- no bounds checks, no index arithmetic.  Edge tiles take the generic path below.
   const bool a_kc = P.lda_k == 1, b_kc = P.ldb_k == 1;
-  const bool fast =
-      P.a2 == nullptr && !ones && ((kend - kbeg) % kBK) == 0 &&
-      (a_kc || (P.M & 3) == 0) && (b_kc || (P.N & 3) == 0) &&   // partial tiles: whole float4 in or out
-      ((a_kc ? P.lda_m : P.lda_k) & 3) == 0 && ((b_kc ? P.ldb_n : P.ldb_k) & 3) == 0 &&
-      ((((uintptr_t)P.a) | ((uintptr_t)P.b)) & 15) == 0 && (kbeg & 3) == 0 &&
-      (P.a_chan_scale == nullptr || kend - kbeg <= kAffK);
-  if (fast) {
-    const int a_slow = a_kc ? (tid >> 2) : (tid >> 4), a_fast = a_kc ? (tid & 3) * 4 : (tid & 15) * 4;
-    const int b_slow = b_kc ? (tid >> 2) : (tid >> 4), b_fast = b_kc ? (tid & 3) * 4 : (tid & 15) * 4;
+  if constexpr (FAST) {
+    const int a_slow = a_kc ? (tid / (kSW / 4)) : (tid >> 4);
+    const int a_fast = a_kc ? (tid % (kSW / 4)) * 4 : (tid & 15) * 4;
+    const int b_slow = b_kc ? (tid / (kSW / 4)) : (tid >> 4);
+    const int b_fast = b_kc ? (tid % (kSW / 4)) * 4 : (tid & 15) * 4;
     const float *pa = a_kc ? P.a + (long)(m0 + a_slow) * P.lda_m + kbeg + a_fast
                            : P.a + (long)(kbeg + a_slow) * P.lda_k + m0 + a_fast;
     const float *pb = b_kc ? P.b + (long)(n0 + b_slow) * P.ldb_n + kbeg + b_fast
@@ -243,14 +253,14 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
     // every load stays an unconditional global_load)
     const bool a_ok = m0 + (a_kc ? a_slow : a_fast) < P.M;
     const bool b_ok = n0 + (b_kc ? b_slow : b_fast) < P.N;
-    const long sa16 = !a_ok ? 0 : (a_kc ? 16 : 16 * P.lda_k);   // per 16 k
-    const long sb16 = !b_ok ? 0 : (b_kc ? 16 : 16 * P.ldb_k);
+    const long sa16 = !a_ok ? 0 : (a_kc ? kSW : kSW * P.lda_k);   // per staging step (kSW k)
+    const long sb16 = !b_ok ? 0 : (b_kc ? kSW : kSW * P.ldb_k);
     if (!a_ok) pa = P.a;
     if (!b_ok) pb = P.b;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool a_aff = P.a_chan_scale != nullptr;   // channel = k (varies per slab): staged in LDS
     if (a_aff) {
-      for (int k = tid; k < kend - kbeg; k += kGemmThreads) {
+      for (int k = tid; k < kend - kbeg; k += THREADS) {
         Asc[k] = P.a_chan_scale[kbeg + k];
         Ash[k] = P.a_chan_shift[kbeg + k];
       }
@@ -268,8 +278,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
       bsh4 = make_float4(sh, sh, sh, sh);
     }
     if (a_aff) __syncthreads();
+    // virtual ones-row of B (row index N): which of this thread's elements is it, if any
+    const int ones_e = !ones ? -1 : (b_kc ? (n0 + b_slow == P.N ? 4 : -1)
+                                          : ((n0 + b_fast <= P.N && P.N < n0 + b_fast + 4) ? P.N - (n0 + b_fast) : -1));
     float4 ra[kSub], rb[kSub];
-    int kslab0 = 0;   // k offset (relative to kbeg) of the slab held in ra/rb
     const long offa0 = pa - P.a, offb0 = pb - P.b;   // element offsets of this thread's first float4
     auto drop4 = [](float4 v, uint32_t key, uint32_t off, float p, float inv) {
       v.x = rng::keep_keyed(key, off + 0, p) ? v.x * inv : 0.f;
@@ -279,7 +291,6 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
       return v;
     };
     auto fetch_fast = [&](int slab) {
-      kslab0 = slab * kBK;
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
         ra[u] = ldg4(pa + (long)(slab * kSub + u) * sa16);
@@ -294,17 +305,18 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
         tile[fst + 2][koff + slow] = v.z; tile[fst + 3][koff + slow] = v.w;
       }
     };
-    auto commit_fast = [&](int buf) {
+    auto commit_fast = [&](int slab, int buf) {
+      const int kslab0 = slab * kBK;   // k offset (relative to kbeg) of the slab held in ra/rb
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
         float4 va = a_ok ? ra[u] : zero4, vb = b_ok ? rb[u] : zero4;
         if (a_aff && a_ok) {
           float4 sc, sh;
           if (a_kc) {
-            sc = *reinterpret_cast<const float4 *>(&Asc[kslab0 + u * 16 + a_fast]);
-            sh = *reinterpret_cast<const float4 *>(&Ash[kslab0 + u * 16 + a_fast]);
+            sc = *reinterpret_cast<const float4 *>(&Asc[kslab0 + u * kSW + a_fast]);
+            sh = *reinterpret_cast<const float4 *>(&Ash[kslab0 + u * kSW + a_fast]);
           } else {
-            const float s1 = Asc[kslab0 + u * 16 + a_slow], h1 = Ash[kslab0 + u * 16 + a_slow];
+            const float s1 = Asc[kslab0 + u * kSW + a_slow], h1 = Ash[kslab0 + u * kSW + a_slow];
             sc = make_float4(s1, s1, s1, s1);
             sh = make_float4(h1, h1, h1, h1);
           }
@@ -316,22 +328,29 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
           vb.z = fmaxf(vb.z * bsc4.z + bsh4.z, 0.f); vb.w = fmaxf(vb.w * bsc4.w + bsh4.w, 0.f);
         }
         if (a_dropout && a_ok)
-          va = drop4(va, a_key, (uint32_t)(offa0 + (long)(kslab0 / 16 + u) * sa16), P.a_drop_p, a_inv);
+          va = drop4(va, a_key, (uint32_t)(offa0 + (long)(slab * kSub + u) * sa16), P.a_drop_p, a_inv);
         if (b_dropout && b_ok)
-          vb = drop4(vb, b_key, (uint32_t)(offb0 + (long)(kslab0 / 16 + u) * sb16), P.b_drop_p, b_inv);
-        put(As[buf], a_kc, a_slow, a_fast, u * 16, va);
-        put(Bs[buf], b_kc, b_slow, b_fast, u * 16, vb);
+          vb = drop4(vb, b_key, (uint32_t)(offb0 + (long)(slab * kSub + u) * sb16), P.b_drop_p, b_inv);
+        if (ones_e == 4) vb = make_float4(1.f, 1.f, 1.f, 1.f);
+        else if (ones_e == 0) vb.x = 1.f;
+        else if (ones_e == 1) vb.y = 1.f;
+        else if (ones_e == 2) vb.z = 1.f;
+        else if (ones_e == 3) vb.w = 1.f;
+        put(As[buf], a_kc, a_slow, a_fast, u * kSW, va);
+        put(Bs[buf], b_kc, b_slow, b_fast, u * kSW, vb);
       }
     };
     const int nslab = (kend - kbeg) / kBK;
+    // (a two-slab-deep register prefetch was measured: no gain -- the loop is not bound by the L2 round
+    // trip -- so one register set it is)
     fetch_fast(0);
-    commit_fast(0);
+    commit_fast(0, 0);
     __syncthreads();
     for (int sl = 0; sl < nslab; ++sl) {
       const bool more = sl + 1 < nslab;
       if (more) fetch_fast(sl + 1);
       mfma_slab(sl & 1);
-      if (more) commit_fast((sl + 1) & 1);
+      if (more) commit_fast(sl + 1, (sl + 1) & 1);
       __syncthreads();
     }
   } else {
@@ -347,15 +366,15 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
       kfetched = k0;
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        fa[u] = fetch_tile(P.a, P.a2, P.lda_m, P.lda_k, m0, P.M, k0 + u * 16, kend, tid);
-        fb[u] = fetch_tile<false>(P.b, nullptr, P.ldb_n, P.ldb_k, n0, P.N, k0 + u * 16, kend, tid);
+        fa[u] = fetch_tile<kSW>(P.a, P.a2, P.lda_m, P.lda_k, m0, P.M, k0 + u * kSW, kend, tid);
+        fb[u] = fetch_tile<kSW, false>(P.b, nullptr, P.ldb_n, P.ldb_k, n0, P.N, k0 + u * kSW, kend, tid);
       }
     };
     auto commit = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        commit_tile(As[buf], fa[u], fxa, P.lda_k, m0, P.M, kfetched + u * 16, kend, false, u * 16, tid);
-        commit_tile(Bs[buf], fb[u], fxb, P.ldb_k, n0, P.N, kfetched + u * 16, kend, ones, u * 16, tid);
+        commit_tile<kSW>(As[buf], fa[u], fxa, P.lda_k, m0, P.M, kfetched + u * kSW, kend, false, u * kSW, tid);
+        commit_tile<kSW>(Bs[buf], fb[u], fxb, P.ldb_k, n0, P.N, kfetched + u * kSW, kend, ones, u * kSW, tid);
       }
     };
     fetch(kbeg);
@@ -394,10 +413,10 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < kNJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          Cs[wr * 32 + i * 16 + fg * 4 + r][wc * 32 + j * 16 + fr] = acc[i][j][r];
+          Cs[wr * 32 + i * 16 + fg * 4 + r][wc * (16 * kNJ) + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
     const int c4 = (tid & 15) * 4;
     const int n = n0 + c4;
@@ -411,8 +430,8 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
     double *const col_sum = P.col_sum, *const col_sumsq = P.col_sumsq;
     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int row = (tid >> 4) + qq * 16;
+    for (int qq = 0; qq < kBM / kRowPhases; ++qq) {
+      const int row = (tid >> 4) + qq * kRowPhases;
       const int m = m0 + row;
       if (m >= pM || n >= pN) continue;
       const float4 cv = *reinterpret_cast<const float4 *>(&Cs[row][c4]);
@@ -441,35 +460,35 @@ __global__ __launch_bounds__(kGemmThreads) void gemm_kernel(GemmBatch batch,
       // column sums of the tile: 16 row-phase partials per column through LDS (the B buffers are free
       // after the last barrier of the K loop), then one double atomic per column and statistic
       float *red = &Bs[0][0][0];
-      static_assert(sizeof(Bs) >= sizeof(float) * 2 * 16 * kBN, "statistics scratch must fit the B buffers");
+      static_assert(sizeof(Bs) >= sizeof(float) * 2 * kRowPhases * kBN, "statistics scratch must fit the B buffers");
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        red[(0 * 16 + (tid >> 4)) * kBN + c4 + e] = cs[e];
-        red[(1 * 16 + (tid >> 4)) * kBN + c4 + e] = cq[e];
+        red[(0 * kRowPhases + (tid >> 4)) * kBN + c4 + e] = cs[e];
+        red[(1 * kRowPhases + (tid >> 4)) * kBN + c4 + e] = cq[e];
       }
       __syncthreads();
       if (tid < 2 * kBN) {
         const int which = tid >> 6, col = tid & 63;
         double acc = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc += (double)red[(which * 16 + r) * kBN + col];
+        for (int r = 0; r < kRowPhases; ++r) acc += (double)red[(which * kRowPhases + r) * kBN + col];
         if (n0 + col < pN) atomicAdd((which ? col_sumsq : col_sum) + n0 + col, acc);
       }
     }
     return;
   }
   // accumulate / bias-gradient path: element-wise atomics straight from the accumulators
-  float bias_v[2];
+  float bias_v[kNJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wc * 32 + j * 16 + fr;
+  for (int j = 0; j < kNJ; ++j) {
+    const int n = n0 + wc * (16 * kNJ) + j * 16 + fr;
     bias_v[j] = (P.bias && slice == 0 && n < pN) ? P.bias[n] : 0.f;
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wc * 32 + j * 16 + fr;
+    for (int j = 0; j < kNJ; ++j) {
+      const int n = n0 + wc * (16 * kNJ) + j * 16 + fr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wr * 32 + i * 16 + fg * 4 + r;
@@ -646,18 +665,25 @@ __global__ __launch_bounds__(kLnBwdThreads) void ln_bwd_kernel(
 
 extern "C" {
 
-int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64_t *rng_counter,
-                      butd_stream_t stream) {
-  if (count <= 0) return 0;
-  if (count > kMaxProblems) return (int)hipErrorInvalidValue;
+static bool fast_eligible(const butd_gemm_problem &p) {
+  const bool a_kc = p.lda_k == 1, b_kc = p.ldb_k == 1;
+  const int kslab = (p.K + kBK - 1) / kBK, split = p.split_k < 1 ? 1 : p.split_k;
+  const long per = (long)((kslab + split - 1) / split) * kBK;   // contraction range of one slice
+  return p.a2 == nullptr && p.K > 0 && (p.K % kBK) == 0 &&
+         (a_kc || (p.M & 3) == 0) && (b_kc || (p.N & 3) == 0) &&   // partial tiles: whole float4 in or out
+         ((a_kc ? p.lda_m : p.lda_k) & 3) == 0 && ((b_kc ? p.ldb_n : p.ldb_k) & 3) == 0 &&
+         ((((uintptr_t)p.a) | ((uintptr_t)p.b)) & 15) == 0 &&
+         (p.a_chan_scale == nullptr || per <= kAffK);
+}
+
+static int launch_group(const butd_gemm_problem *problems, const int *index, int count, bool fast,
+                        const uint64_t *rng_counter, hipStream_t stream) {
   GemmBatch batch;
   long total = 0;
   batch.count = 0;
   for (int i = 0; i < count; ++i) {
-    butd_gemm_problem p = problems[i];
-    if (p.M <= 0 || p.N <= 0) continue;
+    butd_gemm_problem p = problems[index[i]];
     if (p.split_k < 1) p.split_k = 1;
-    if (p.split_k > 1 && !p.accumulate) return (int)hipErrorInvalidValue;
     const int ncols = p.N + (p.ones_col ? 1 : 0);
     const int tn = (ncols + kBN - 1) / kBN, tm = (p.M + kBM - 1) / kBM;
     batch.blk_begin[batch.count] = (int)total;
@@ -669,9 +695,38 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
   }
   if (batch.count == 0) return 0;
   for (int i = batch.count; i <= kMaxProblems; ++i) batch.blk_begin[i] = (int)total;
-  hipLaunchKernelGGL(gemm_kernel, dim3((unsigned)total), dim3(kGemmThreads), 0, (hipStream_t)stream,
-                     batch, rng_counter);
+  static const int forced = getenv("BUTD_GEMM_THREADS") ? atoi(getenv("BUTD_GEMM_THREADS")) : 0;
+  // 8 waves per tile when the grid cannot give every CU two workgroups (the matrix phase of a lone
+  // workgroup is then split over twice the waves); 4 waves for the large grids (measured both ways)
+  const int threads = forced ? forced : (total <= 320 ? 512 : 256);
+  const dim3 grid((unsigned)total);
+  if (fast && threads == 256)
+    hipLaunchKernelGGL((gemm_kernel<256, true>), grid, dim3(256), 0, stream, batch, rng_counter);
+  else if (fast)
+    hipLaunchKernelGGL((gemm_kernel<512, true>), grid, dim3(512), 0, stream, batch, rng_counter);
+  else if (threads == 256)
+    hipLaunchKernelGGL((gemm_kernel<256, false>), grid, dim3(256), 0, stream, batch, rng_counter);
+  else
+    hipLaunchKernelGGL((gemm_kernel<512, false>), grid, dim3(512), 0, stream, batch, rng_counter);
   return (int)hipGetLastError();
+}
+
+int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64_t *rng_counter,
+                      butd_stream_t stream) {
+  if (count <= 0) return 0;
+  if (count > kMaxProblems) return (int)hipErrorInvalidValue;
+  // the problems of a group are independent: the fast-eligible ones and the rest run as two launches
+  int fast_idx[kMaxProblems], slow_idx[kMaxProblems], nf = 0, ns = 0;
+  for (int i = 0; i < count; ++i) {
+    const butd_gemm_problem &p = problems[i];
+    if (p.M <= 0 || p.N <= 0) continue;
+    if (p.split_k > 1 && !p.accumulate) return (int)hipErrorInvalidValue;
+    if ((p.col_sum != nullptr) && (p.accumulate || p.split_k > 1)) return (int)hipErrorInvalidValue;
+    if (fast_eligible(p)) fast_idx[nf++] = i; else slow_idx[ns++] = i;
+  }
+  int err = launch_group(problems, fast_idx, nf, true, rng_counter, (hipStream_t)stream);
+  if (err) return err;
+  return launch_group(problems, slow_idx, ns, false, rng_counter, (hipStream_t)stream);
 }
 
 #define LN_DISPATCH_T(THREADS, KERNEL, ...)                                                     \

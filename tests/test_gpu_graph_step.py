@@ -1,0 +1,61 @@
+"""-m gpu: the hipGraph training step with the furthest-point-sampling chain prefetched for the NEXT
+batch on a forked stream must train exactly like the step that samples in line -- over several
+DIFFERENT batches (so a stale or mis-paired prefetch shows), including an unannounced batch."""
+import copy
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model():
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from butd_detr_amd.offline_text import offline_factory
+    attention_blocks.set_backend("hip")
+    torch.manual_seed(0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=64,
+                       num_decoder_layers=2, num_encoder_layers=1, self_position_embedding="loc_learned",
+                       contrastive_align_loss=True, butd=True, self_attend=True,
+                       text_encoder_factory=offline_factory(0))
+    m = m.cuda().train()
+    for mod in m.modules():                      # identical arithmetic in both runs: no dropout draws
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if hasattr(mod, "dropout") and isinstance(getattr(mod, "dropout"), float):
+            mod.dropout = 0.0
+    return m
+
+
+def test_prefetched_sampling_trains_like_inline_sampling():
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, synthetic_batch
+    try:
+        dev = torch.device("cuda", 0)
+        batches = [synthetic_batch(2, dev, seed=100 + 7 * i, n_points=4096, tokens=24) for i in range(4)]
+        ref_model = _model()
+        pre_model = copy.deepcopy(ref_model)
+        # learning rate 0: the per-batch losses are functions of (fixed weights, batch, sampled indices)
+        # only, so they must agree to rounding -- a stale or mis-paired prefetch changes them visibly
+        ref = GraphedTrainStep(ref_model, FlatAdamW(ref_model, lr=0.0, lr_backbone=0.0), warmup=1,
+                               prefetch_sampling=False)
+        pre = GraphedTrainStep(pre_model, FlatAdamW(pre_model, lr=0.0, lr_backbone=0.0), warmup=1,
+                               prefetch_sampling=True)
+        ref_losses, pre_losses = [], []
+        for i, (inp, tgt) in enumerate(batches):
+            ref_losses.append(float(ref(inp, tgt)))
+            # batch 2 arrives unannounced (the step before did not name it): falls back to sampling it
+            nxt = batches[i + 1][0] if i + 1 < len(batches) and i != 1 else None
+            pre_losses.append(float(pre(inp, tgt, next_inputs=nxt)))
+        assert len({round(l, 3) for l in ref_losses}) == len(ref_losses)      # the batches do differ
+        for a, b in zip(pre_losses, ref_losses):
+            assert abs(a - b) <= 1e-4 * max(abs(b), 1.0), (pre_losses, ref_losses)
+        # and the sampled indices the prefetching step consumed for the last batch are that batch's
+        want = torch.cat([i.reshape(-1) for i in pre_model.backbone_net.sample(batches[-1][0]["point_clouds"])])
+        assert torch.equal(pre.s_inds_cur, want)
+    finally:
+        attention_blocks.set_backend("torch")
