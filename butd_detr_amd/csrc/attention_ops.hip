@@ -18,6 +18,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "../../include/butd_attention.h"
 #include "rng.h"
 
@@ -165,6 +167,9 @@ __device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, const Ope
   }
 }
 
+struct Whole { static constexpr bool ragged = false; };   // slab kinds of the fast path (see below)
+struct Ragged { static constexpr bool ragged = true; };
+
 // FAST: every problem of the launch satisfies fast_eligible() (host side): interior tiles stream whole
 // float4s with addresses  base + slab * step  and no bounds checks; the generic instantiation handles
 // ragged K, unaligned operands and the a2 companion.  Two kernels instead of one runtime branch: with
@@ -238,8 +243,18 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
   // Fast path (interior tiles, the common case): every address is  base + slab * step  with the
   // per-thread bases computed once; a slab costs each thread 2*kSub float4 loads, 2*kSub LDS writes and
   // the MFMAs -- no bounds checks, no index arithmetic.  Edge tiles take the generic path below.
-  const bool a_kc = P.lda_k == 1, b_kc = P.ldb_k == 1;
   if constexpr (FAST) {
+    // The loop is specialised at compile time on the operand layouts and on "plain" vs "with effects"
+    // (affine / dropout / ones-row / ragged last slab) and selected by one switch per workgroup: with
+    // every mode behind run-time branches in one loop body the kernel was ~8 % slower (the path taken
+    // was a few hundred instructions scattered over a 30 KB body).
+    const bool rt_a_kc = P.lda_k == 1, rt_b_kc = P.ldb_k == 1;
+    const bool rt_fx = P.a_chan_scale != nullptr || P.b_chan_scale != nullptr || a_dropout || b_dropout ||
+                       ones || ((kend - kbeg) % kBK) != 0;
+    auto run_fast = [&](auto a_kc_t, auto b_kc_t, auto fx_t) {
+    constexpr bool a_kc = decltype(a_kc_t)::value, b_kc = decltype(b_kc_t)::value;
+    constexpr bool FX = decltype(fx_t)::value;
+    const bool f_ones = FX && ones, f_adrop = FX && a_dropout, f_bdrop = FX && b_dropout;
     const int a_slow = a_kc ? (tid / (kSW / 4)) : (tid >> 4);
     const int a_fast = a_kc ? (tid % (kSW / 4)) * 4 : (tid & 15) * 4;
     const int b_slow = b_kc ? (tid / (kSW / 4)) : (tid >> 4);
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     if (!a_ok) pa = P.a;
     if (!b_ok) pb = P.b;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool a_aff = P.a_chan_scale != nullptr;   // channel = k (varies per slab): staged in LDS
+    const bool a_aff = FX && P.a_chan_scale != nullptr;   // channel = k (varies per slab): staged in LDS
     if (a_aff) {
       for (int k = tid; k < kend - kbeg; k += THREADS) {
         Asc[k] = P.a_chan_scale[kbeg + k];
@@ -266,7 +281,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
       }
     }
     float4 bsc4 = make_float4(1.f, 1.f, 1.f, 1.f), bsh4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool b_aff = P.b_chan_scale != nullptr;
+    const bool b_aff = FX && P.b_chan_scale != nullptr;
     if (b_aff && !b_kc) {  // channel = B row = 4 consecutive rows of this thread: loop-invariant
       if (b_ok) {
         bsc4 = *reinterpret_cast<const float4 *>(P.b_chan_scale + n0 + b_fast);
@@ -279,7 +294,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     }
     if (a_aff) __syncthreads();
     // virtual ones-row of B (row index N): which of this thread's elements is it, if any
-    const int ones_e = !ones ? -1 : (b_kc ? (n0 + b_slow == P.N ? 4 : -1)
+    const int ones_e = !f_ones ? -1 : (b_kc ? (n0 + b_slow == P.N ? 4 : -1)
                                           : ((n0 + b_fast <= P.N && P.N < n0 + b_fast + 4) ? P.N - (n0 + b_fast) : -1));
     float4 ra[kSub], rb[kSub];
     const long offa0 = pa - P.a, offb0 = pb - P.b;   // element offsets of this thread's first float4
@@ -290,11 +305,23 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
       v.w = rng::keep_keyed(key, off + 3, p) ? v.w * inv : 0.f;
       return v;
     };
-    auto fetch_fast = [&](int slab) {
+    // k position (inside a staging step) of this thread's float4, per operand; a float4 whose k is
+    // beyond the slice (ragged last slab, K % 4 == 0) is zero
+    const int krange = kend - kbeg;
+    const int a_k = a_kc ? a_fast : a_slow, b_k = b_kc ? b_fast : b_slow;
+    // fetch / commit come in two flavours selected at compile time: whole slabs (the steady state: no
+    // predicates at all) and the ragged last slab (its predicates cost ~8 % when left in the main loop)
+    auto fetch_fast = [&](int slab, auto kind) {
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        ra[u] = ldg4(pa + (long)(slab * kSub + u) * sa16);
-        rb[u] = ldg4(pb + (long)(slab * kSub + u) * sb16);
+        if constexpr (!decltype(kind)::ragged) {
+          ra[u] = ldg4(pa + (long)(slab * kSub + u) * sa16);
+          rb[u] = ldg4(pb + (long)(slab * kSub + u) * sb16);
+        } else {
+          const int k0 = slab * kBK + u * kSW;
+          ra[u] = (k0 + a_k < krange) ? ldg4(pa + (long)(slab * kSub + u) * sa16) : zero4;
+          rb[u] = (k0 + b_k < krange) ? ldg4(pb + (long)(slab * kSub + u) * sb16) : zero4;
+        }
       }
     };
     auto put = [&](float (*tile)[kLd], bool kc, int slow, int fst, int koff, float4 v) {
@@ -305,12 +332,18 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
         tile[fst + 2][koff + slow] = v.z; tile[fst + 3][koff + slow] = v.w;
       }
     };
-    auto commit_fast = [&](int slab, int buf) {
+    auto commit_fast = [&](int slab, int buf, auto kind) {
       const int kslab0 = slab * kBK;   // k offset (relative to kbeg) of the slab held in ra/rb
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        float4 va = a_ok ? ra[u] : zero4, vb = b_ok ? rb[u] : zero4;
-        if (a_aff && a_ok) {
+        bool a_in = true, b_in = true;
+        if constexpr (decltype(kind)::ragged) {
+          a_in = kslab0 + u * kSW + a_k < krange;
+          b_in = kslab0 + u * kSW + b_k < krange;
+        }
+        const bool a_live = a_ok && a_in, b_live = b_ok && b_in;
+        float4 va = a_live ? ra[u] : zero4, vb = b_live ? rb[u] : zero4;
+        if (a_aff && a_live) {
           float4 sc, sh;
           if (a_kc) {
             sc = *reinterpret_cast<const float4 *>(&Asc[kslab0 + u * kSW + a_fast]);
@@ -323,35 +356,64 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
           va.x = fmaxf(va.x * sc.x + sh.x, 0.f); va.y = fmaxf(va.y * sc.y + sh.y, 0.f);
           va.z = fmaxf(va.z * sc.z + sh.z, 0.f); va.w = fmaxf(va.w * sc.w + sh.w, 0.f);
         }
-        if (b_aff && b_ok) {
+        if (b_aff && b_live) {
           vb.x = fmaxf(vb.x * bsc4.x + bsh4.x, 0.f); vb.y = fmaxf(vb.y * bsc4.y + bsh4.y, 0.f);
           vb.z = fmaxf(vb.z * bsc4.z + bsh4.z, 0.f); vb.w = fmaxf(vb.w * bsc4.w + bsh4.w, 0.f);
         }
-        if (a_dropout && a_ok)
+        if (f_adrop && a_live)
           va = drop4(va, a_key, (uint32_t)(offa0 + (long)(slab * kSub + u) * sa16), P.a_drop_p, a_inv);
-        if (b_dropout && b_ok)
+        if (f_bdrop && b_live)
           vb = drop4(vb, b_key, (uint32_t)(offb0 + (long)(slab * kSub + u) * sb16), P.b_drop_p, b_inv);
-        if (ones_e == 4) vb = make_float4(1.f, 1.f, 1.f, 1.f);
-        else if (ones_e == 0) vb.x = 1.f;
-        else if (ones_e == 1) vb.y = 1.f;
-        else if (ones_e == 2) vb.z = 1.f;
-        else if (ones_e == 3) vb.w = 1.f;
+        if (b_in) {   // the ones-row is 1 for every k inside the slice
+          if (ones_e == 4) vb = make_float4(1.f, 1.f, 1.f, 1.f);
+          else if (ones_e == 0) vb.x = 1.f;
+          else if (ones_e == 1) vb.y = 1.f;
+          else if (ones_e == 2) vb.z = 1.f;
+          else if (ones_e == 3) vb.w = 1.f;
+        }
         put(As[buf], a_kc, a_slow, a_fast, u * kSW, va);
         put(Bs[buf], b_kc, b_slow, b_fast, u * kSW, vb);
       }
     };
-    const int nslab = (kend - kbeg) / kBK;
+    const int nslab = (krange + kBK - 1) / kBK;
     // (a two-slab-deep register prefetch was measured: no gain -- the loop is not bound by the L2 round
     // trip -- so one register set it is)
-    fetch_fast(0);
-    commit_fast(0, 0);
+    const int nwhole = krange / kBK;
+    if (!FX || nwhole > 0) {
+      fetch_fast(0, Whole());
+      commit_fast(0, 0, Whole());
+    } else {
+      fetch_fast(0, Ragged());
+      commit_fast(0, 0, Ragged());
+    }
     __syncthreads();
     for (int sl = 0; sl < nslab; ++sl) {
-      const bool more = sl + 1 < nslab;
-      if (more) fetch_fast(sl + 1);
-      mfma_slab(sl & 1);
-      if (more) commit_fast(sl + 1, (sl + 1) & 1);
+      const int nx = sl + 1;
+      if (nx < nwhole) {
+        fetch_fast(nx, Whole());
+        mfma_slab(sl & 1);
+        commit_fast(nx, nx & 1, Whole());
+      } else if (FX && nx < nslab) {
+        fetch_fast(nx, Ragged());
+        mfma_slab(sl & 1);
+        commit_fast(nx, nx & 1, Ragged());
+      } else {
+        mfma_slab(sl & 1);
+      }
       __syncthreads();
+    }
+    };   // run_fast
+    typedef std::true_type T_;
+    typedef std::false_type F_;
+    switch ((rt_a_kc ? 1 : 0) | (rt_b_kc ? 2 : 0) | (rt_fx ? 4 : 0)) {
+      case 0: run_fast(F_(), F_(), F_()); break;
+      case 1: run_fast(T_(), F_(), F_()); break;
+      case 2: run_fast(F_(), T_(), F_()); break;
+      case 3: run_fast(T_(), T_(), F_()); break;
+      case 4: run_fast(F_(), F_(), T_()); break;
+      case 5: run_fast(T_(), F_(), T_()); break;
+      case 6: run_fast(F_(), T_(), T_()); break;
+      default: run_fast(T_(), T_(), T_()); break;
     }
   } else {
     // streaming: double-buffered LDS, one barrier per slab: slab i+1 travels global -> registers while
@@ -669,7 +731,7 @@ static bool fast_eligible(const butd_gemm_problem &p) {
   const bool a_kc = p.lda_k == 1, b_kc = p.ldb_k == 1;
   const int kslab = (p.K + kBK - 1) / kBK, split = p.split_k < 1 ? 1 : p.split_k;
   const long per = (long)((kslab + split - 1) / split) * kBK;   // contraction range of one slice
-  return p.a2 == nullptr && p.K > 0 && (p.K % kBK) == 0 &&
+  return p.a2 == nullptr && p.K > 0 && (p.K & 3) == 0 &&   // a ragged LAST slab is predicated per float4
          (a_kc || (p.M & 3) == 0) && (b_kc || (p.N & 3) == 0) &&   // partial tiles: whole float4 in or out
          ((a_kc ? p.lda_m : p.lda_k) & 3) == 0 && ((b_kc ? p.ldb_n : p.ldb_k) & 3) == 0 &&
          ((((uintptr_t)p.a) | ((uintptr_t)p.b)) & 15) == 0 &&

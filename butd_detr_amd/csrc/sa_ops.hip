@@ -24,11 +24,15 @@ __global__ __launch_bounds__(kThreads) void sa_group_kernel(int N, int np, int n
                                                             long feat_stride,
                                                             const int *__restrict__ idx, float radius,
                                                             int normalize, float *__restrict__ X,
-                                                            long total) {
+                                                            int ldx, long total) {
   const int Cin = 3 + C;
   for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
-    const long p = e / Cin;
-    const int c = (int)(e - p * Cin);
+    const long p = e / ldx;
+    const int c = (int)(e - p * ldx);
+    if (c >= Cin) {   // padding columns (row stride rounded up for 16-byte rows)
+      X[e] = 0.f;
+      continue;
+    }
     const long g = p / ns;           // (b, j)
     const long b = g / np;
     const int src = idx[p];
@@ -324,13 +328,12 @@ __global__ __launch_bounds__(kThreads) void sa_scatter_rows_kernel(int N, int np
                                                                    const float *__restrict__ dX,
                                                                    const int *__restrict__ idx,
                                                                    float *__restrict__ d_feats,
-                                                                   long total) {
-  const int Cin = 3 + C;
+                                                                   int ldx, long total) {
   for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
     const long p = e / C;
     const int c = (int)(e - p * C);
     const long b = p / ((long)np * ns);
-    atomicAdd(d_feats + (b * N + idx[p]) * C + c, dX[p * Cin + 3 + c]);
+    atomicAdd(d_feats + (b * N + idx[p]) * C + c, dX[p * ldx + 3 + c]);
   }
 }
 
@@ -348,11 +351,12 @@ extern "C" {
 
 int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const float *new_xyz,
                   const float *feats, long feat_stride, const int *idx, float radius, int normalize,
-                  float *X, butd_stream_t stream) {
-  const long total = (long)B * np * ns * (3 + C);
+                  float *X, int ldx, butd_stream_t stream) {
+  if (ldx < 3 + C) return (int)hipErrorInvalidValue;
+  const long total = (long)B * np * ns * ldx;
   if (total <= 0) return 0;
   hipLaunchKernelGGL(sa_group_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
-                     N, np, ns, C, xyz, new_xyz, feats, feat_stride, idx, radius, normalize, X, total);
+                     N, np, ns, C, xyz, new_xyz, feats, feat_stride, idx, radius, normalize, X, ldx, total);
   return (int)hipGetLastError();
 }
 
@@ -436,12 +440,13 @@ int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, 
   return (int)hipGetLastError();
 }
 
-int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, const int *idx,
+int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, int ldx, const int *idx,
                          float *d_feats_pm, butd_stream_t stream) {
+  if (ldx < 3 + C) return (int)hipErrorInvalidValue;
   const long total = (long)B * np * ns * C;
   if (total <= 0) return 0;
   hipLaunchKernelGGL(sa_scatter_rows_kernel, dim3(blocks_for(total, 65536)), dim3(kThreads), 0,
-                     (hipStream_t)stream, N, np, ns, C, dX, idx, d_feats_pm, total);
+                     (hipStream_t)stream, N, np, ns, C, dX, idx, d_feats_pm, ldx, total);
   return (int)hipGetLastError();
 }
 

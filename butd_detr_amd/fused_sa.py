@@ -44,11 +44,16 @@ class _SAMlpPool(torch.autograd.Function):
         ws = [w.reshape(w.shape[0], -1) for w in (w1, w2, w3)]
         C1, C2, C3 = (w.shape[0] for w in ws)
         assert ws[0].shape[1] == Cin and ws[1].shape[1] == C1 and ws[2].shape[1] == C2
+        # rows of 3+C floats (6, 131, 259) are not 16-byte aligned: pad the grouped input and the first
+        # weight matrix to a multiple of 4 columns (zeros) so the first product takes the float4 path
+        Kp = (Cin + 3) // 4 * 4
+        if Kp != Cin:
+            ws[0] = torch.nn.functional.pad(ws[0], (0, Kp - Cin))
 
-        X = torch.empty((P, Cin), device=dev)
+        X = torch.empty((P, Kp), device=dev)
         fptr = None if feats_pm is None else feats_pm.data_ptr() + 4 * feat_ptr_offset
         _call("butd_sa_group", xyz, B, N, np_, ns, C, xyz.data_ptr(), new_xyz.data_ptr(), fptr,
-              feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr())
+              feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr(), Kp)
 
         stats = torch.zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
         aff = torch.empty((3, 4, max(C1, C2, C3)), device=dev)  # per layer: mean, rstd, scale, shift
@@ -59,14 +64,19 @@ class _SAMlpPool(torch.autograd.Function):
         zmax = zmin = amax = amin = None
         for li, (Cl, w) in enumerate(zip((C1, C2, C3), ws)):
             Z = torch.empty((P, Cl), device=dev)
-            _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff)], xyz)
             last = li == 2
+            # BatchNorm sums straight from the GEMM epilogue -- while the row count is moderate: every
+            # 64-row tile ends in 2 double atomics per column on the SAME addresses, and at 10^6 rows that
+            # contention costs more than the separate streaming pass (which reduces 256 rows first)
+            in_gemm_stats = training and not last and P <= int(__import__("os").environ.get("BUTD_SA_EPI_ROWS", 131072))
+            _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff,
+                        col_stats=(stats[li, 0], stats[li, 1]) if in_gemm_stats else None)], xyz)
             if last:
                 zmax = torch.empty((G, Cl), device=dev)
                 zmin = torch.empty((G, Cl), device=dev)
                 amax = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
                 amin = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
-            if training or last:
+            if last or (training and not in_gemm_stats):
                 _call("butd_sa_colstats", xyz, P, Cl, Z.data_ptr(), stats[li, 0].data_ptr(),
                       stats[li, 1].data_ptr(), ns if last else 0, _p(zmax), _p(zmin), _p(amax), _p(amin))
             g, b, rm, rv, nbt, eps = layers[li]
@@ -86,15 +96,15 @@ class _SAMlpPool(torch.autograd.Function):
               out_pm.data_ptr(), zsel.data_ptr(), asel.data_ptr())
         ctx.save_for_backward(X, Zs[0], Zs[1], Zs[2], idx, aff, zsel, asel, ws[0], ws[1], ws[2], g1, g2, g3)
         ctx.cfg = (B, N, np_, ns, C, bool(training), feats_pm is not None and feats_pm.requires_grad,
-                   w1.shape, w2.shape, w3.shape)
+                   w1.shape, w2.shape, w3.shape, Cin)
         return out_cm, out_pm
 
     @staticmethod
     def backward(ctx, d_cm, d_pm):
         X, Z1, Z2, Z3, idx, aff, zsel, asel, w1, w2, w3, g1, g2, g3 = ctx.saved_tensors
-        B, N, np_, ns, C, training, need_dfeat, s1, s2, s3 = ctx.cfg
+        B, N, np_, ns, C, training, need_dfeat, s1, s2, s3, Cin = ctx.cfg
         dev = X.device
-        P, Cin = X.shape
+        P, Kp = X.shape                                 # Kp = Cin rounded up to a multiple of 4
         C1, C2, C3 = w1.shape[0], w2.shape[0], w3.shape[0]
         if d_cm is None:
             d_out = d_pm.transpose(1, 2).contiguous()
@@ -104,10 +114,10 @@ class _SAMlpPool(torch.autograd.Function):
             d_out = d_cm + d_pm.transpose(1, 2)
         tr = int(training)
         S = torch.zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
-        dW = torch.zeros(C3 * C2 + C2 * C1 + C1 * Cin, device=dev)
+        dW = torch.zeros(C3 * C2 + C2 * C1 + C1 * Kp, device=dev)
         dW3 = dW[:C3 * C2].view(C3, C2)
         dW2 = dW[C3 * C2:C3 * C2 + C2 * C1].view(C2, C1)
-        dW1 = dW[C3 * C2 + C2 * C1:].view(C1, Cin)
+        dW1 = dW[C3 * C2 + C2 * C1:].view(C1, Kp)
         mean = lambda l: aff[l, 0]
         rstd = lambda l: aff[l, 1]
         scale = lambda l: aff[l, 2]
@@ -142,20 +152,21 @@ class _SAMlpPool(torch.autograd.Function):
         dZ1 = dH1
         d_feats = None
         if need_dfeat:
-            dX = torch.empty((P, Cin), device=dev)
-            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Cin), _dgrad(dZ1, w1, dX, P, C1, Cin)], X)
+            dX = torch.empty((P, Kp), device=dev)
+            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp), _dgrad(dZ1, w1, dX, P, C1, Kp)], X)
             d_feats = torch.zeros((B, N, C), device=dev)
-            _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), idx.data_ptr(),
+            _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), Kp, idx.data_ptr(),
                   d_feats.data_ptr())
         else:
-            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Cin)], X)
+            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp)], X)
+        dW1 = dW1[:, :Cin]
         Sf = S.float()
         dgs = [Sf[l, 1, :c].contiguous() if training else None for l, c in ((0, C1), (1, C2), (2, C3))]
         dbs = [Sf[l, 0, :c].contiguous() if training else None for l, c in ((0, C1), (1, C2), (2, C3))]
         if not training:   # eval-mode BN: y = gamma*(z-rm)*rs+beta -> parameter grads not produced here
             dgs = dbs = [None, None, None]
         return (None, d_feats, None, None, None, None, None, None,
-                dW1.view(s1), dgs[0], dbs[0], None, None, None, None,
+                dW1.reshape(s1), dgs[0], dbs[0], None, None, None, None,
                 dW2.view(s2), dgs[1], dbs[1], None, None, None, None,
                 dW3.view(s3), dgs[2], dbs[2], None, None, None, None,
                 None, None)

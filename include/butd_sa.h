@@ -24,10 +24,11 @@ typedef void *butd_stream_t;
 
 /* X[p, 0:3] = (xyz[b, idx[p]] - new_xyz[b, j]) (/ radius if normalize), X[p, 3:3+C] = feats[b, idx[p], :]
  * xyz (B,N,3); new_xyz (B,np,3); feats point-major with row stride feat_stride floats (may be NULL,
- * C = 0); idx (B,np,ns) int32; X (B*np*ns, 3+C). */
+ * C = 0); idx (B,np,ns) int32; X (B*np*ns rows of ldx >= 3+C floats; columns 3+C..ldx-1 are zero-filled:
+ * ldx = 3+C rounded up to a multiple of 4 keeps every row 16-byte aligned for the GEMM's float4 path). */
 int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const float *new_xyz,
                   const float *feats, long feat_stride, const int *idx, float radius, int normalize,
-                  float *X, butd_stream_t stream);
+                  float *X, int ldx, butd_stream_t stream);
 
 /* Column statistics of Z (P x C): sum[c] += sum_p z, sumsq[c] += sum_p z^2 (double, atomically
  * accumulated: caller zero-fills).  If pool_ns > 0 also the per-group (pool_ns consecutive rows)
@@ -80,9 +81,9 @@ int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, 
                    const float *mean, const float *rstd, const double *S1, const double *S2,
                    int training, butd_stream_t stream);
 
-/* d_feats_pm[b, idx[p], c] += dX[p, 3 + c]  (dX (P, 3+C) row-major, d_feats_pm (B,N,C) point-major,
- * caller zero-fills). */
-int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, const int *idx,
+/* d_feats_pm[b, idx[p], c] += dX[p, 3 + c]  (dX: P rows of ldx >= 3+C floats, d_feats_pm (B,N,C)
+ * point-major, caller zero-fills). */
+int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, int ldx, const int *idx,
                          float *d_feats_pm, butd_stream_t stream);
 
 #ifdef __cplusplus
