@@ -1078,30 +1078,15 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(
   }
 }
 
-// delta[b,h,q] = sum_n dO[q][n] * O[q][n]
-__global__ __launch_bounds__(256) void attn_delta_kernel(int H, int Lq, int D, long total,
-                                                         const float *__restrict__ out,
-                                                         const float *__restrict__ dout,
-                                                         float *__restrict__ delta) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;  // over (b, q, h)
-  if (i >= total) return;
-  const int h = (int)(i % H);
-  const long bq = i / H;
-  const int qq = (int)(bq % Lq);
-  const long b = bq / Lq;
-  const float *o = out + bq * (long)H * D + (long)h * D;
-  const float *g = dout + bq * (long)H * D + (long)h * D;
-  float s = 0.f;
-  for (int n = 0; n < D; ++n) s += o[n] * g[n];
-  delta[(b * H + h) * Lq + qq] = s;
-}
-
-// dQ: same walk as the forward with K and V swapping roles.
+// dQ: same walk as the forward with K and V swapping roles.  Also produces
+// delta[b,h,q] = sum_n dO[q][n] * O[q][n]  (each query row belongs to exactly one wave here) for the
+// dK/dV kernel that is launched next -- it used to be a launch of its own.
 template <int NS, int NT>
 __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
-    const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ dout,
-    const float *__restrict__ lse, const float *__restrict__ delta, float *__restrict__ dq,
+    const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
+    const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
+    float *__restrict__ dq,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
   __shared__ __attribute__((aligned(16))) float Kimg[2][64][I::LD];
@@ -1128,7 +1113,16 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
   load_row_frag<NS>(gf, gb, E, qi, Lq, fg, D);
   // rows beyond Lq: lse = +inf makes every probability exp(s - inf) = 0
   const float my_lse = qi < Lq ? lse[((long)b * H + h) * Lq + qi] : INFINITY;
-  const float my_delta = qi < Lq ? delta[((long)b * H + h) * Lq + qi] : 0.f;
+  float my_delta;
+  {
+    float of[NS];
+    load_row_frag<NS>(of, out + (long)b * Lq * E + h * D, E, qi, Lq, fg, D);
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) part += gf[s] * of[s];
+    my_delta = quad_sum(part);   // the four lanes of a query hold disjoint d-groups
+    if (fg == 0 && qi < Lq) delta[((long)b * H + h) * Lq + qi] = my_delta;
+  }
   int kcol[NT];
   bool kok[NT];
 #pragma unroll
@@ -1393,11 +1387,8 @@ int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
   if (B <= 0 || H <= 0 || Lq <= 0) return 0;
   if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const long total = (long)B * Lq * H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, H, Lq,
-                     D, total, out, dout, delta);
   const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
-  ATTN_DISPATCH(attn_bwd_dq_kernel, gq, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta, dq,
+  ATTN_DISPATCH(attn_bwd_dq_kernel, gq, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq,
                 dropout_p, dropout_site, rng_counter);
   ATTN_DISPATCH(attn_bwd_dkv_kernel, gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
                 dk, dv, dropout_p, dropout_site, rng_counter);

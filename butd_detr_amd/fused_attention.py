@@ -45,6 +45,66 @@ def _next_site():
     return _site[0]
 
 
+class ZeroArena:
+    """One zero-filled device buffer per training step for everything the fused backward passes
+    accumulate into with atomics (weight-gradient slabs, BatchNorm sums, scatter targets): ``reset()``
+    is ONE memset at the start of a step and ``zeros()`` hands out consecutive 16-byte aligned views,
+    instead of ~130 ``torch.zeros`` fills per step.  Views are only valid until the next ``reset()``,
+    so the arena is opt-in (``with arena:``) for loops that consume the gradients inside the step --
+    ``GraphedTrainStep`` copies them into its flat buffer in the same graph.  The capacity is found on
+    the first (eager) steps: overflow goes to extra chunks that ``reset()`` later merges."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.chunks, self.index, self.offset = [], 0, 0
+
+    def reset(self):
+        capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
+        if len(self.chunks) > 1 and not capturing:
+            total = sum(c.numel() for c in self.chunks)
+            self.chunks = [torch.zeros(total, dtype=torch.uint8, device=self.device)]
+        else:
+            for c in self.chunks:
+                c.zero_()
+        self.index, self.offset = 0, 0
+
+    def zeros(self, shape, dtype=torch.float32):
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        n = 1
+        for d in shape:
+            n *= d
+        nbytes = (n * torch.empty((), dtype=dtype).element_size() + 15) // 16 * 16
+        while True:
+            if self.index < len(self.chunks):
+                c = self.chunks[self.index]
+                if self.offset + nbytes <= c.numel():
+                    raw = c[self.offset:self.offset + nbytes]
+                    self.offset += nbytes
+                    return raw.view(dtype)[:n].view(shape)
+                self.index, self.offset = self.index + 1, 0
+                continue
+            self.chunks.append(torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=self.device))
+
+    def __enter__(self):
+        global _arena
+        self._prev, _arena = _arena, self
+        return self
+
+    def __exit__(self, *exc):
+        global _arena
+        _arena = self._prev
+
+
+_arena = None
+
+
+def zeros(shape, dtype=torch.float32, device=None):
+    """``torch.zeros`` for accumulation targets of the fused blocks, served from the active arena."""
+    if _arena is not None and device is not None and torch.device(device) == _arena.device:
+        return _arena.zeros(shape, dtype)
+    return torch.zeros(shape, dtype=dtype, device=device)
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -151,7 +211,7 @@ class _AttentionBlock(torch.autograd.Function):
         dev = xq.device
         dy = dy.contiguous()
         # one zero-filled slab for everything that is accumulated with atomics
-        slab = torch.zeros(3 * E * E + 3 * E + E * E + E + 2 * E, device=dev)
+        slab = zeros(3 * E * E + 3 * E + E * E + E + 2 * E, device=dev)
         o = 0
         d_w_in = slab[o:o + 3 * E * E].view(3 * E, E); o += 3 * E * E
         d_b_in = slab[o:o + 3 * E]; o += 3 * E
@@ -227,7 +287,7 @@ class _FfnBlock(torch.autograd.Function):
         M = B * L
         dev = x.device
         dy = dy.contiguous()
-        slab = torch.zeros(Fh * E + Fh + E * Fh + E + 2 * E, device=dev)
+        slab = zeros(Fh * E + Fh + E * Fh + E + 2 * E, device=dev)
         off = 0
         d_w1 = slab[off:off + Fh * E].view(Fh, E); off += Fh * E
         d_b1 = slab[off:off + Fh]; off += Fh

@@ -14,7 +14,7 @@ import torch
 
 from . import _hiplib
 from ._hiplib import BnSegment
-from .fused_attention import _gemm, _problem, _stream, rng_counter, _site
+from .fused_attention import _gemm, _problem, _stream, rng_counter, _site, zeros
 
 _lib = _hiplib.load()
 
@@ -54,7 +54,7 @@ class _MlpChains(torch.autograd.Function):
         outp = [params[i * per + 4 * nh:i * per + 4 * nh + 2] for i in range(G)]
         p = spec.p_drop if spec.training else 0.0
         Z = [torch.empty((P, GH), device=dev) for _ in range(nh)]
-        stats = torch.zeros((nh, 2, GH), dtype=torch.float64, device=dev)
+        stats = zeros((nh, 2, GH), dtype=torch.float64, device=dev)
         aff = torch.empty((nh, 4, GH), device=dev)       # per layer: mean, rstd, scale, shift
         sl = lambda i: slice(i * H, (i + 1) * H)
 
@@ -120,7 +120,7 @@ class _MlpChains(torch.autograd.Function):
                 w, b = hidden[i][l][0], hidden[i][l][1]
                 sizes += [w.numel(), 0 if b is None else b.numel()]
             sizes += [outp[i][0].numel(), 0 if outp[i][1] is None else outp[i][1].numel()]
-        slab = torch.zeros(sum(sizes), device=dev)
+        slab = zeros(sum(sizes), device=dev)
         views, o = [], 0
         for n in sizes:
             views.append(slab[o:o + n] if n else None)
@@ -128,7 +128,7 @@ class _MlpChains(torch.autograd.Function):
         dW = [[(views[i * (2 * nh + 2) + 2 * l], views[i * (2 * nh + 2) + 2 * l + 1]) for l in range(nh)]
               for i in range(G)]
         dWo = [(views[i * (2 * nh + 2) + 2 * nh], views[i * (2 * nh + 2) + 2 * nh + 1]) for i in range(G)]
-        S = torch.zeros((nh, 2, GH), dtype=torch.float64, device=dev)
+        S = zeros((nh, 2, GH), dtype=torch.float64, device=dev)
 
         def operand(l, i):
             if l == 0:
@@ -164,7 +164,7 @@ class _MlpChains(torch.autograd.Function):
             if l > 0:
                 dH = torch.empty((P, GH), device=dev)
             elif need_dx:
-                dx = torch.zeros((P, Cin), device=dev) if G > 1 else torch.empty((P, Cin), device=dev)
+                dx = zeros((P, Cin), device=dev) if G > 1 else torch.empty((P, Cin), device=dev)
             probs = []
             for i in range(G):
                 w = hidden[i][l][0]

@@ -9,7 +9,7 @@ BatchNorm+ReLU, so no NCHW tensor, transpose, BN-apply or ReLU pass ever touches
 import torch
 
 from . import _hiplib
-from .fused_attention import _dgrad, _fwd, _gemm, _wgrad
+from .fused_attention import _dgrad, _fwd, _gemm, _wgrad, zeros
 
 _lib = _hiplib.load()
 
@@ -55,7 +55,7 @@ class _SAMlpPool(torch.autograd.Function):
         _call("butd_sa_group", xyz, B, N, np_, ns, C, xyz.data_ptr(), new_xyz.data_ptr(), fptr,
               feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr(), Kp)
 
-        stats = torch.zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
+        stats = zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
         aff = torch.empty((3, 4, max(C1, C2, C3)), device=dev)  # per layer: mean, rstd, scale, shift
         layers = ((g1, b1, rm1, rv1, nbt1, eps1), (g2, b2, rm2, rv2, nbt2, eps2),
                   (g3, b3, rm3, rv3, nbt3, eps3))
@@ -113,8 +113,8 @@ class _SAMlpPool(torch.autograd.Function):
         else:
             d_out = d_cm + d_pm.transpose(1, 2)
         tr = int(training)
-        S = torch.zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
-        dW = torch.zeros(C3 * C2 + C2 * C1 + C1 * Kp, device=dev)
+        S = zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
+        dW = zeros(C3 * C2 + C2 * C1 + C1 * Kp, device=dev)
         dW3 = dW[:C3 * C2].view(C3, C2)
         dW2 = dW[C3 * C2:C3 * C2 + C2 * C1].view(C2, C1)
         dW1 = dW[C3 * C2 + C2 * C1:].view(C1, Kp)
@@ -154,7 +154,7 @@ class _SAMlpPool(torch.autograd.Function):
         if need_dfeat:
             dX = torch.empty((P, Kp), device=dev)
             _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp), _dgrad(dZ1, w1, dX, P, C1, Kp)], X)
-            d_feats = torch.zeros((B, N, C), device=dev)
+            d_feats = zeros((B, N, C), device=dev)
             _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), Kp, idx.data_ptr(),
                   d_feats.data_ptr())
         else:

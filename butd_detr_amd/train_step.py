@@ -231,11 +231,19 @@ class GraphedTrainStep:
     changing a single kernel.  Shapes are static: a new (batch, points, tokens) signature re-captures.
     """
 
-    def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True):
+    def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
+                 zero_arena=True):
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
         self.warmup = warmup
         self.prefetch_sampling = prefetch_sampling
         self._announced = None
+        self.arena = None
+        if zero_arena:
+            try:
+                from .fused_attention import ZeroArena
+                self.arena = ZeroArena(next(model.parameters()).device)
+            except Exception:       # torch backend without the HIP library: stock zero fills
+                self.arena = None
         self.flat_opt = isinstance(optimizer, FlatAdamW)
         self.flat = (_OptimizerGradients(optimizer) if self.flat_opt else
                      FlatGradients([p for g in optimizer.param_groups for p in g["params"]]))
@@ -251,6 +259,13 @@ class GraphedTrainStep:
         return m.backbone_net
 
     def _fwd_bwd(self):
+        if self.arena is None:
+            return self._fwd_bwd_body()
+        self.arena.reset()                      # ONE memset for every atomics target of the step
+        with self.arena:
+            return self._fwd_bwd_body()
+
+    def _fwd_bwd_body(self):
         if self.prefetch_sampling:
             main = torch.cuda.current_stream()
             self.s_inds_cur.copy_(self.s_inds_next)          # this batch's samples (prefetched)
