@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kLnBwdThreads) void ln_bwd_kernel(
     const float *__restrict__ residual, const float *__restrict__ gamma,
     const float *__restrict__ mean, const float *__restrict__ rstd, float *__restrict__ dx,
     float *__restrict__ d_residual, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    float dropout_p, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+    float dropout_p, uint32_t site, const uint64_t *__restrict__ rng_counter, int rows_per_wave) {
   __shared__ float red[2][kLnBwdThreads / 64][64 * PER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool drop = dropout_p > 0.f;
@@ -663,8 +663,8 @@ __global__ __launch_bounds__(kLnBwdThreads) void ln_bwd_kernel(
     pg[i] = 0.f;
     pb[i] = 0.f;
   }
-  const int row0 = (blockIdx.x * (kLnBwdThreads / 64) + wave) * kLnRowsPerWave;
-  for (int rr = 0; rr < kLnRowsPerWave; ++rr) {
+  const int row0 = (blockIdx.x * (kLnBwdThreads / 64) + wave) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
     const int row = row0 + rr;
     if (row >= rows) break;
     const float mu = mean[row], rs = rstd[row];
@@ -822,10 +822,14 @@ int butd_add_dropout_layernorm_bwd(int rows, int cols, const float *dy, const fl
   if (rows <= 0) return 0;
   if (cols <= 0 || cols > 64 * kLnMaxPerLane) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const int rows_per_block = (kLnBwdThreads / 64) * kLnRowsPerWave;
+  // one row per wave while that still leaves workgroups for every CU to spare (a 2048-row call is 128
+  // workgroups); several rows per wave only for very tall inputs, where it trims the dgamma/dbeta atomics
+  static const int forced = getenv("BUTD_LN_RPW") ? atoi(getenv("BUTD_LN_RPW")) : 0;
+  const int rpw = forced ? forced : (rows >= 65536 ? kLnRowsPerWave : 1);
+  const int rows_per_block = (kLnBwdThreads / 64) * rpw;
   const dim3 grid((rows + rows_per_block - 1) / rows_per_block);
   LN_DISPATCH_T(kLnBwdThreads, ln_bwd_kernel, rows, cols, dy, x, residual, gamma, mean, rstd, dx, d_residual, dgamma,
-              dbeta, dropout_p, dropout_site, rng_counter);
+              dbeta, dropout_p, dropout_site, rng_counter, rpw);
   return (int)hipGetLastError();
 }
 
