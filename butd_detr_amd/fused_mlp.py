@@ -26,7 +26,7 @@ def _call(name, ref, *args):
 
 
 def _split(M):
-    return max(1, min(32, M // 256))
+    return min(32, max(M // 256, min(8, M // 64), 1))      # see fused_attention._wgrad
 
 
 class ChainSpec:
