@@ -27,7 +27,8 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kBM = 64, kBN = 64, kBK = 32, kLd = kBK + 4;  // LDS row stride 68 floats = 17 x 16 B
+constexpr int kBK = 32, kLd = kBK + 4;  // slab depth; LDS row stride 36 floats = 9 x 16 B
+// Output tiles are TILE x TILE with TILE = 64 (large grids) or 32 (grids that would leave CUs idle).
 // The kernel is instantiated for 256 threads (4 waves, wave tile 32x32) and 512 threads (8 waves, wave
 // tile 32x16: half the MFMA chain per wave and twice the waves per SIMD for small grids).  One staging
 // step moves ONE float4 per thread and operand: a (64 rows x SW k) sub-slab, SW = THREADS/16.
@@ -66,20 +67,20 @@ struct TileIdx {
   int slow, fast;   // position along the strided / contiguous dimension inside the slab
   bool kc;          // contraction-contiguous?
 };
-template <int SW>
+template <int SW, int TILE>
 __device__ inline TileIdx tile_idx(long ld_k, int tid) {
   TileIdx t;
   t.kc = ld_k == 1;
-  t.slow = t.kc ? (tid / (SW / 4)) : (tid >> 4);
-  t.fast = t.kc ? (tid % (SW / 4)) * 4 : (tid & 15) * 4;
+  t.slow = t.kc ? (tid / (SW / 4)) : (tid / (TILE / 4));
+  t.fast = t.kc ? (tid % (SW / 4)) * 4 : (tid % (TILE / 4)) * 4;
   return t;
 }
 
-template <int SW, bool WITH_A2 = true>
+template <int SW, int TILE, bool WITH_A2 = true>
 __device__ inline Frag4 fetch_tile(const float *__restrict__ src, const float *__restrict__ src2,
                                    long ld_row, long ld_k, int row0, int nrows, int k0, int kend,
                                    int tid) {
-  const TileIdx t = tile_idx<SW>(ld_k, tid);
+  const TileIdx t = tile_idx<SW, TILE>(ld_k, tid);
   const long ld_slow = t.kc ? ld_row : ld_k;
   const int slow_g = (t.kc ? row0 : k0) + t.slow, fast_g = (t.kc ? k0 : row0) + t.fast;
   const int slow_lim = t.kc ? nrows : kend, fast_lim = t.kc ? kend : nrows;
@@ -124,10 +125,10 @@ struct OperandFx {
   long ld_row;
 };
 
-template <int SW>
+template <int SW, int TILE>
 __device__ inline void commit_tile(float (*tile)[kLd], const Frag4 &f, const OperandFx &fx, long ld_k,
                                    int row0, int nrows, int k0, int kend, bool ones, int koff, int tid) {
-  const TileIdx t = tile_idx<SW>(ld_k, tid);
+  const TileIdx t = tile_idx<SW, TILE>(ld_k, tid);
   float v[4] = {f.a.x, f.a.y, f.a.z, f.a.w};
   if (fx.has2) {
     v[0] = combine(v[0], f.a2.x, fx.mode2, fx.scale2); v[1] = combine(v[1], f.a2.y, fx.mode2, fx.scale2);
@@ -174,14 +175,18 @@ struct Ragged { static constexpr bool ragged = true; };
 // float4s with addresses  base + slab * step  and no bounds checks; the generic instantiation handles
 // ragged K, unaligned operands and the a2 companion.  Two kernels instead of one runtime branch: with
 // both paths in one body the compiler merged their MFMA blocks and serialized loads behind them.
-template <int THREADS, bool FAST>
+template <int THREADS, int TILE, bool FAST>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
                                                        const uint64_t *__restrict__ rng_counter) {
-  constexpr int kSW = THREADS / 16;        // k-width of one staging step
+  constexpr int kBM = TILE, kBN = TILE;
+  constexpr int kSW = 4 * THREADS / TILE;  // k-width of one staging step (one float4 per thread)
   constexpr int kSub = kBK / kSW;          // staging steps per slab
   constexpr int kWavesN = THREADS / 128;   // wave grid 2 x kWavesN
-  constexpr int kNJ = 4 / kWavesN;         // 16-column fragments per wave
-  constexpr int kRowPhases = THREADS / 16; // rows written per epilogue pass
+  constexpr int kMI = TILE / 32;           // 16-row fragments per wave
+  constexpr int kNJ = TILE / (16 * kWavesN);   // 16-column fragments per wave
+  constexpr int kRQ = TILE / 4;            // float4 per tile row / per k-row of a row-contiguous operand
+  constexpr int kRowPhases = THREADS / kRQ;    // rows written per epilogue pass
+  static_assert(kSub >= 1 && kNJ >= 1 && kMI >= 1 && kRowPhases <= TILE, "unsupported THREADS x TILE");
   __shared__ __attribute__((aligned(16))) float As[2][kBM][kLd];
   __shared__ __attribute__((aligned(16))) float Bs[2][kBN][kLd];
   __shared__ __attribute__((aligned(16))) float Asc[kAffK], Ash[kAffK];
@@ -209,9 +214,9 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
   const int wr = wave / kWavesN, wc = wave % kWavesN;
   const int fr = lane & 15, fg = lane >> 4;
 
-  f32x4 acc[2][kNJ];
+  f32x4 acc[kMI][kNJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kMI; ++i)
 #pragma unroll
     for (int j = 0; j < kNJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -224,17 +229,17 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
   auto mfma_slab = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < kBK / 16; ++u) {
-      f32x4 af[2], bf[kNJ];
+      f32x4 af[kMI], bf[kNJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
-        af[i] = *reinterpret_cast<const f32x4 *>(&As[buf][wr * 32 + i * 16 + fr][u * 16 + fg * 4]);
+      for (int i = 0; i < kMI; ++i)
+        af[i] = *reinterpret_cast<const f32x4 *>(&As[buf][wr * (16 * kMI) + i * 16 + fr][u * 16 + fg * 4]);
 #pragma unroll
       for (int j = 0; j < kNJ; ++j)
         bf[j] = *reinterpret_cast<const f32x4 *>(&Bs[buf][wc * (16 * kNJ) + j * 16 + fr][u * 16 + fg * 4]);
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < kMI; ++i)
 #pragma unroll
           for (int j = 0; j < kNJ; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
@@ -255,10 +260,10 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     constexpr bool a_kc = decltype(a_kc_t)::value, b_kc = decltype(b_kc_t)::value;
     constexpr bool FX = decltype(fx_t)::value;
     const bool f_ones = FX && ones, f_adrop = FX && a_dropout, f_bdrop = FX && b_dropout;
-    const int a_slow = a_kc ? (tid / (kSW / 4)) : (tid >> 4);
-    const int a_fast = a_kc ? (tid % (kSW / 4)) * 4 : (tid & 15) * 4;
-    const int b_slow = b_kc ? (tid / (kSW / 4)) : (tid >> 4);
-    const int b_fast = b_kc ? (tid % (kSW / 4)) * 4 : (tid & 15) * 4;
+    const int a_slow = a_kc ? (tid / (kSW / 4)) : (tid / kRQ);
+    const int a_fast = a_kc ? (tid % (kSW / 4)) * 4 : (tid % kRQ) * 4;
+    const int b_slow = b_kc ? (tid / (kSW / 4)) : (tid / kRQ);
+    const int b_fast = b_kc ? (tid % (kSW / 4)) * 4 : (tid % kRQ) * 4;
     const float *pa = a_kc ? P.a + (long)(m0 + a_slow) * P.lda_m + kbeg + a_fast
                            : P.a + (long)(kbeg + a_slow) * P.lda_k + m0 + a_fast;
     const float *pb = b_kc ? P.b + (long)(n0 + b_slow) * P.ldb_n + kbeg + b_fast
@@ -348,16 +353,17 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     auto mfma_fast = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < kBK / 16; ++u) {
-        f32x4 af[2], bf[kNJ];
+        f32x4 af[kMI], bf[kNJ];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) af[i] = frag(As[buf], a_kc, wr * 32 + i * 16 + fr, u * 16 + fg * 4);
+        for (int i = 0; i < kMI; ++i)
+          af[i] = frag(As[buf], a_kc, wr * (16 * kMI) + i * 16 + fr, u * 16 + fg * 4);
 #pragma unroll
         for (int j = 0; j < kNJ; ++j)
           bf[j] = frag(Bs[buf], b_kc, wc * (16 * kNJ) + j * 16 + fr, u * 16 + fg * 4);
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < kMI; ++i)
 #pragma unroll
             for (int j = 0; j < kNJ; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
@@ -459,15 +465,15 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
       kfetched = k0;
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        fa[u] = fetch_tile<kSW>(P.a, P.a2, P.lda_m, P.lda_k, m0, P.M, k0 + u * kSW, kend, tid);
-        fb[u] = fetch_tile<kSW, false>(P.b, nullptr, P.ldb_n, P.ldb_k, n0, P.N, k0 + u * kSW, kend, tid);
+        fa[u] = fetch_tile<kSW, TILE>(P.a, P.a2, P.lda_m, P.lda_k, m0, P.M, k0 + u * kSW, kend, tid);
+        fb[u] = fetch_tile<kSW, TILE, false>(P.b, nullptr, P.ldb_n, P.ldb_k, n0, P.N, k0 + u * kSW, kend, tid);
       }
     };
     auto commit = [&](int buf) {
 #pragma unroll
       for (int u = 0; u < kSub; ++u) {
-        commit_tile<kSW>(As[buf], fa[u], fxa, P.lda_k, m0, P.M, kfetched + u * kSW, kend, false, u * kSW, tid);
-        commit_tile<kSW>(Bs[buf], fb[u], fxb, P.ldb_k, n0, P.N, kfetched + u * kSW, kend, ones, u * kSW, tid);
+        commit_tile<kSW, TILE>(As[buf], fa[u], fxa, P.lda_k, m0, P.M, kfetched + u * kSW, kend, false, u * kSW, tid);
+        commit_tile<kSW, TILE>(Bs[buf], fb[u], fxb, P.ldb_k, n0, P.N, kfetched + u * kSW, kend, ones, u * kSW, tid);
       }
     };
     fetch(kbeg);
@@ -504,14 +510,14 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     float(*Cs)[kBN + 4] = reinterpret_cast<float(*)[kBN + 4]>(&As[0][0][0]);
     static_assert(sizeof(As) >= sizeof(float) * kBM * (kBN + 4), "C tile must fit the A buffers");
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < kMI; ++i)
 #pragma unroll
       for (int j = 0; j < kNJ; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          Cs[wr * 32 + i * 16 + fg * 4 + r][wc * (16 * kNJ) + j * 16 + fr] = acc[i][j][r];
+          Cs[wr * (16 * kMI) + i * 16 + fg * 4 + r][wc * (16 * kNJ) + j * 16 + fr] = acc[i][j][r];
     __syncthreads();
-    const int c4 = (tid & 15) * 4;
+    const int c4 = (tid % kRQ) * 4, rphase = tid / kRQ;
     const int n = n0 + c4;
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (P.bias && slice == 0) {
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qq = 0; qq < kBM / kRowPhases; ++qq) {
-      const int row = (tid >> 4) + qq * kRowPhases;
+      const int row = rphase + qq * kRowPhases;
       const int m = m0 + row;
       if (m >= pM || n >= pN) continue;
       const float4 cv = *reinterpret_cast<const float4 *>(&Cs[row][c4]);
@@ -556,12 +562,12 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
       static_assert(sizeof(Bs) >= sizeof(float) * 2 * kRowPhases * kBN, "statistics scratch must fit the B buffers");
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        red[(0 * kRowPhases + (tid >> 4)) * kBN + c4 + e] = cs[e];
-        red[(1 * kRowPhases + (tid >> 4)) * kBN + c4 + e] = cq[e];
+        red[(0 * kRowPhases + rphase) * kBN + c4 + e] = cs[e];
+        red[(1 * kRowPhases + rphase) * kBN + c4 + e] = cq[e];
       }
       __syncthreads();
       if (tid < 2 * kBN) {
-        const int which = tid >> 6, col = tid & 63;
+        const int which = tid / kBN, col = tid % kBN;
         double acc = 0.0;
 #pragma unroll
         for (int r = 0; r < kRowPhases; ++r) acc += (double)red[(which * kRowPhases + r) * kBN + col];
@@ -578,13 +584,13 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     bias_v[j] = (P.bias && slice == 0 && n < pN) ? P.bias[n] : 0.f;
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kMI; ++i)
 #pragma unroll
     for (int j = 0; j < kNJ; ++j) {
       const int n = n0 + wc * (16 * kNJ) + j * 16 + fr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wr * 32 + i * 16 + fg * 4 + r;
+        const int m = m0 + wr * (16 * kMI) + i * 16 + fg * 4 + r;
         if (m >= pM) continue;
         float v = acc[i][j][r];
         if (n < pN) {
@@ -769,38 +775,56 @@ static bool fast_eligible(const butd_gemm_problem &p) {
          (p.a_chan_scale == nullptr || per <= kAffK);
 }
 
-static int launch_group(const butd_gemm_problem *problems, const int *index, int count, bool fast,
-                        const uint64_t *rng_counter, hipStream_t stream) {
-  GemmBatch batch;
+static long fill_batch(GemmBatch &batch, const butd_gemm_problem *problems, const int *index, int count,
+                       int tile) {
   long total = 0;
   batch.count = 0;
   for (int i = 0; i < count; ++i) {
     butd_gemm_problem p = problems[index[i]];
     if (p.split_k < 1) p.split_k = 1;
     const int ncols = p.N + (p.ones_col ? 1 : 0);
-    const int tn = (ncols + kBN - 1) / kBN, tm = (p.M + kBM - 1) / kBM;
+    const int tn = (ncols + tile - 1) / tile, tm = (p.M + tile - 1) / tile;
     batch.blk_begin[batch.count] = (int)total;
     batch.tiles_n[batch.count] = tn;
     batch.tiles_m[batch.count] = tm;
     batch.p[batch.count++] = p;
     total += (long)tn * tm * p.split_k;
-    if (total > 0x7fffffffL) return (int)hipErrorInvalidValue;
+    if (total > 0x7fffffffL) return -1;
   }
-  if (batch.count == 0) return 0;
   for (int i = batch.count; i <= kMaxProblems; ++i) batch.blk_begin[i] = (int)total;
-  static const int forced = getenv("BUTD_GEMM_THREADS") ? atoi(getenv("BUTD_GEMM_THREADS")) : 0;
-  // 8 waves per tile when the grid cannot give every CU two workgroups (the matrix phase of a lone
-  // workgroup is then split over twice the waves); 4 waves for the large grids (measured both ways)
-  const int threads = forced ? forced : (total <= 320 ? 512 : 256);
-  const dim3 grid((unsigned)total);
-  if (fast && threads == 256)
-    hipLaunchKernelGGL((gemm_kernel<256, true>), grid, dim3(256), 0, stream, batch, rng_counter);
-  else if (fast)
-    hipLaunchKernelGGL((gemm_kernel<512, true>), grid, dim3(512), 0, stream, batch, rng_counter);
-  else if (threads == 256)
-    hipLaunchKernelGGL((gemm_kernel<256, false>), grid, dim3(256), 0, stream, batch, rng_counter);
-  else
-    hipLaunchKernelGGL((gemm_kernel<512, false>), grid, dim3(512), 0, stream, batch, rng_counter);
+  return total;
+}
+
+static int launch_group(const butd_gemm_problem *problems, const int *index, int count, bool fast,
+                        const uint64_t *rng_counter, hipStream_t stream) {
+  if (count == 0) return 0;
+  GemmBatch batch;
+  long total = fill_batch(batch, problems, index, count, 64);
+  if (total < 0) return (int)hipErrorInvalidValue;
+  if (total == 0) return 0;
+  // Configuration by grid size (measured with the whole training step, graph replay): 32x32 tiles up to
+  // 10 000 64x64-tiles' worth of work -- four times the workgroups, a quarter of the matrix phase each,
+  // and the phases of co-resident workgroups overlap (a 2048x288x288 product: 13.9 -> 10.1 us, an
+  // 8192-row one 28.7 -> 25.6 us, step 35.7 -> 33.0 ms); 64x64 tiles / 4 waves for the 10^5..10^6-row
+  // set-abstraction products, where the larger tile's operand reuse wins.
+  static const int forced = getenv("BUTD_GEMM_CFG") ? atoi(getenv("BUTD_GEMM_CFG")) : 0;
+  static const long t32 = getenv("BUTD_GEMM_T32") ? atol(getenv("BUTD_GEMM_T32")) : 10000;
+  const int cfg = forced ? forced : (total <= t32 ? 32 : 64);
+  if (cfg == 32) {
+    total = fill_batch(batch, problems, index, count, 32);
+    if (total < 0) return (int)hipErrorInvalidValue;
+    const dim3 grid((unsigned)total);
+    if (fast) hipLaunchKernelGGL((gemm_kernel<256, 32, true>), grid, dim3(256), 0, stream, batch, rng_counter);
+    else hipLaunchKernelGGL((gemm_kernel<256, 32, false>), grid, dim3(256), 0, stream, batch, rng_counter);
+  } else if (cfg == 512) {
+    const dim3 grid((unsigned)total);
+    if (fast) hipLaunchKernelGGL((gemm_kernel<512, 64, true>), grid, dim3(512), 0, stream, batch, rng_counter);
+    else hipLaunchKernelGGL((gemm_kernel<512, 64, false>), grid, dim3(512), 0, stream, batch, rng_counter);
+  } else {
+    const dim3 grid((unsigned)total);
+    if (fast) hipLaunchKernelGGL((gemm_kernel<256, 64, true>), grid, dim3(256), 0, stream, batch, rng_counter);
+    else hipLaunchKernelGGL((gemm_kernel<256, 64, false>), grid, dim3(256), 0, stream, batch, rng_counter);
+  }
   return (int)hipGetLastError();
 }
 
