@@ -212,8 +212,10 @@ class BeaUTyDETR(nn.Module):
         cluster_feature = end_points["query_points_feature"]     # (B, d, Q)
         cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
         query = self.decoder_query_proj(cluster_feature).transpose(1, 2).contiguous()
-        if self.contrastive_align_loss:
-            end_points["proposal_proj_queries"] = self._normalized_proj(query)
+        # contrastive projections of the proposal / per-layer queries (bdetr.py:263-268,300-305): the same
+        # MLP on seven tensors that nothing downstream of the model reads before the loss -- collected
+        # here and projected as ONE stacked batch after the decoder (row-wise op: identical values)
+        proj_inputs = [("proposal_", query)] if self.contrastive_align_loss else []
 
         center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
                                           end_points=end_points, prefix="proposal_")
@@ -233,10 +235,14 @@ class BeaUTyDETR(nn.Module):
                           detected_feats=detected_feats if self.butd else None,
                           detected_mask=detected_mask if self.butd else None)
             if self.contrastive_align_loss:
-                end_points[f"{prefix}proj_queries"] = self._normalized_proj(query)
+                proj_inputs.append((prefix, query))
             center, size = head(query.transpose(1, 2), base_xyz=cluster_xyz,
                                 end_points=end_points, prefix=prefix, features_pm=query)
             base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        if proj_inputs:
+            proj = self._normalized_proj(torch.stack([q for _, q in proj_inputs]))
+            for i, (prefix, _) in enumerate(proj_inputs):
+                end_points[f"{prefix}proj_queries"] = proj[i]
         return end_points
 
     def init_bn_momentum(self):
