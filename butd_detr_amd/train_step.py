@@ -48,17 +48,21 @@ def surrogate_loss(end_points, targets, prefixes=None):
     valid = ~end_points["text_attention_mask"]                        # (B, L) True = real token
     loss = F.binary_cross_entropy_with_logits(
         end_points["seeds_obj_cls_logits"].squeeze(1), targets["seed_label"])
-    for p in prefixes:
-        center, size = end_points[f"{p}center"], end_points[f"{p}pred_size"]
-        loss = loss + F.smooth_l1_loss(center, targets["gt_center"].expand_as(center))
-        loss = loss + F.smooth_l1_loss(size, targets["gt_size"].expand_as(size))
-        logits = end_points[f"{p}sem_cls_scores"]                      # (B, Q, 256)
-        tgt = targets["gt_token"][:, None].expand(-1, logits.shape[1])
-        loss = loss + F.cross_entropy(logits.flatten(0, 1), tgt.flatten())
-        pq = end_points[f"{p}proj_queries"]                            # (B, Q, 64)
-        sim = torch.matmul(pq, tok.transpose(1, 2)) / 0.07             # (B, Q, L)
-        sim = sim.masked_fill(~valid[:, None, :], -1e4)
-        loss = loss + F.cross_entropy(sim.flatten(0, 1), tgt.flatten())
+    # the same four terms for every prefix: evaluated once on the stacked (P, B, Q, .) outputs
+    # (sum over prefixes of per-prefix means = one sum-reduction divided by the per-prefix count)
+    stack = lambda key: torch.stack([end_points[f"{p}{key}"] for p in prefixes])
+    center, size = stack("center"), stack("pred_size")
+    per_prefix = center[0].numel()
+    loss = loss + F.smooth_l1_loss(center, targets["gt_center"].expand_as(center), reduction="sum") / per_prefix
+    loss = loss + F.smooth_l1_loss(size, targets["gt_size"].expand_as(size), reduction="sum") / per_prefix
+    logits = stack("sem_cls_scores")                                  # (P, B, Q, 256)
+    n_p, n_b, n_q = logits.shape[:3]
+    tgt = targets["gt_token"][None, :, None].expand(n_p, -1, n_q).flatten()
+    loss = loss + F.cross_entropy(logits.flatten(0, 2), tgt, reduction="sum") / (n_b * n_q)
+    pq = stack("proj_queries")                                        # (P, B, Q, 64)
+    sim = torch.matmul(pq, tok.transpose(1, 2)) / 0.07                # (P, B, Q, L)
+    sim = sim.masked_fill(~valid[None, :, None, :], -1e4)
+    loss = loss + F.cross_entropy(sim.flatten(0, 2), tgt, reduction="sum") / (n_b * n_q)
     return loss
 
 
