@@ -72,7 +72,8 @@ def build_model(args, device):
 def gemm_roofline(step_fn):
     """Dominant hand-written kernel of the step: ``gemm_kernel`` (fp32 MFMA grouped GEMM: every
     projection / FFN / 1x1-conv product of the attention stack and of the set-abstraction MLPs and all
-    their gradient products; ~30 % of the GPU time of a step, rocprof profiles/).  One EAGER training step
+    their gradient products, the Conv1d chains of the heads; ~35 % of the GPU time of a step, rocprof
+    profiles/).  One EAGER training step
     is replayed with a HIP-event pair around every launch on the launch stream; algorithmic FLOPs =
     sum over the problems of a launch of 2*M*N*K, achieved = sum FLOPs / sum duration."""
     from butd_detr_amd import fused_attention as fa
@@ -88,14 +89,17 @@ def gemm_roofline(step_fn):
         records.append((sum(2.0 * p.M * p.N * p.K for p in problems), e0, e1))
 
     fa._gemm = timed
+    import butd_detr_amd.fused_mlp as fmlp
     import butd_detr_amd.fused_sa as fsa
     fsa._gemm = timed
+    fmlp._gemm = timed
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         fa._gemm = orig
         fsa._gemm = orig
+        fmlp._gemm = orig
     flops = sum(r[0] for r in records)
     ms = sum(r[1].elapsed_time(r[2]) for r in records)
     achieved = flops / (ms * 1e-3) / 1e12
@@ -249,7 +253,7 @@ def main():
                                    f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "
                                    "3 encoder + 6 decoder layers, fwd+loss+bwd+clip+AdamW, train mode",
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "attention_backend": backend, "launch": "eager+DDP+torch AdamW" if args.eager else "hipGraph replay + flat-gradient all-reduce + flat AdamW", "final_loss": round(float(loss), 4)},
+                       "attention_backend": backend, "launch": "eager+DDP+torch AdamW" if args.eager else "hipGraph replay (FPS chain of the next batch prefetched on a forked stream) + flat-gradient all-reduce + packed AdamW", "final_loss": round(float(loss), 4)},
         }
         if backend == "hip":
             out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, targets))
