@@ -102,15 +102,24 @@ class CrossAttentionLayer(nn.Module):
     def forward(self, vis_feats, vis_key_padding_mask, text_feats, text_key_padding_mask,
                 pos_feats, detected_feats=None, detected_mask=None):
         """vis/pos (B,V,d), text (B,L,d), boxes (B,D,d); masks True = padding."""
-        vis_query = vis_feats + pos_feats  # positional features only on the query (:79-80)
-        text_in = text_feats               # keys/values of cross_vl are the layer INPUT (:83,:101-102)
-        # language attends to vision, then its FFN
+        # the two branches only READ each other's layer input (:83,:101-102), so they are independent
+        text_out = self.language_branch(text_feats, vis_feats, vis_key_padding_mask)
+        vis_out = self.vision_branch(vis_feats, text_feats, text_key_padding_mask, pos_feats,
+                                     detected_feats, detected_mask)
+        return vis_out, text_out
+
+    def language_branch(self, text_feats, vis_feats, vis_key_padding_mask):
+        """language attends to vision, then its FFN"""
         text_feats = ab.attention_block(self.cross_lv, self.dropout_lv, self.norm_lv,
                                         residual=text_feats, query=text_feats,
                                         key=vis_feats, value=vis_feats,
                                         key_padding_mask=vis_key_padding_mask)
-        text_feats = ab.ffn_block(self.ffn_lv, self.norm_lv2, text_feats)
-        # vision attends to language
+        return ab.ffn_block(self.ffn_lv, self.norm_lv2, text_feats)
+
+    def vision_branch(self, vis_feats, text_in, text_key_padding_mask, pos_feats,
+                      detected_feats=None, detected_mask=None):
+        """vision attends to language (keys/values = the layer INPUT text), [to the boxes], FFN"""
+        vis_query = vis_feats + pos_feats  # positional features only on the query (:79-80)
         vis_feats = ab.attention_block(self.cross_vl, self.dropout_vl, self.norm_vl,
                                        residual=vis_feats, query=vis_query,
                                        key=text_in, value=text_in,
@@ -120,8 +129,7 @@ class CrossAttentionLayer(nn.Module):
                                            residual=vis_feats, query=vis_feats,
                                            key=detected_feats, value=detected_feats,
                                            key_padding_mask=detected_mask)
-        vis_feats = ab.ffn_block(self.ffn_vl, self.norm_vl2, vis_feats)
-        return vis_feats, text_feats
+        return ab.ffn_block(self.ffn_vl, self.norm_vl2, vis_feats)
 
 
 class TransformerEncoderLayerNoFFN(nn.Module):
