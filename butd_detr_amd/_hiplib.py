@@ -49,13 +49,15 @@ class GemmProblem(ctypes.Structure):
                 ("b_chan_scale", _c_void_p), ("b_chan_shift", _c_void_p),
                 ("a_drop_p", _c_float), ("a_drop_site", _c_u32),
                 ("b_drop_p", _c_float), ("b_drop_site", _c_u32),
-                ("col_sum", _c_void_p), ("col_sumsq", _c_void_p)]
+                ("col_sum", _c_void_p), ("col_sumsq", _c_void_p),
+                ("c_add", _c_int), ("c2", _c_void_p)]
 
 
 ATTENTION_SYMBOLS = {
     "butd_gemm_grouped": (_c_int, [ctypes.POINTER(GemmProblem), _c_int, _c_void_p, _c_void_p]),
     "butd_attention_fwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
-    "butd_attention_bwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+    "butd_attention_bwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
+                           + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_fwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 3
                                        + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_bwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 10

@@ -87,6 +87,20 @@ def attention_block(attn, dropout, norm, *, residual, query, key, value, key_pad
     return norm(residual + dropout(out))
 
 
+def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None):
+    """The block in the two shapes the model uses it (every call site of
+    encoder_decoder_layers.py:87-122,149-155,179-185,356-404):
+        memory is None:  self-attention,  query = key = x (+ pos), value = x
+        otherwise:       cross-attention, query = x (+ pos), key = value = memory
+    with residual x.  Knowing the structure lets the fused backward return summed gradients."""
+    if _BACKEND == "hip" and x.is_cuda:
+        from . import fused_attention
+        return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask)
+    q = x if pos is None else x + pos
+    k, v = (q, x) if memory is None else (memory, memory)
+    return norm(x + dropout(_mha_torch(attn, q, k, v, key_padding_mask)))
+
+
 def ffn_block(ffn, norm, x):
     """LayerNorm(x + FFN(x)); ffn = Sequential(Linear, ReLU, Dropout, Linear, Dropout)."""
     if _BACKEND == "hip" and x.is_cuda:

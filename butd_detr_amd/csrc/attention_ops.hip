@@ -527,6 +527,9 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
     }
     const bool vec_ok = (n + 3 < pN) && ((ldc & 3) == 0) && ((((uintptr_t)cptr) & 15) == 0);
     double *const col_sum = P.col_sum, *const col_sumsq = P.col_sumsq;
+    const bool c_add = P.c_add != 0;
+    float *const c2ptr = P.c2;
+    const bool vec2_ok = vec_ok && ((((uintptr_t)c2ptr) & 15) == 0);
     float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int qq = 0; qq < kBM / kRowPhases; ++qq) {
@@ -547,12 +550,27 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
         }
       }
       float *dst = cptr + (long)m * ldc + n;
+      if (c2ptr) {   // second destination accumulates the same values
+        float *d2 = c2ptr + (long)m * ldc + n;
+        if (vec2_ok) {
+          const float4 o = *reinterpret_cast<const float4 *>(d2);
+          *reinterpret_cast<float4 *>(d2) = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < pN) d2[e] += v[e];
+        }
+      }
       if (vec_ok) {
+        if (c_add) {
+          const float4 o = *reinterpret_cast<const float4 *>(dst);
+          v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+        }
         *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (n + e < pN) dst[e] = v[e];
+          if (n + e < pN) dst[e] = c_add ? dst[e] + v[e] : v[e];
       }
     }
     if (col_sum) {
@@ -768,6 +786,8 @@ static bool fast_eligible(const butd_gemm_problem &p) {
   const bool a_kc = p.lda_k == 1, b_kc = p.ldb_k == 1;
   const int kslab = (p.K + kBK - 1) / kBK, split = p.split_k < 1 ? 1 : p.split_k;
   const long per = (long)((kslab + split - 1) / split) * kBK;   // contraction range of one slice
+  // (a companion operand a2 stays on the generic kernel: its extra register set cost the fast
+  // instantiations a wave of occupancy, measured)
   return p.a2 == nullptr && p.K > 0 && (p.K & 3) == 0 &&   // a ragged LAST slab is predicated per float4
          (a_kc || (p.M & 3) == 0) && (b_kc || (p.N & 3) == 0) &&   // partial tiles: whole float4 in or out
          ((a_kc ? p.lda_m : p.lda_k) & 3) == 0 && ((b_kc ? p.ldb_n : p.ldb_k) & 3) == 0 &&
@@ -838,7 +858,8 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
     const butd_gemm_problem &p = problems[i];
     if (p.M <= 0 || p.N <= 0) continue;
     if (p.split_k > 1 && !p.accumulate) return (int)hipErrorInvalidValue;
-    if ((p.col_sum != nullptr) && (p.accumulate || p.split_k > 1)) return (int)hipErrorInvalidValue;
+    if ((p.col_sum != nullptr || p.c_add || p.c2 != nullptr) && (p.accumulate || p.ones_col || p.split_k > 1))
+      return (int)hipErrorInvalidValue;
     if (fast_eligible(p)) fast_idx[nf++] = i; else slow_idx[ns++] = i;
   }
   int err = launch_group(problems, fast_idx, nf, true, rng_counter, (hipStream_t)stream);
@@ -1145,7 +1166,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
-    float *__restrict__ dq,
+    float *__restrict__ dq, long ldo, float dq_scale,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
   __shared__ __attribute__((aligned(16))) float Kimg[2][64][I::LD];
@@ -1260,13 +1281,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
     cur ^= 1;
   }
   if (live && qi < Lq) {
-    float *ob = dq + ((long)b * Lq + qi) * E + h * D;
+    float *ob = dq + ((long)b * Lq + qi) * ldo + h * D;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int d = nt * 16 + fg * 4 + i;
-        if (d < D) ob[d] = acc[nt][i];
+        if (d < D) ob[d] = acc[nt][i] * dq_scale;
       }
   }
 }
@@ -1280,7 +1301,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ dout,
     const float *__restrict__ lse, const float *__restrict__ delta, float *__restrict__ dk,
-    float *__restrict__ dv, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+    float *__restrict__ dv, long ldo, float p_drop, uint32_t site,
+    const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
   __shared__ __attribute__((aligned(16))) float Qimg[2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float Gimg[2][64][I::LD];
@@ -1398,8 +1420,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(
     cur ^= 1;
   }
   if (live && ki < Lk) {
-    float *okp = dk + ((long)b * Lk + ki) * E + h * D;
-    float *ovp = dv + ((long)b * Lk + ki) * E + h * D;
+    float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
+    float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1441,16 +1463,19 @@ int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
 int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
                        const float *v, const uint8_t *key_padding_mask, const float *out,
                        const float *dout, const float *lse, float *delta, float *dq, float *dk,
-                       float *dv, float dropout_p, uint32_t dropout_site,
-                       const uint64_t *rng_counter, butd_stream_t stream) {
+                       float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                       uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream) {
   if (B <= 0 || H <= 0 || Lq <= 0) return 0;
   if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
+  if (ld_dq == 0) ld_dq = (long)H * D;
+  if (ld_dkv == 0) ld_dkv = (long)H * D;
+  if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
   ATTN_DISPATCH(attn_bwd_dq_kernel, gq, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq,
-                dropout_p, dropout_site, rng_counter);
+                ld_dq, dq_scale, dropout_p, dropout_site, rng_counter);
   ATTN_DISPATCH(attn_bwd_dkv_kernel, gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
-                dk, dv, dropout_p, dropout_site, rng_counter);
+                dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter);
   return (int)hipGetLastError();
 }
 

@@ -110,25 +110,19 @@ class CrossAttentionLayer(nn.Module):
 
     def language_branch(self, text_feats, vis_feats, vis_key_padding_mask):
         """language attends to vision, then its FFN"""
-        text_feats = ab.attention_block(self.cross_lv, self.dropout_lv, self.norm_lv,
-                                        residual=text_feats, query=text_feats,
-                                        key=vis_feats, value=vis_feats,
-                                        key_padding_mask=vis_key_padding_mask)
+        text_feats = ab.block(self.cross_lv, self.dropout_lv, self.norm_lv, x=text_feats,
+                              memory=vis_feats, key_padding_mask=vis_key_padding_mask)
         return ab.ffn_block(self.ffn_lv, self.norm_lv2, text_feats)
 
     def vision_branch(self, vis_feats, text_in, text_key_padding_mask, pos_feats,
                       detected_feats=None, detected_mask=None):
         """vision attends to language (keys/values = the layer INPUT text), [to the boxes], FFN"""
-        vis_query = vis_feats + pos_feats  # positional features only on the query (:79-80)
-        vis_feats = ab.attention_block(self.cross_vl, self.dropout_vl, self.norm_vl,
-                                       residual=vis_feats, query=vis_query,
-                                       key=text_in, value=text_in,
-                                       key_padding_mask=text_key_padding_mask)
+        # positional features only on the query (:79-80)
+        vis_feats = ab.block(self.cross_vl, self.dropout_vl, self.norm_vl, x=vis_feats, pos=pos_feats,
+                             memory=text_in, key_padding_mask=text_key_padding_mask)
         if detected_feats is not None and self.use_butd_enc_attn:
-            vis_feats = ab.attention_block(self.cross_d, self.dropout_d, self.norm_d,
-                                           residual=vis_feats, query=vis_feats,
-                                           key=detected_feats, value=detected_feats,
-                                           key_padding_mask=detected_mask)
+            vis_feats = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=vis_feats,
+                                 memory=detected_feats, key_padding_mask=detected_mask)
         return ab.ffn_block(self.ffn_vl, self.norm_vl2, vis_feats)
 
 
@@ -143,9 +137,8 @@ class TransformerEncoderLayerNoFFN(nn.Module):
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
         assert src_mask is None, "attn_mask is never used on this path"
-        return ab.attention_block(self.self_attn, self.dropout1, self.norm1, residual=src,
-                                  query=src, key=src, value=src,
-                                  key_padding_mask=src_key_padding_mask)
+        return ab.block(self.self_attn, self.dropout1, self.norm1, x=src,
+                        key_padding_mask=src_key_padding_mask)
 
 
 class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
@@ -153,10 +146,8 @@ class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
 
     def forward(self, src, pos, src_mask=None, src_key_padding_mask=None):
         assert src_mask is None, "attn_mask is never used on this path"
-        qk = src + pos
-        return ab.attention_block(self.self_attn, self.dropout1, self.norm1, residual=src,
-                                  query=qk, key=qk, value=src,
-                                  key_padding_mask=src_key_padding_mask)
+        return ab.block(self.self_attn, self.dropout1, self.norm1, x=src, pos=pos,
+                        key_padding_mask=src_key_padding_mask)
 
 
 class BiEncoderLayer(nn.Module):
@@ -244,20 +235,16 @@ class BiDecoderLayer(nn.Module):
         if self.self_posembed is not None:
             query_pos = self.self_posembed(query_pos).transpose(1, 2).contiguous()
         else:
-            query_pos = torch.zeros_like(query)
+            query_pos = None       # the reference adds zeros_like(query) (:364-365)
 
-        qk = query + query_pos
-        query = ab.attention_block(self.self_attn, self.dropout1, self.norm1, residual=query,
-                                   query=qk, key=qk, value=query, key_padding_mask=padding_mask)
-        query = ab.attention_block(self.cross_l, self.dropout_l, self.norm_l, residual=query,
-                                   query=query + query_pos, key=lang_feats, value=lang_feats,
-                                   key_padding_mask=text_key_padding_mask)
+        query = ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=query_pos,
+                         key_padding_mask=padding_mask)
+        query = ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=query_pos,
+                         memory=lang_feats, key_padding_mask=text_key_padding_mask)
         if detected_feats is not None:
-            query = ab.attention_block(self.cross_d, self.dropout_d, self.norm_d, residual=query,
-                                       query=query + query_pos, key=detected_feats,
-                                       value=detected_feats, key_padding_mask=detected_mask)
-        query = ab.attention_block(self.cross_v, self.dropout_v, self.norm_v, residual=query,
-                                   query=query + query_pos, key=vis_feats, value=vis_feats,
-                                   key_padding_mask=None)
+            query = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=query_pos,
+                             memory=detected_feats, key_padding_mask=detected_mask)
+        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=query_pos,
+                         memory=vis_feats, key_padding_mask=None)
         query = ab.ffn_block(self.ffn, self.norm2, query)
         return query.contiguous()

@@ -116,7 +116,7 @@ def _ptr(t):
 def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.0, bias=None,
              bias_grad=None, scale=1.0, relu=False, accumulate=False, ones_col=False, split_k=1,
              dropout_p=0.0, site=0, a_affine=None, b_affine=None, a_drop=(0.0, 0), b_drop=(0.0, 0),
-             col_stats=None):
+             col_stats=None, c_add=False, c2=None):
     asc, ash = a_affine if a_affine is not None else (None, None)
     bsc, bsh = b_affine if b_affine is not None else (None, None)
     return GemmProblem(_ptr(a), _ptr(a2), _ptr(b), _ptr(bias), _ptr(c), _ptr(bias_grad), M, N, K,
@@ -125,7 +125,8 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                        _ptr(asc), _ptr(ash), _ptr(bsc), _ptr(bsh),
                        float(a_drop[0]), int(a_drop[1]), float(b_drop[0]), int(b_drop[1]),
                        _ptr(col_stats[0]) if col_stats is not None else None,
-                       _ptr(col_stats[1]) if col_stats is not None else None)
+                       _ptr(col_stats[1]) if col_stats is not None else None,
+                       int(c_add), _ptr(c2))
 
 
 def _gemm(problems, ref):
@@ -241,7 +242,8 @@ class _AttentionBlock(torch.autograd.Function):
             err = _lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                           _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
                                           delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                          p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(xq))
+                                          0, 0, 1.0, p_attn, site_attn, rng_counter(dev).data_ptr(),
+                                          _stream(xq))
         _hiplib.check(err, "butd_attention_bwd")
         scale = math.sqrt(1.0 / float(D))
         d_xq = torch.empty((B, Lq, E), device=dev)
@@ -350,3 +352,160 @@ def multi_head_attention(attn, query, key, value, key_padding_mask=None):
     """Bare MHA (no residual / norm) -- not on the model's path; routed through the torch maths."""
     from . import attention_blocks
     return attention_blocks._mha_torch(attn, query, key, value, key_padding_mask)
+
+
+# -------------------------------------------------------------------------------------------------
+# The block as the model uses it: every call site of the encoder / decoder layers
+# (encoder_decoder_layers.py:87-122,149-155,179-185,356-404) is one of
+#     self-attention :  query = key = x (+ pos),  value = x,        residual = x
+#     cross-attention:  query = x (+ pos),        key = value = memory, residual = x
+# Told that structure, the backward returns the SUMMED gradients of x / pos / memory itself: the
+# gradients of the attention core are written side by side (dq|dk|dv or dk|dv) so the input-projection
+# gradients are single products over the concatenated contraction, and the residual-path gradient is
+# accumulated by the GEMM epilogue (c_add / c2) -- autograd used to launch 2-4 tensor adds per block.
+# -------------------------------------------------------------------------------------------------
+def _xwgrad(dy, ldy, x, dw, db, M, N, K):
+    """dw[N,K] += dy[M,N]^T @ x[M,K] (dy rows ldy floats apart), db[N] += column sums of dy."""
+    split = max(1, min(256, M // 512)) if M >= 16384 else min(32, max(M // 256, min(8, M // 64), 1))
+    return _problem(dy, x, dw, N, K, M, (1, ldy), (1, K), K, bias_grad=db, ones_col=True,
+                    accumulate=True, split_k=split)
+
+
+class _XpmBlock(torch.autograd.Function):
+    """LayerNorm(x + Dropout(MHA(x + pos, key, value))) with (key, value) = (x + pos, x) when
+    ``mem is None`` and (mem, mem) otherwise."""
+
+    @staticmethod
+    def forward(ctx, x, pos, mem, mask, w_in, b_in, w_o, b_o, gamma, beta,
+                num_heads, eps, p_attn, p_out, site_attn, site_out):
+        B, Lq, E = x.shape
+        H, D = num_heads, E // num_heads
+        dev = x.device
+        self_attn = mem is None
+        xq = x if pos is None else x + pos
+        xk, xv = (xq, x) if self_attn else (mem, mem)
+        Lk = xk.shape[1]
+        Mq, Mk = B * Lq, B * Lk
+        q = torch.empty((B, Lq, E), device=dev)
+        k = torch.empty((B, Lk, E), device=dev)
+        v = torch.empty((B, Lk, E), device=dev)
+        scale = math.sqrt(1.0 / float(D))
+        _gemm([_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale),
+               _fwd(xk, w_in[E:2 * E], k, Mk, E, E, bias=b_in[E:2 * E]),
+               _fwd(xv, w_in[2 * E:], v, Mk, E, E, bias=b_in[2 * E:])], x)
+        att = torch.empty((B, Lq, E), device=dev)
+        lse = torch.empty((B, H, Lq), device=dev)
+        with torch.cuda.device(dev):
+            err = _lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                          _ptr(mask), att.data_ptr(), lse.data_ptr(), p_attn, site_attn,
+                                          rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_attention_fwd")
+        proj = torch.empty((B, Lq, E), device=dev)
+        _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
+        y = torch.empty((B, Lq, E), device=dev)
+        mean = torch.empty((Mq,), device=dev)
+        rstd = torch.empty((Mq,), device=dev)
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_fwd(
+                Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
+                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
+                rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
+        ctx.save_for_backward(x, xq if pos is not None else None, mem, mask, w_in, w_o, gamma, q, k, v,
+                              att, lse, proj, mean, rstd)
+        ctx.cfg = (H, p_attn, p_out, site_attn, site_out)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, xq_saved, mem, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean, rstd = ctx.saved_tensors
+        H, p_attn, p_out, site_attn, site_out = ctx.cfg
+        has_pos = xq_saved is not None
+        xq = xq_saved if has_pos else x
+        self_attn = mem is None
+        B, Lq, E = x.shape
+        Lk = Lq if self_attn else mem.shape[1]
+        D = E // H
+        Mq, Mk = B * Lq, B * Lk
+        dev = x.device
+        dy = dy.contiguous()
+        slab = zeros(3 * E * E + 3 * E + E * E + E + 2 * E, device=dev)
+        o = 0
+        d_w_in = slab[o:o + 3 * E * E].view(3 * E, E); o += 3 * E * E
+        d_b_in = slab[o:o + 3 * E]; o += 3 * E
+        d_w_o = slab[o:o + E * E].view(E, E); o += E * E
+        d_b_o = slab[o:o + E]; o += E
+        d_gamma = slab[o:o + E]; o += E
+        d_beta = slab[o:o + E]
+        R = torch.empty((B, Lq, E), device=dev)              # d(residual path) -> total gradient of x
+        d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else R
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_bwd(
+                Mq, E, dy.data_ptr(), proj.data_ptr(), x.data_ptr(), gamma.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr(), d_proj.data_ptr(), R.data_ptr(),
+                d_gamma.data_ptr(), d_beta.data_ptr(), p_out, site_out, rng_counter(dev).data_ptr(),
+                _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        d_att = torch.empty((B, Lq, E), device=dev)
+        _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
+               _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], x)
+        # gradients of the attention core, packed: self: G = [dq | dk | dv]; cross: dq, G = [dk | dv]
+        if self_attn:
+            G = torch.empty((B, Lq, 3 * E), device=dev)
+            ldg = 3 * E
+            dq_ptr, dk_ptr, dv_ptr = G.data_ptr(), G.data_ptr() + 4 * E, G.data_ptr() + 8 * E
+            ld_dq = ldg
+        else:
+            dq = torch.empty((B, Lq, E), device=dev)
+            G = torch.empty((B, Lk, 2 * E), device=dev)
+            ldg = 2 * E
+            dq_ptr, dk_ptr, dv_ptr = dq.data_ptr(), G.data_ptr(), G.data_ptr() + 4 * E
+            ld_dq = E
+        delta = torch.empty((B, H, Lq), device=dev)
+        scale = math.sqrt(1.0 / float(D))
+        with torch.cuda.device(dev):
+            err = _lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                          _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
+                                          delta.data_ptr(), dq_ptr, dk_ptr, dv_ptr, ld_dq, ldg, scale,
+                                          p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_attention_bwd")
+        d_pos = d_mem = None
+        if self_attn and has_pos:
+            # d_pos = [dq|dk] W_in[:2E]  (also added into R);  R += dv Wv in a second launch (same target)
+            d_pos = torch.empty((B, Lq, E), device=dev)
+            _gemm([_problem(G, w_in, d_pos, Mq, E, 2 * E, (ldg, 1), (1, E), E, c2=R),
+                   _xwgrad(G, ldg, xq, d_w_in[:2 * E], d_b_in[:2 * E], Mq, 2 * E, E)], x)
+            Gv = G[:, :, 2 * E:]
+            _gemm([_problem(Gv, w_in[2 * E:], R, Mq, E, E, (ldg, 1), (1, E), E, c_add=True),
+                   _xwgrad(Gv, ldg, x, d_w_in[2 * E:], d_b_in[2 * E:], Mq, E, E)], x)
+        elif self_attn:
+            _gemm([_problem(G, w_in, R, Mq, E, 3 * E, (ldg, 1), (1, E), E, c_add=True),
+                   _xwgrad(G, ldg, x, d_w_in, d_b_in, Mq, 3 * E, E)], x)
+        else:
+            d_mem = torch.empty((B, Lk, E), device=dev)
+            if has_pos:
+                d_pos = torch.empty((B, Lq, E), device=dev)
+                qprob = _problem(dq, w_in, d_pos, Mq, E, E, (E, 1), (1, E), E, c2=R)
+            else:
+                qprob = _problem(dq, w_in, R, Mq, E, E, (E, 1), (1, E), E, c_add=True)
+            _gemm([qprob,
+                   _problem(G, w_in[E:], d_mem, Mk, E, 2 * E, (ldg, 1), (1, E), E),
+                   _xwgrad(dq, E, xq, d_w_in[:E], d_b_in[:E], Mq, E, E),
+                   _xwgrad(G, ldg, mem, d_w_in[E:], d_b_in[E:], Mk, 2 * E, E)], x)
+        return (R, d_pos, d_mem, None, d_w_in, d_b_in, d_w_o, d_b_o, d_gamma, d_beta,
+                None, None, None, None, None, None)
+
+
+def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None):
+    """LayerNorm(x + Dropout(MHA(x + pos, k, v))), (k, v) = (x + pos, x) or (memory, memory)."""
+    training = attn.training
+    p_attn = float(attn.dropout) if training else 0.0
+    p_out = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
+    x = x.contiguous()
+    pos = None if pos is None else pos.contiguous()
+    memory = None if memory is None else memory.contiguous()
+    _check(x, pos, memory)
+    return _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
+                           attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
+                           norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
+                           _next_site(), _next_site())

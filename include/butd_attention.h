@@ -58,6 +58,14 @@ typedef struct {
    * split_k == 1): col_sum[n] += sum_m C[m,n], col_sumsq[n] += sum_m C[m,n]^2 in double (atomics, the
    * caller zero-fills) -- the BatchNorm batch statistics of a 1x1 convolution, in the same pass. */
   double *col_sum, *col_sumsq;
+  /* Optional accumulation into existing data by the plain-store epilogue (accumulate == 0,
+   * split_k == 1; every element has exactly one writer, so no atomics):
+   *   c_add != 0:  C <- C + epilogue(v)            (e.g. the residual-path gradient already in C)
+   *   c2 != NULL:  C2 <- C2 + epilogue(v) as well   (same ldc; a second consumer of the same product)
+   * They let a block return  d_res + dq*Wq  and  dq*Wq  from ONE product instead of autograd adding
+   * tensors afterwards.  No other problem of the same launch may write C (c_add) or C2. */
+  int c_add;
+  float *c2;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).
@@ -75,12 +83,16 @@ int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
                        float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
                        butd_stream_t stream);
 
-/* Backward of the above.  delta (B,H,Lq) scratch; dq (B,Lq,H*D), dk, dv (B,Lk,H*D) are overwritten. */
+/* Backward of the above.  delta (B,H,Lq) scratch (written here); dq (B,Lq,.), dk, dv (B,Lk,.) are
+ * overwritten.  The gradient rows may be wider than H*D: ld_dq / ld_dkv are their row strides in floats
+ * (0 = H*D), so dq|dk|dv (or dk|dv) can sit side by side in one matrix and the input-projection
+ * gradients become ONE product over the concatenated contraction.  dq is multiplied by dq_scale on the
+ * way out (the 1/sqrt(D) the forward projection applied to q). */
 int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
                        const float *v, const uint8_t *key_padding_mask, const float *out,
                        const float *dout, const float *lse, float *delta, float *dq, float *dk,
-                       float *dv, float dropout_p, uint32_t dropout_site,
-                       const uint64_t *rng_counter, butd_stream_t stream);
+                       float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                       uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
 
 /* y = LayerNorm(residual + dropout(x)) over the last dim (cols <= 1024), eps as nn.LayerNorm.
  * Saves mean/rstd (rows) for backward. */

@@ -65,6 +65,57 @@ def test_attention_block_matches_torch(mods, B, Lq, Lk, masked):
         _close(gh, gr, 2e-3)
 
 
+@pytest.mark.parametrize("pattern", ["self_pos", "self", "cross_pos", "cross"])
+@pytest.mark.parametrize("B,Lq,Lk,masked", [(2, 64, 64, False), (3, 256, 132, True), (2, 80, 1024, False),
+                                            (1, 17, 5, True)])
+def test_structured_block_matches_torch(mods, pattern, B, Lq, Lk, masked):
+    """attention_blocks.block (x, pos, memory): the fused backward returns SUMMED gradients (packed
+    dq|dk|dv, c_add / c2 epilogues); they must equal what autograd accumulates for the torch maths."""
+    ab, fa, MHA, _ = mods
+    torch.manual_seed(Lq * 7 + Lk)
+    E, H = 288, 8
+    is_self = pattern.startswith("self")
+    if is_self:
+        Lk = Lq
+    attn = MHA(E, H, dropout=0.1).cuda().eval()
+    norm = torch.nn.LayerNorm(E).cuda()
+    with torch.no_grad():
+        attn.in_proj_bias.uniform_(-0.1, 0.1)
+        attn.out_proj.bias.uniform_(-0.1, 0.1)
+        norm.weight.uniform_(0.8, 1.2)
+        norm.bias.uniform_(-0.1, 0.1)
+    drop = torch.nn.Dropout(0.1).eval()
+    x = torch.randn(B, Lq, E, device="cuda", requires_grad=True)
+    pos = torch.randn(B, Lq, E, device="cuda", requires_grad=True) if pattern.endswith("pos") else None
+    mem = None if is_self else torch.randn(B, Lk, E, device="cuda", requires_grad=True)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+        for b in range(B):
+            mask[b, Lk - 1 - b:] = True
+    probe = torch.randn(B, Lq, E, device="cuda")
+    leaves = [t for t in (x, pos, mem) if t is not None]
+    params = list(attn.parameters()) + list(norm.parameters())
+
+    def run(backend):
+        ab.set_backend(backend)
+        for t in leaves + params:
+            t.grad = None
+        # consume x twice more outside the block, as the layers do (other gradient contributions)
+        y = ab.block(attn, drop, norm, x=x, pos=pos, memory=mem, key_padding_mask=mask)
+        ((y * probe).sum() + (x * x).sum() * 0.01).backward()
+        return y, [t.grad.clone() for t in leaves + params]
+
+    try:
+        y_ref, g_ref = run("torch")
+        y_hip, g_hip = run("hip")
+    finally:
+        ab.set_backend("torch")
+    _close(y_hip, y_ref)
+    for gh, gr in zip(g_hip, g_ref):
+        _close(gh, gr, 2e-3)
+
+
 def test_fully_masked_row_is_nan_like_torch(mods):
     ab, fa, MHA, _ = mods
     attn = MHA(288, 8, dropout=0.0).cuda().eval()
