@@ -109,7 +109,7 @@ class BeaUTyDETR(nn.Module):
             self.contrastive_align_projection_image = _align_mlp(d_model)
             self.contrastive_align_projection_text = _align_mlp(d_model)
 
-        self.overlap_text_tower = True
+        self.overlap_text_tower = os.environ.get("BUTD_TEXT_OVERLAP", "1") != "0"   # env: debug hook
         self._side_stream = None
         self.init_bn_momentum()
 

@@ -9,6 +9,8 @@ box L1, size L1, soft-token cross-entropy, query/token contrastive logits, seed 
 ``find_unused_parameters``), followed by the same clip + AdamW update.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
