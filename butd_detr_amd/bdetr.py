@@ -121,9 +121,20 @@ class BeaUTyDETR(nn.Module):
             inputs["text"], padding="longest", return_tensors="pt"
         ).to(inputs["point_clouds"].device)
 
-    def _run_text_tower(self, tokenized, end_points):
-        encoded_text = self.text_encoder(**tokenized)
-        end_points["text_feats"] = self.text_projector(encoded_text.last_hidden_state)
+    @torch.no_grad()
+    def encode_text(self, tokenized):
+        """The FROZEN language model on its own (bdetr.py:80-83 freezes every RoBERTa parameter): its
+        output depends on the tokens only, so a training loop may run it for the next batch while the
+        current one trains and hand the result in as ``inputs["text_encoder_output"]``."""
+        return self.text_encoder(**tokenized).last_hidden_state
+
+    def text_encoder_is_frozen(self):
+        return not any(p.requires_grad for p in self.text_encoder.parameters())
+
+    def _run_text_tower(self, tokenized, end_points, hidden=None):
+        if hidden is None:
+            hidden = self.text_encoder(**tokenized).last_hidden_state
+        end_points["text_feats"] = self.text_projector(hidden)
         # HF masks are 1 = token; torch attention wants True = padding (bdetr.py:171)
         end_points["text_attention_mask"] = tokenized.attention_mask.ne(1).bool()
         end_points["tokenized"] = tokenized
@@ -136,7 +147,11 @@ class BeaUTyDETR(nn.Module):
             tokenized = self.tokenize(inputs)
         pc = inputs["point_clouds"]
         text_out = {}
-        if pc.is_cuda and self.overlap_text_tower:
+        hidden = inputs.get("text_encoder_output")
+        if hidden is not None:          # language model already run (prefetched): projector only
+            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
+            self._run_text_tower(tokenized, text_out, hidden)
+        elif pc.is_cuda and self.overlap_text_tower:
             main = torch.cuda.current_stream(pc.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(pc.device)

@@ -230,7 +230,9 @@ class GraphedTrainStep:
     batch on a forked stream while the current batch trains on the other 248 CUs, exactly as a data
     loader prefetches: ``step(inputs_k, targets_k, next_inputs=inputs_k+1)``.  Every replay still runs
     one sampling chain and one model pass; a call whose inputs were not announced by the previous call
-    falls back to sampling them on the spot.
+    falls back to sampling them on the spot.  ``prefetch_text`` does the same with the FROZEN language
+    model (its output depends on the tokens only): batch k+1's RoBERTa pass runs on a forked stream during
+    batch k instead of in front of batch k+1's encoder; ignored when the text encoder is trainable.
 
     Eager PyTorch launches ~4 900 kernels per step here and is host-bound ("HIP streams and
     graphs instead of a tracing compiler"); a graph replay removes the launch overhead without
@@ -238,11 +240,14 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
-                 zero_arena=True):
+                 zero_arena=True, prefetch_text=True):
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
         self.warmup = warmup
         self.prefetch_sampling = prefetch_sampling
+        self.prefetch_text = bool(prefetch_text and hasattr(self._module(), "text_encoder_is_frozen")
+                                  and self._module().text_encoder_is_frozen())
         self._announced = None
+        self._tok_cache = None
         self.arena = None
         if zero_arena:
             try:
@@ -260,9 +265,14 @@ class GraphedTrainStep:
         inds = self._backbone().sample(self.s_next_pc)
         torch.cat([i.reshape(-1) for i in inds], out=self.s_inds_next)
 
+    def _module(self):
+        return self.model.module if hasattr(self.model, "module") else self.model
+
     def _backbone(self):
-        m = self.model.module if hasattr(self.model, "module") else self.model
-        return m.backbone_net
+        return self._module().backbone_net
+
+    def _encode_text_into_next(self):
+        self.s_text_next.copy_(self._module().encode_text(self.s_tok_next))
 
     def _fwd_bwd(self):
         if self.arena is None:
@@ -278,6 +288,12 @@ class GraphedTrainStep:
             self._sample_stream.wait_stream(main)            # fork: next batch's chain on 8 CUs
             with torch.cuda.stream(self._sample_stream):
                 self._sample_into_next()
+        if self.prefetch_text:
+            main = torch.cuda.current_stream()
+            self.s_text_cur.copy_(self.s_text_next)          # this batch's language features
+            self._text_stream.wait_stream(main)
+            with torch.cuda.stream(self._text_stream):
+                self._encode_text_into_next()
         end_points = self.model.forward_tokenized(self.s_inputs, self.s_tok)
         loss = surrogate_loss(end_points, self.s_targets)
         self.flat.detach()                      # fresh .grad tensors: no per-parameter accumulate
@@ -285,6 +301,8 @@ class GraphedTrainStep:
         self.flat.gather([p.grad for p in self.flat.params])
         if self.prefetch_sampling:
             torch.cuda.current_stream().wait_stream(self._sample_stream)   # join
+        if self.prefetch_text:
+            torch.cuda.current_stream().wait_stream(self._text_stream)
         return loss.detach()
 
     def _update(self):
@@ -327,6 +345,13 @@ class GraphedTrainStep:
             self._sample_stream = torch.cuda.Stream()
             self._sample_into_next()                          # prime with THIS batch
             torch.cuda.synchronize()
+        if self.prefetch_text:
+            self.s_tok_next = BatchEncoding({k: v.clone() for k, v in tok.items()})
+            self.s_text_next = self._module().encode_text(self.s_tok_next).clone()   # prime with THIS batch
+            self.s_text_cur = torch.empty_like(self.s_text_next)
+            self.s_inputs["text_encoder_output"] = self.s_text_cur
+            self._text_stream = torch.cuda.Stream()
+            torch.cuda.synchronize()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -344,20 +369,40 @@ class GraphedTrainStep:
             self._update()
 
     def __call__(self, inputs, targets, next_inputs=None):
-        tok = self.model.tokenize(inputs)                      # host work stays in the step
+        # host work stays in the step; a batch announced by the previous call was tokenised then
+        if self._tok_cache is not None and self._tok_cache[0] is inputs:
+            tok = self._tok_cache[1]
+        else:
+            tok = self.model.tokenize(inputs)
+        self._tok_cache = None
         sig = (tuple(inputs["point_clouds"].shape), tuple(tok["input_ids"].shape))
         if sig != self._sig:
             self._capture(inputs, targets, tok)
             self._sig = sig
-            self._announced = inputs["point_clouds"]
+            self._announced = inputs
         self._copy_in(inputs, targets, tok)
+        announced = self._announced is inputs
+        nxt = next_inputs if next_inputs is not None else inputs
         if self.prefetch_sampling:
-            if self._announced is not inputs["point_clouds"]:  # not prefetched: sample it now
+            if not announced:                                  # not prefetched: sample it now
                 self.s_next_pc.copy_(inputs["point_clouds"][..., :3])
                 self._sample_into_next()
-            nxt = (next_inputs or inputs)["point_clouds"]
-            self.s_next_pc.copy_(nxt[..., :3], non_blocking=True)
-            self._announced = nxt if next_inputs is not None else None
+            self.s_next_pc.copy_(nxt["point_clouds"][..., :3], non_blocking=True)
+        text_ok = True
+        if self.prefetch_text:
+            if not announced:                                  # not prefetched: encode it now
+                for k in self.s_tok_next.keys():
+                    self.s_tok_next[k].copy_(tok[k])
+                self._encode_text_into_next()
+            tok_next = tok if nxt is inputs else self.model.tokenize(nxt)
+            text_ok = tuple(tok_next["input_ids"].shape) == tuple(self.s_tok_next["input_ids"].shape)
+            if text_ok:
+                for k in self.s_tok_next.keys():
+                    self.s_tok_next[k].copy_(tok_next[k], non_blocking=True)
+                if nxt is not inputs:
+                    self._tok_cache = (nxt, tok_next)
+        # a next batch of another token length re-captures anyway: treat it as unannounced
+        self._announced = nxt if (next_inputs is not None and text_ok) else None
         self.g_fwd_bwd.replay()
         self.flat.all_reduce_mean(self.group)
         self.g_update.replay()

@@ -1,5 +1,6 @@
-"""-m gpu: the hipGraph training step with the furthest-point-sampling chain prefetched for the NEXT
-batch on a forked stream must train exactly like the step that samples in line -- over several
+"""-m gpu: the hipGraph training step with the furthest-point-sampling chain and the frozen language
+model prefetched for the NEXT batch on forked streams must train exactly like the step that runs them
+in line -- over several
 DIFFERENT batches (so a stale or mis-paired prefetch shows), including an unannounced batch."""
 import copy
 import warnings
@@ -42,7 +43,7 @@ def test_prefetched_sampling_trains_like_inline_sampling():
         # learning rate 0: the per-batch losses are functions of (fixed weights, batch, sampled indices)
         # only, so they must agree to rounding -- a stale or mis-paired prefetch changes them visibly
         ref = GraphedTrainStep(ref_model, FlatAdamW(ref_model, lr=0.0, lr_backbone=0.0), warmup=1,
-                               prefetch_sampling=False)
+                               prefetch_sampling=False, prefetch_text=False)
         pre = GraphedTrainStep(pre_model, FlatAdamW(pre_model, lr=0.0, lr_backbone=0.0), warmup=1,
                                prefetch_sampling=True)
         ref_losses, pre_losses = [], []
