@@ -143,6 +143,25 @@ __global__ __launch_bounds__(256) void mlp_dz_kernel(long P, int C, long ld, flo
   }
 }
 
+__global__ __launch_bounds__(256) void mlp_bn_relu_apply_kernel(long P, int C, long ld,
+                                                                const float *__restrict__ Z,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift,
+                                                                float *__restrict__ out) {
+  const int cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const int c = blockIdx.y * 256 + cq * 4;
+  if (c >= C) return;
+  const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
+  const float4 sh = *reinterpret_cast<const float4 *>(shift + c);
+  const long r0 = (long)blockIdx.x * kRows, r1 = min(P, r0 + kRows);
+  for (long r = r0 + ph; r < r1; r += 4) {
+    const float4 z = *reinterpret_cast<const float4 *>(Z + r * ld + c);
+    *reinterpret_cast<float4 *>(out + r * ld + c) =
+        make_float4(fmaxf(sc.x * z.x + sh.x, 0.f), fmaxf(sc.y * z.y + sh.y, 0.f),
+                    fmaxf(sc.z * z.z + sh.z, 0.f), fmaxf(sc.w * z.w + sh.w, 0.f));
+  }
+}
+
 inline int launch_status() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -180,6 +199,14 @@ int butd_mlp_dz(long P, int C, long ld, float *g, const float *Z, const float *s
   hipLaunchKernelGGL(mlp_dz_kernel, dim3((unsigned)((P + kRows - 1) / kRows), (C + 255) / 256),
                      dim3(256), 0, (hipStream_t)stream, P, C, ld, g, Z, scale, mean, rstd, S1, S2,
                      training);
+  return launch_status();
+}
+
+int butd_mlp_bn_relu_apply(long P, int C, long ld, const float *Z, const float *scale,
+                           const float *shift, float *out, butd_stream_t stream) {
+  if (P < 1 || C < 4 || (C & 3) || (ld & 3)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(mlp_bn_relu_apply_kernel, dim3((unsigned)((P + kRows - 1) / kRows), (C + 255) / 256),
+                     dim3(256), 0, (hipStream_t)stream, P, C, ld, Z, scale, shift, out);
   return launch_status();
 }
 

@@ -1,14 +1,18 @@
-"""Conv1d(k=1) + BatchNorm1d + ReLU (+ Dropout) chains on the gfx950 kernels of include/butd_mlp.h.
+"""Conv(k=1) + BatchNorm + ReLU (+ Dropout) chains on the gfx950 kernels of include/butd_mlp.h.
 
 ``mlp_chains`` runs G parallel chains that share one input -- the three ``ThreeLayerMLP`` of a
-``ClsAgnosticPredictHead`` (models/modules.py:89-180), or G = 1 for ``PointsObjClsModule`` (:19-49) and
-``PositionEmbeddingLearned`` (:52-67) -- forward AND backward, in training (batch statistics,
-running-stat update, dropout) or eval mode.  Activations are position-major ``(P = B*L, C)`` matrices;
-the hidden activations of the G chains sit side by side in one ``(P, G*H)`` matrix.  Every layer is ONE
+``ClsAgnosticPredictHead`` (models/modules.py:89-180), or G = 1 for ``PointsObjClsModule`` (:19-49),
+``PositionEmbeddingLearned`` (:52-67) and the ``SharedMLP`` of ``PointnetFPModule``
+(pointnet2_modules.py:371-416) -- forward AND backward, in training (batch statistics, running-stat
+update, dropout) or eval mode.  Activations are position-major ``(P = B*L, C)`` matrices; the hidden
+activations of the G chains sit side by side in one ``(P, G*H_l)`` matrix per layer.  Every layer is ONE
 grouped MFMA GEMM launch whose epilogue accumulates the BatchNorm column sums and whose operand staging
 applies the previous layer's BatchNorm + ReLU + Dropout, plus one tiny bookkeeping launch: a 3-chain
 predict head is 5 launches forward and 10 backward, where the stock chain is ~33 + ~60 (Conv1d via
 MIOpen with NCHW transposes, BatchNorm, ReLU, Dropout kernels and their backward).
+
+A chain ends either in a plain convolution (heads, position embeddings) or -- ``out is None`` -- in
+BatchNorm + ReLU (SharedMLP), whose activation is then materialised by ``butd_mlp_bn_relu_apply``.
 """
 import torch
 
@@ -30,50 +34,61 @@ def _split(M):
 
 
 class ChainSpec:
-    """Static description of G chains: hidden widths, output widths, buffers, flags (not tensors that
-    need gradients: those go through ``_MlpChains.apply`` positionally)."""
+    """Static description of G chains: hidden widths per layer, output widths (empty: the chains end in
+    BatchNorm + ReLU), buffers, flags (not tensors that need gradients: those go through
+    ``_MlpChains.apply`` positionally)."""
 
-    def __init__(self, G, nh, H, outs, bn_buffers, eps, momentum, p_drop, training, site0):
-        self.G, self.nh, self.H, self.outs = G, nh, H, outs
-        self.bn_buffers = bn_buffers        # [chain][layer] -> (running_mean, running_var, nbt)
+    def __init__(self, G, Hs, outs, bn_buffers, eps, momentum, p_drop, training, site0):
+        self.G, self.Hs, self.nh, self.outs = G, list(Hs), len(Hs), outs
+        self.tail = not outs                 # no final convolution
+        self.bn_buffers = bn_buffers         # [chain][layer] -> (running_mean, running_var, nbt)
         self.eps, self.momentum, self.p_drop = eps, momentum, p_drop
         self.training, self.site0 = training, site0
 
 
+def _unpack(spec, params):
+    G, nh = spec.G, spec.nh
+    per = 4 * nh + (0 if spec.tail else 2)
+    hidden = [[params[i * per + 4 * l:i * per + 4 * l + 4] for l in range(nh)] for i in range(G)]
+    outp = None if spec.tail else [params[i * per + 4 * nh:i * per + 4 * nh + 2] for i in range(G)]
+    return hidden, outp
+
+
 class _MlpChains(torch.autograd.Function):
-    """params: per chain, per hidden layer (w, bias|None, gamma, beta), then (w_out, b_out|None)."""
+    """params: per chain, per hidden layer (w, bias|None, gamma, beta), then (w_out, b_out|None) unless
+    the chains end in BatchNorm + ReLU."""
 
     @staticmethod
     def forward(ctx, x, spec, *params):
-        G, nh, H = spec.G, spec.nh, spec.H
+        G, nh, Hs = spec.G, spec.nh, spec.Hs
         P, Cin = x.shape
-        GH = G * H
         dev = x.device
-        per = 4 * nh + 2
-        hidden = [[params[i * per + 4 * l:i * per + 4 * l + 4] for l in range(nh)] for i in range(G)]
-        outp = [params[i * per + 4 * nh:i * per + 4 * nh + 2] for i in range(G)]
+        hidden, outp = _unpack(spec, params)
         p = spec.p_drop if spec.training else 0.0
-        Z = [torch.empty((P, GH), device=dev) for _ in range(nh)]
-        stats = zeros((nh, 2, GH), dtype=torch.float64, device=dev)
-        aff = torch.empty((nh, 4, GH), device=dev)       # per layer: mean, rstd, scale, shift
-        sl = lambda i: slice(i * H, (i + 1) * H)
+        Z = [torch.empty((P, G * H), device=dev) for H in Hs]
+        Hmax = max(Hs)
+        stats = zeros((nh, 2, G * Hmax), dtype=torch.float64, device=dev)
+        aff = torch.empty((nh, 4, G * Hmax), device=dev)       # per layer: mean, rstd, scale, shift
+        sl = lambda l, i: slice(i * Hs[l], (i + 1) * Hs[l])
 
         def operand(l, i):
             """Input of layer l (l == nh: the output layer) of chain i: tensor, row stride, prologue."""
             if l == 0:
                 return x, Cin, None, (0.0, 0)
-            return (Z[l - 1][:, sl(i)], GH, (aff[l - 1, 2, sl(i)], aff[l - 1, 3, sl(i)]),
+            s = sl(l - 1, i)
+            return (Z[l - 1][:, s], G * Hs[l - 1], (aff[l - 1, 2, s], aff[l - 1, 3, s]),
                     (p, spec.site0 + (l - 1) * G + i))
 
         for l in range(nh):
+            H, GH = Hs[l], G * Hs[l]
             probs = []
             for i in range(G):
                 w, b = hidden[i][l][0], hidden[i][l][1]
                 a, lda, a_aff, a_drop = operand(l, i)
-                K = Cin if l == 0 else H
-                probs.append(_problem(a, w, Z[l][:, sl(i)], P, H, K, (lda, 1), (K, 1), GH, bias=b,
+                K = Cin if l == 0 else Hs[l - 1]
+                probs.append(_problem(a, w, Z[l][:, sl(l, i)], P, H, K, (lda, 1), (K, 1), GH, bias=b,
                                       a_affine=a_aff, a_drop=a_drop,
-                                      col_stats=(stats[l, 0, sl(i)], stats[l, 1, sl(i)])))
+                                      col_stats=(stats[l, 0, sl(l, i)], stats[l, 1, sl(l, i)])))
             _gemm(probs, x)
             segs = (BnSegment * _hiplib.MLP_MAX_SEGMENTS)()
             for i in range(G):
@@ -83,15 +98,22 @@ class _MlpChains(torch.autograd.Function):
             _call("butd_mlp_bn_finalize", x, G, H, P, stats[l, 0].data_ptr(), stats[l, 1].data_ptr(), segs,
                   float(spec.eps), float(spec.momentum), int(spec.training), aff[l, 0].data_ptr(),
                   aff[l, 1].data_ptr(), aff[l, 2].data_ptr(), aff[l, 3].data_ptr())
-        outs, probs = [], []
-        for i in range(G):
-            w, b = outp[i]
-            a, lda, a_aff, a_drop = operand(nh, i)
-            o = torch.empty((P, spec.outs[i]), device=dev)
-            probs.append(_problem(a, w, o, P, spec.outs[i], H, (lda, 1), (H, 1), spec.outs[i], bias=b,
-                                  a_affine=a_aff, a_drop=a_drop))
-            outs.append(o)
-        _gemm(probs, x)
+        if spec.tail:
+            GH = G * Hs[-1]
+            out = torch.empty((P, GH), device=dev)
+            _call("butd_mlp_bn_relu_apply", x, P, GH, GH, Z[-1].data_ptr(), aff[nh - 1, 2].data_ptr(),
+                  aff[nh - 1, 3].data_ptr(), out.data_ptr())
+            outs = [out]
+        else:
+            outs, probs = [], []
+            for i in range(G):
+                w, b = outp[i]
+                a, lda, a_aff, a_drop = operand(nh, i)
+                o = torch.empty((P, spec.outs[i]), device=dev)
+                probs.append(_problem(a, w, o, P, spec.outs[i], Hs[-1], (lda, 1), (Hs[-1], 1), spec.outs[i],
+                                      bias=b, a_affine=a_aff, a_drop=a_drop))
+                outs.append(o)
+            _gemm(probs, x)
         ctx.save_for_backward(x, aff, *Z, *params)
         ctx.spec, ctx.p = spec, p
         return tuple(outs)
@@ -99,80 +121,92 @@ class _MlpChains(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         spec, p = ctx.spec, ctx.p
-        G, nh, H = spec.G, spec.nh, spec.H
+        G, nh, Hs = spec.G, spec.nh, spec.Hs
         saved = ctx.saved_tensors
         x, aff = saved[0], saved[1]
         Z = saved[2:2 + nh]
-        params = saved[2 + nh:]
+        hidden, outp = _unpack(spec, saved[2 + nh:])
         P, Cin = x.shape
-        GH = G * H
         dev = x.device
-        per = 4 * nh + 2
-        hidden = [[params[i * per + 4 * l:i * per + 4 * l + 4] for l in range(nh)] for i in range(G)]
-        outp = [params[i * per + 4 * nh:i * per + 4 * nh + 2] for i in range(G)]
-        sl = lambda i: slice(i * H, (i + 1) * H)
-        d_outs = [torch.zeros((P, spec.outs[i]), device=dev) if d is None else d.contiguous()
-                  for i, d in enumerate(d_outs)]
+        Hmax = max(Hs)
+        sl = lambda l, i: slice(i * Hs[l], (i + 1) * Hs[l])
         # one zero-filled slab for every weight / bias gradient (accumulated with atomics)
         sizes = []
         for i in range(G):
             for l in range(nh):
                 w, b = hidden[i][l][0], hidden[i][l][1]
                 sizes += [w.numel(), 0 if b is None else b.numel()]
-            sizes += [outp[i][0].numel(), 0 if outp[i][1] is None else outp[i][1].numel()]
+            if not spec.tail:
+                sizes += [outp[i][0].numel(), 0 if outp[i][1] is None else outp[i][1].numel()]
         slab = zeros(sum(sizes), device=dev)
         views, o = [], 0
         for n in sizes:
             views.append(slab[o:o + n] if n else None)
             o += n
-        dW = [[(views[i * (2 * nh + 2) + 2 * l], views[i * (2 * nh + 2) + 2 * l + 1]) for l in range(nh)]
+        stride = 2 * nh + (0 if spec.tail else 2)
+        dW = [[(views[i * stride + 2 * l], views[i * stride + 2 * l + 1]) for l in range(nh)]
               for i in range(G)]
-        dWo = [(views[i * (2 * nh + 2) + 2 * nh], views[i * (2 * nh + 2) + 2 * nh + 1]) for i in range(G)]
-        S = zeros((nh, 2, GH), dtype=torch.float64, device=dev)
+        S = zeros((nh, 2, G * Hmax), dtype=torch.float64, device=dev)
 
         def operand(l, i):
             if l == 0:
                 return x, Cin, None, (0.0, 0)
-            return (Z[l - 1][:, sl(i)], GH, (aff[l - 1, 2, sl(i)], aff[l - 1, 3, sl(i)]),
+            s = sl(l - 1, i)
+            return (Z[l - 1][:, s], G * Hs[l - 1], (aff[l - 1, 2, s], aff[l - 1, 3, s]),
                     (p, spec.site0 + (l - 1) * G + i))
 
         def wgrad(dy, ldy, N, l, i, dw, db):
             """dw[N,K] += dy[P,N]^T @ input_of_layer_l[P,K]  (+ db = column sums of dy)."""
             a, lda, b_aff, b_drop = operand(l, i)
-            K = Cin if l == 0 else H
+            K = Cin if l == 0 else Hs[l - 1]
             return _problem(dy, a, dw, N, K, P, (1, ldy), (1, lda), K, bias_grad=db,
                             ones_col=db is not None, accumulate=True, split_k=_split(P),
                             b_affine=b_aff, b_drop=b_drop)
 
-        dH = torch.empty((P, GH), device=dev)
-        probs = []
-        for i in range(G):
-            n_out = spec.outs[i]
-            probs.append(wgrad(d_outs[i], n_out, n_out, nh, i, dWo[i][0], dWo[i][1]))
-            probs.append(_problem(d_outs[i], outp[i][0], dH[:, sl(i)], P, H, n_out, (n_out, 1), (1, H), GH))
-        _gemm(probs, x)
+        GHl = G * Hs[-1]
+        if spec.tail:      # d(out) is d(relu(bn(z))) of the last layer: it IS that layer's dH
+            dH = d_outs[0].contiguous()
+            if dH.data_ptr() == d_outs[0].data_ptr():
+                dH = dH.clone()                       # mask_stats works in place
+        else:
+            d_outs = [zeros((P, spec.outs[i]), device=dev) if d is None else d.contiguous()
+                      for i, d in enumerate(d_outs)]
+            dWo = [(views[i * stride + 2 * nh], views[i * stride + 2 * nh + 1]) for i in range(G)]
+            dH = torch.empty((P, GHl), device=dev)
+            probs = []
+            for i in range(G):
+                n_out = spec.outs[i]
+                probs.append(wgrad(d_outs[i], n_out, n_out, nh, i, dWo[i][0], dWo[i][1]))
+                probs.append(_problem(d_outs[i], outp[i][0], dH[:, sl(nh - 1, i)], P, Hs[-1], n_out,
+                                      (n_out, 1), (1, Hs[-1]), GHl))
+            _gemm(probs, x)
         need_dx = ctx.needs_input_grad[0]
         dx = None
         for l in reversed(range(nh)):
+            H, GH = Hs[l], G * Hs[l]
+            # the activation of a BatchNorm+ReLU tail is not followed by a dropout
+            p_l = 0.0 if (spec.tail and l == nh - 1) else float(p)
             _call("butd_mlp_mask_stats", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
-                  aff[l, 3].data_ptr(), aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), float(p),
+                  aff[l, 3].data_ptr(), aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), p_l,
                   spec.site0 + l * G, H, rng_counter(dev).data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr())
             _call("butd_mlp_dz", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
                   aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr(),
                   int(spec.training))
             dZ = dH
             if l > 0:
-                dH = torch.empty((P, GH), device=dev)
+                dH = torch.empty((P, G * Hs[l - 1]), device=dev)
             elif need_dx:
                 dx = zeros((P, Cin), device=dev) if G > 1 else torch.empty((P, Cin), device=dev)
             probs = []
             for i in range(G):
                 w = hidden[i][l][0]
-                probs.append(wgrad(dZ[:, sl(i)], GH, H, l, i, dW[i][l][0], dW[i][l][1]))
+                probs.append(wgrad(dZ[:, sl(l, i)], GH, H, l, i, dW[i][l][0], dW[i][l][1]))
                 if l > 0:
-                    probs.append(_problem(dZ[:, sl(i)], w, dH[:, sl(i)], P, H, H, (GH, 1), (1, H), GH))
+                    Hp = Hs[l - 1]
+                    probs.append(_problem(dZ[:, sl(l, i)], w, dH[:, sl(l - 1, i)], P, Hp, H, (GH, 1), (1, Hp),
+                                          G * Hp))
                 elif need_dx:
-                    probs.append(_problem(dZ[:, sl(i)], w, dx, P, Cin, H, (GH, 1), (1, Cin), Cin,
+                    probs.append(_problem(dZ[:, sl(l, i)], w, dx, P, Cin, H, (GH, 1), (1, Cin), Cin,
                                           accumulate=G > 1))
             _gemm(probs, x)
         Sf = S.float()
@@ -181,35 +215,40 @@ class _MlpChains(torch.autograd.Function):
             for l in range(nh):
                 w, b = hidden[i][l][0], hidden[i][l][1]
                 grads += [dW[i][l][0].view(w.shape), None if b is None else dW[i][l][1],
-                          Sf[l, 1, sl(i)], Sf[l, 0, sl(i)]]
-            grads += [dWo[i][0].view(outp[i][0].shape), dWo[i][1]]
+                          Sf[l, 1, sl(l, i)], Sf[l, 0, sl(l, i)]]
+            if not spec.tail:
+                grads += [dWo[i][0].view(outp[i][0].shape), dWo[i][1]]
         return (dx, None, *grads)
 
 
 def mlp_chains(x_pm, chains, training):
     """x_pm (P, Cin) fp32 contiguous; ``chains``: list of (hidden, out, p_drop) with
-    hidden = [(conv, bn), ...] (Conv1d k=1 / BatchNorm1d modules), out = Conv1d.  All chains share the
-    hidden width and depth.  -> list of (P, out_channels) tensors."""
+    hidden = [(conv, bn), ...] (1x1 Conv1d/Conv2d and BatchNorm1d/2d modules), out = the final 1x1 conv
+    or None (the chain ends in BatchNorm + ReLU).  All chains share depth and hidden widths.
+    -> list of (P, out_channels) tensors (one (P, H_last) tensor when ``out`` is None)."""
     G = len(chains)
     nh = len(chains[0][0])
-    H = chains[0][0][0][0].out_channels
+    Hs = [conv.out_channels for conv, _ in chains[0][0]]
     p_drop = chains[0][2]
     bn0 = chains[0][0][0][1]
+    tail = chains[0][1] is None
     params, buffers, outs = [], [], []
     for hidden, out, p in chains:
-        assert len(hidden) == nh and p == p_drop
+        assert len(hidden) == nh and p == p_drop and (out is None) == tail
         bufs = []
-        for conv, bn in hidden:
-            assert conv.out_channels == H and conv.kernel_size == (1,) and bn.eps == bn0.eps
+        for l, (conv, bn) in enumerate(hidden):
+            assert conv.out_channels == Hs[l] and all(k == 1 for k in conv.kernel_size) and bn.eps == bn0.eps
             assert bn.momentum == bn0.momentum and bn.affine and bn.track_running_stats
             params += [conv.weight, conv.bias, bn.weight, bn.bias]
             bufs.append((bn.running_mean, bn.running_var, bn.num_batches_tracked))
         buffers.append(bufs)
-        params += [out.weight, out.bias]
-        outs.append(out.out_channels)
-    assert G <= _hiplib.MLP_MAX_SEGMENTS and 2 * G <= 8 and H % 4 == 0
+        if not tail:
+            params += [out.weight, out.bias]
+            outs.append(out.out_channels)
+    assert G <= _hiplib.MLP_MAX_SEGMENTS and 2 * G <= 8 and all(H % 4 == 0 for H in Hs)
+    assert not tail or G == 1
     site0 = _site[0] + 1
     _site[0] += G * nh
     momentum = 0.1 if bn0.momentum is None else bn0.momentum
-    spec = ChainSpec(G, nh, H, outs, buffers, bn0.eps, momentum, p_drop, bool(training), site0)
+    spec = ChainSpec(G, Hs, outs, buffers, bn0.eps, momentum, p_drop, bool(training), site0)
     return list(_MlpChains.apply(x_pm.contiguous(), spec, *params))

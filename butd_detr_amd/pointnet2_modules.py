@@ -99,9 +99,23 @@ class PointnetFPModule(nn.Module):
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
-            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
         else:
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         if unknow_feats is not None:
             interpolated = torch.cat([interpolated, unknow_feats], dim=1)
+        from . import attention_blocks
+        if attention_blocks.get_backend() == "hip" and interpolated.is_cuda and self._chain_ok():
+            # SharedMLP = [1x1 conv -> BatchNorm2d -> ReLU] x n on position-major rows: grouped MFMA GEMMs
+            # with the BatchNorm folded into the next operand load (fused_mlp); returned as the (B,C,n)
+            # view of the position-major result, which is the layout the encoder wants next
+            from .fused_mlp import mlp_chains
+            b, c, n = interpolated.shape
+            x_pm = interpolated.transpose(1, 2).reshape(b * n, c)
+            out = mlp_chains(x_pm, [([(l.conv, l.bn.bn) for l in self.mlp], None, 0.0)], self.training)[0]
+            return out.view(b, n, -1).transpose(1, 2)
         return self.mlp(interpolated.unsqueeze(-1)).squeeze(-1)
+
+    def _chain_ok(self):
+        return all(hasattr(l, "bn") and l.conv.bias is None and l.conv.out_channels % 4 == 0
+                   and hasattr(l, "activation") for l in self.mlp) and self.mlp[0].conv.in_channels % 4 == 0

@@ -62,6 +62,12 @@ int butd_mlp_dz(long P, int C, long ld, float *g, const float *Z, const float *s
                 const float *mean, const float *rstd, const double *S1, const double *S2,
                 int training, butd_stream_t stream);
 
+/* out[p, c] = relu(scale[c] * Z[p, c] + shift[c])  (P x C, row stride ld for both): the materialised
+ * output of a chain that ENDS in BatchNorm + ReLU (the SharedMLP of PointnetFPModule,
+ * pointnet2_modules.py:371-416).  C % 4 == 0. */
+int butd_mlp_bn_relu_apply(long P, int C, long ld, const float *Z, const float *scale,
+                           const float *shift, float *out, butd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,3 +232,38 @@ def test_three_layer_mlp_standalone_and_dropout(backend):
     _close(y1, y_ref)
     for a, b in zip(got, want):
         _close(a, b, 2e-3, frac=1e-3)
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("mlp,n,m", [([512, 256, 256], 512, 256), ([512, 256, 288], 1024, 512)])
+def test_fp_module_matches_torch(backend, train, mlp, n, m):
+    """PointnetFPModule (pointnet2_modules.py:371-416): 3-NN interpolation (HIP index ops on both sides)
+    + skip concat + SharedMLP -- the SharedMLP as a BatchNorm+ReLU-terminated fused chain vs stock torch."""
+    from butd_detr_amd.pointnet2_modules import PointnetFPModule
+    torch.manual_seed(n)
+    B = 4
+    ref = PointnetFPModule(mlp=list(mlp)).cuda()
+    with torch.no_grad():
+        for mod in ref.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+                mod.running_mean.uniform_(-0.1, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+                mod.weight[:3] *= -1.0
+    fused = copy.deepcopy(ref)
+    unknown = torch.rand(B, n, 3, device="cuda")
+    known = torch.rand(B, m, 3, device="cuda")
+    c_skip, c_known = mlp[0] // 2, mlp[0] - mlp[0] // 2
+    f_unknown = torch.randn(B, c_skip, n, device="cuda")
+    f_known = torch.randn(B, c_known, m, device="cuda")
+    probe = torch.randn(B, mlp[-1], n, device="cuda")
+
+    def run(mod):
+        a = f_unknown.clone().requires_grad_(True)
+        k = f_known.clone().requires_grad_(True)
+        out = mod(unknown, known, a, k)
+        (out * probe).sum().backward()
+        return [out], [a.grad, k.grad]
+
+    _compare(backend, ref, fused, run, train)
