@@ -53,19 +53,23 @@ __global__ __launch_bounds__(kThreads) void sa_group_kernel(int N, int np, int n
 // pool_ns rows, or single rows when not pooling), so the pooling needs no cross-thread step and every
 // load is a coalesced 16-byte access; sums are reduced across the TPG row-phases in LDS and leave the
 // block as ONE double atomic per column.
-constexpr int kChunkRows = 256;
+constexpr int kChunkRows = 256;      // tall inputs (>= 2^19 rows): fewest atomics
+constexpr int kChunkRowsSmall = 64;  // otherwise: four times the workgroups (a 65 536-row level is 256
+                                     // workgroups of 256 rows, and every thread then walks 16-64 rows of
+                                     // dependent load -> store: 100 us where the data takes 25)
+inline int chunk_rows(long P) { return P >= (1L << 19) ? kChunkRows : kChunkRowsSmall; }
 
 __global__ __launch_bounds__(kThreads) void sa_colstats_kernel(
     long P, int C, const float *__restrict__ Z, double *__restrict__ sum, double *__restrict__ sumsq,
     int pool_ns, float *__restrict__ zmax, float *__restrict__ zmin, uint8_t *__restrict__ amax,
-    uint8_t *__restrict__ amin) {
+    uint8_t *__restrict__ amin, int chunk) {
   __shared__ float red[2][kThreads][4];
   const int c4n = C >> 2;                 // float4 columns (16, 32 or 64)
   const int tpg = kThreads / c4n;         // row phases (16, 8 or 4)
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
   const int gs = pool_ns > 0 ? pool_ns : 1;
-  const long row0 = (long)blockIdx.x * kChunkRows;
-  const long rows = min((long)kChunkRows, P - row0);
+  const long row0 = (long)blockIdx.x * chunk;
+  const long rows = min((long)chunk, P - row0);
   const long ngroups = rows / gs;
   float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
   for (long g = sub; g < ngroups; g += tpg) {
@@ -164,25 +168,23 @@ __global__ __launch_bounds__(kThreads) void sa_pool_finalize_kernel(
 
 // ---------------------------------------------------------------------------------------- backward
 __global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(
-    int np, int C, long G, const float *__restrict__ d_out_cm, const float *__restrict__ zsel,
+    int np, int C, long G, int groups_per_block, const float *__restrict__ d_out_pm, const float *__restrict__ zsel,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, double *__restrict__ S1, double *__restrict__ S2) {
-  // block = 32 groups x all channels: thread t owns column (t % C), groups sub, sub+tpc, ...
+  // block = groups_per_block groups x all channels: thread t owns column (t % C), groups sub, sub+tpc, ...
   __shared__ float red[2][kThreads];
   const int tpc = kThreads / C;
   const int col = threadIdx.x % C, sub = threadIdx.x / C;
-  const long g0 = (long)blockIdx.x * 32;
-  const long ng = min((long)32, G - g0);
+  const long g0 = (long)blockIdx.x * groups_per_block;
+  const long ng = min((long)groups_per_block, G - g0);
   float s1 = 0.f, s2 = 0.f;
   if (sub < tpc) {
     const float sc = scale[col], sh = shift[col], mu = mean[col], rs = rstd[col];
     for (long gi = sub; gi < ng; gi += tpc) {
       const long g = g0 + gi;
-      const long b = g / np;
-      const int j = (int)(g - b * np);
       const float z = zsel[g * C + col];
       if (sc * z + sh > 0.f) {
-        const float dy = d_out_cm[(b * C + col) * np + j];
+        const float dy = d_out_pm[g * C + col];
         s1 += dy;
         s2 += dy * (z - mu) * rs;
       }
@@ -205,15 +207,15 @@ __global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(
 // dZ of the last layer, in place on Z: workgroup = kChunkRows rows x all columns, a thread owns one
 // float4 column group and every TPG-th row (same decomposition as the statistics kernels).
 __global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
-    int np, int ns, int C, long P, float *__restrict__ Z, const float *__restrict__ d_out_cm,
+    int np, int ns, int C, long P, float *__restrict__ Z, const float *__restrict__ d_out_pm,
     const float *__restrict__ zsel, const uint8_t *__restrict__ asel, const float *__restrict__ gamma,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, const double *__restrict__ S1, const double *__restrict__ S2,
-    int training) {
+    int training, int chunk) {
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
-  const long row0 = (long)blockIdx.x * kChunkRows;
-  const long rows = min((long)kChunkRows, P - row0);
+  const long row0 = (long)blockIdx.x * chunk;
+  const long rows = min((long)chunk, P - row0);
   const double invP = 1.0 / (double)P;
   float sc[4], sh[4], mu[4], rs[4], ga[4], a1[4], a2[4];
 #pragma unroll
@@ -227,10 +229,10 @@ __global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
     const long p = row0 + r;
     const long g = p / ns;
     const int k = (int)(p - g * ns);
-    const long b = g / np;
-    const int j = (int)(g - b * np);
     const long o = p * C + cq * 4;
     const float4 z4 = *reinterpret_cast<const float4 *>(Z + o);
+    const float4 dy4 = *reinterpret_cast<const float4 *>(d_out_pm + g * C + cq * 4);
+    const float dyv[4] = {dy4.x, dy4.y, dy4.z, dy4.w};
     const float4 zs4 = *reinterpret_cast<const float4 *>(zsel + g * C + cq * 4);
     const uchar4 as4 = *reinterpret_cast<const uchar4 *>(asel + g * C + cq * 4);
     const float z[4] = {z4.x, z4.y, z4.z, z4.w}, zs[4] = {zs4.x, zs4.y, zs4.z, zs4.w};
@@ -239,7 +241,7 @@ __global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float dy = 0.f;
-      if (as[e] == k && sc[e] * zs[e] + sh[e] > 0.f) dy = d_out_cm[(b * C + cq * 4 + e) * np + j];
+      if (as[e] == k && sc[e] * zs[e] + sh[e] > 0.f) dy = dyv[e];
       out[e] = training ? ga[e] * rs[e] * (dy - a1[e] - (z[e] - mu[e]) * rs[e] * a2[e]) : sc[e] * dy;
     }
     *reinterpret_cast<float4 *>(Z + o) = make_float4(out[0], out[1], out[2], out[3]);
@@ -249,12 +251,12 @@ __global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
 __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
     long P, int C, float *__restrict__ dH, const float *__restrict__ Z, const float *__restrict__ scale,
     const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
-    double *__restrict__ S1, double *__restrict__ S2) {
+    double *__restrict__ S1, double *__restrict__ S2, int chunk) {
   __shared__ float red[2][kThreads][4];
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
-  const long row0 = (long)blockIdx.x * kChunkRows;
-  const long rows = min((long)kChunkRows, P - row0);
+  const long row0 = (long)blockIdx.x * chunk;
+  const long rows = min((long)chunk, P - row0);
   const float4 sc4 = *reinterpret_cast<const float4 *>(scale + cq * 4);
   const float4 sh4 = *reinterpret_cast<const float4 *>(shift + cq * 4);
   const float4 mu4 = *reinterpret_cast<const float4 *>(mean + cq * 4);
@@ -297,11 +299,11 @@ __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
 __global__ __launch_bounds__(kThreads) void sa_dz_mid_kernel(
     long P, int C, float *__restrict__ g, const float *__restrict__ Z, const float *__restrict__ gamma,
     const float *__restrict__ scale, const float *__restrict__ mean, const float *__restrict__ rstd,
-    const double *__restrict__ S1, const double *__restrict__ S2, int training) {
+    const double *__restrict__ S1, const double *__restrict__ S2, int training, int chunk) {
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
-  const long row0 = (long)blockIdx.x * kChunkRows;
-  const long rows = min((long)kChunkRows, P - row0);
+  const long row0 = (long)blockIdx.x * chunk;
+  const long rows = min((long)chunk, P - row0);
   const double invP = 1.0 / (double)P;
   float sc[4], mu[4], rs[4], ga[4], a1[4], a2[4];
 #pragma unroll
@@ -363,11 +365,12 @@ int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const f
 int butd_sa_colstats(long P, int C, const float *Z, double *sum, double *sumsq, int pool_ns,
                      float *zmax, float *zmin, uint8_t *amax, uint8_t *amin, butd_stream_t stream) {
   if (P <= 0) return 0;
-  if (!cols_ok(C) || (pool_ns > 0 && (kChunkRows % pool_ns || P % pool_ns)))
+  const int chunk = chunk_rows(P);
+  if (!cols_ok(C) || (pool_ns > 0 && (chunk % pool_ns || P % pool_ns)))
     return (int)hipErrorInvalidValue;
-  const unsigned blocks = (unsigned)((P + kChunkRows - 1) / kChunkRows);
+  const unsigned blocks = (unsigned)((P + chunk - 1) / chunk);
   hipLaunchKernelGGL(sa_colstats_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, P, C, Z,
-                     sum, sumsq, pool_ns, zmax, zmin, amax, amin);
+                     sum, sumsq, pool_ns, zmax, zmin, amax, amin, chunk);
   return (int)hipGetLastError();
 }
 
@@ -394,27 +397,31 @@ int butd_sa_pool_finalize(int B, int np, int C, const float *zmax, const float *
   return (int)hipGetLastError();
 }
 
-int butd_sa_pool_bwd_stats(int B, int np, int C, const float *d_out_cm, const float *zsel,
+int butd_sa_pool_bwd_stats(int B, int np, int C, const float *d_out_pm, const float *zsel,
                            const float *scale, const float *shift, const float *mean,
                            const float *rstd, double *S1, double *S2, butd_stream_t stream) {
   const long G = (long)B * np;
   if (G <= 0) return 0;
   if (!cols_ok(C)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3((unsigned)((G + 31) / 32)), dim3(kThreads), 0,
-                     (hipStream_t)stream, np, C, G, d_out_cm, zsel, scale, shift, mean, rstd, S1, S2);
+  // few groups per workgroup while that keeps the grid small enough for the per-column atomics
+  const int gpb = G >= 8192 ? 32 : 8;
+  hipLaunchKernelGGL(sa_pool_bwd_stats_kernel, dim3((unsigned)((G + gpb - 1) / gpb)),
+                     dim3(kThreads), 0, (hipStream_t)stream, np, C, G, gpb, d_out_pm, zsel, scale, shift, mean,
+                     rstd, S1, S2);
   return (int)hipGetLastError();
 }
 
-int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_cm, const float *zsel,
+int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_pm, const float *zsel,
                     const uint8_t *asel, const float *gamma, const float *scale, const float *shift,
                     const float *mean, const float *rstd, const double *S1, const double *S2,
                     int training, butd_stream_t stream) {
   const long P = (long)B * np * ns;
   if (P <= 0) return 0;
   if (!cols_ok(C)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sa_dz_last_kernel, dim3((unsigned)((P + kChunkRows - 1) / kChunkRows)),
-                     dim3(kThreads), 0, (hipStream_t)stream, np, ns, C, P, Z, d_out_cm, zsel, asel, gamma,
-                     scale, shift, mean, rstd, S1, S2, training);
+  const int chunk = chunk_rows(P);
+  hipLaunchKernelGGL(sa_dz_last_kernel, dim3((unsigned)((P + chunk - 1) / chunk)),
+                     dim3(kThreads), 0, (hipStream_t)stream, np, ns, C, P, Z, d_out_pm, zsel, asel, gamma,
+                     scale, shift, mean, rstd, S1, S2, training, chunk);
   return (int)hipGetLastError();
 }
 
@@ -423,9 +430,10 @@ int butd_sa_mask_stats(long P, int C, float *dH, const float *Z, const float *sc
                        double *S2, butd_stream_t stream) {
   if (P <= 0) return 0;
   if (!cols_ok(C)) return (int)hipErrorInvalidValue;
-  const unsigned blocks = (unsigned)((P + kChunkRows - 1) / kChunkRows);
+  const int chunk = chunk_rows(P);
+  const unsigned blocks = (unsigned)((P + chunk - 1) / chunk);
   hipLaunchKernelGGL(sa_mask_stats_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, P, C,
-                     dH, Z, scale, shift, mean, rstd, S1, S2);
+                     dH, Z, scale, shift, mean, rstd, S1, S2, chunk);
   return (int)hipGetLastError();
 }
 
@@ -434,9 +442,10 @@ int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, 
                    int training, butd_stream_t stream) {
   if (P <= 0) return 0;
   if (!cols_ok(C)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(sa_dz_mid_kernel, dim3((unsigned)((P + kChunkRows - 1) / kChunkRows)),
+  const int chunk = chunk_rows(P);
+  hipLaunchKernelGGL(sa_dz_mid_kernel, dim3((unsigned)((P + chunk - 1) / chunk)),
                      dim3(kThreads), 0, (hipStream_t)stream, P, C, g, Z, gamma, scale, mean, rstd, S1, S2,
-                     training);
+                     training, chunk);
   return (int)hipGetLastError();
 }
 

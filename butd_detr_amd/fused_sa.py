@@ -106,12 +106,13 @@ class _SAMlpPool(torch.autograd.Function):
         dev = X.device
         P, Kp = X.shape                                 # Kp = Cin rounded up to a multiple of 4
         C1, C2, C3 = w1.shape[0], w2.shape[0], w3.shape[0]
+        # gradient of the pooled output, position-major (B, np, C) like everything else here
         if d_cm is None:
-            d_out = d_pm.transpose(1, 2).contiguous()
+            d_out = d_pm.contiguous()
         elif d_pm is None:
-            d_out = d_cm.contiguous()
+            d_out = d_cm.transpose(1, 2).contiguous()
         else:
-            d_out = d_cm + d_pm.transpose(1, 2)
+            d_out = d_pm + d_cm.transpose(1, 2)
         tr = int(training)
         S = zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
         dW = zeros(C3 * C2 + C2 * C1 + C1 * Kp, device=dev)

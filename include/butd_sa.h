@@ -57,15 +57,16 @@ int butd_sa_pool_finalize(int B, int np, int C, const float *zmax, const float *
 
 /* Backward through max-pool + ReLU + BatchNorm(train) of the last layer, part 1: per channel
  * S1[c] = sum_g dy, S2[c] = sum_g dy * zhat_sel over the groups whose pooled activation is > 0
- * (dy = d_out_cm[b,c,j]); S1 = dbeta, S2 = dgamma.  Caller zero-fills S1/S2 (double). */
-int butd_sa_pool_bwd_stats(int B, int np, int C, const float *d_out_cm, const float *zsel,
+ * (dy = d_out_pm[b,j,c], the gradient of the pooled output POSITION-major (B,np,C): coalesced for the
+ * channel-per-thread kernels); S1 = dbeta, S2 = dgamma.  Caller zero-fills S1/S2 (double). */
+int butd_sa_pool_bwd_stats(int B, int np, int C, const float *d_out_pm, const float *zsel,
                            const float *scale, const float *shift, const float *mean,
                            const float *rstd, double *S1, double *S2, butd_stream_t stream);
 
 /* part 2, in place on Z (P x C) -> dZ:  dZ[p,c] = gamma*rstd * (dy3[p,c] - S1/P - zhat[p,c]*S2/P),
- * dy3[p,c] = d_out_cm[b,c,j] if k(p) == asel[g,c] and the pooled activation is > 0, else 0.
+ * dy3[p,c] = d_out_pm[b,j,c] if k(p) == asel[g,c] and the pooled activation is > 0, else 0.
  * training == 0 (BN uses running statistics): dZ = scale * dy3. */
-int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_cm, const float *zsel,
+int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_pm, const float *zsel,
                     const uint8_t *asel, const float *gamma, const float *scale, const float *shift,
                     const float *mean, const float *rstd, const double *S1, const double *S2,
                     int training, butd_stream_t stream);
