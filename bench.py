@@ -120,6 +120,49 @@ def gemm_roofline(step_fn):
             "algorithmic_flops_per_step": flops}
 
 
+def attention_roofline(batch, reps=10):
+    """The attention core on the encoder's visual self-attention shape (B x 8 heads, 1024 x 1024, head
+    dim 36, dropout 0.1): forward and backward launches timed with HIP events on the launch stream;
+    algorithmic FLOPs = 4*Lq*Lk*D per head forward, 2.5x that backward."""
+    from butd_detr_amd import _hiplib, fused_attention as fa
+    lib = _hiplib.load()
+    B, H, D, L = batch, 8, 36, 1024
+    E = H * D
+    dev = torch.device("cuda", torch.cuda.current_device())
+    q, k, v, do = (torch.randn(B, L, E, device=dev) for _ in range(4))
+    out, dq, dk, dv = (torch.empty(B, L, E, device=dev) for _ in range(4))
+    lse, delta = torch.empty(B, H, L, device=dev), torch.empty(B, H, L, device=dev)
+    ctr = fa.rng_counter(dev).data_ptr()
+    stream = torch.cuda.current_stream()
+
+    def fwd():
+        return lib.butd_attention_fwd(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
+                                      lse.data_ptr(), 0.1, 7, ctr, stream.cuda_stream)
+
+    def bwd():
+        return lib.butd_attention_bwd(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
+                                      do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
+                                      dv.data_ptr(), 0, 0, 1.0, 0.1, 7, ctr, stream.cuda_stream)
+
+    def timed(fn):
+        assert fn() == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(reps):
+            fn()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_f, ms_b = timed(fwd), timed(bwd)
+    flops_f = 4.0 * L * L * D * H * B
+    achieved = (flops_f * 3.5) / ((ms_f + ms_b) * 1e-3) / 1e12
+    return {"kernel": "attn_fwd / attn_bwd_dq / attn_bwd_dkv (B=%d, 8 heads, 1024x1024, head dim 36)" % B,
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(achieved / FP32_MATRIX_PEAK_TF, 4), "traffic": _pmc_traffic("attn_fwd_kernel"),
+            "fwd_ms": round(ms_f, 4), "bwd_ms": round(ms_b, 4)}
+
+
 def _pmc_traffic(kernel):
     """HBM bytes per launch from the committed PMC profile (profiles/r01_pmc.json), or None."""
     path = os.path.join(ROOT, "profiles", "r01_pmc.json")
@@ -268,6 +311,7 @@ def main():
         if backend == "hip":
             out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, targets))
             out["roofline_ball_query"] = ball_query_roofline(inputs)
+            out["roofline_attention"] = attention_roofline(args.batch)
         else:
             out["roofline"] = ball_query_roofline(inputs)
         if world == 1 and not args.no_cpu_baseline:
