@@ -1023,16 +1023,23 @@ struct Img {
   }
 };
 
-template <int NS, int NT>
-__global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(
+// NG = 2 (small grids, e.g. the decoder's 256 queries: 256 workgroups = ONE wave per SIMD, nothing to
+// hide a stall behind): two wave groups of a 512-thread workgroup walk the even / odd key tiles of the
+// same 64 queries with their own LDS images and merge their (o, m, l) states through LDS at the end.
+template <int NS, int NT, int NG>
+__global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
     float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
-  __shared__ __attribute__((aligned(16))) float Kimg[2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float Vimg[2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float Bias[2][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float KimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float VimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
+  const int grp = threadIdx.x / kAttnThreads;
+  float(*Kimg)[64][I::LD] = KimgG[grp];
+  float(*Vimg)[64][I::LD] = VimgG[grp];
+  float(*Bias)[64] = BiasG[grp];
+  const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const long E = (long)H * D;
@@ -1062,22 +1069,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // key tiles of this wave group: grp, grp + NG, ... (a tile past Lk stages zeros with -inf bias and
+  // contributes nothing, so both groups run the same number of iterations and barriers)
+  const int iters = ((Lk + 63) / 64 + NG - 1) / NG;
   typename I::Regs kr, vr;
   float br = 0.f;
-  I::fetch(kr, kb, E, D, 0, Lk, tid);
-  I::fetch(vr, vb, E, D, 0, Lk, tid);
-  if (tid < 64) br = key_bias(mb, tid, Lk);
+  I::fetch(kr, kb, E, D, grp * 64, Lk, tid);
+  I::fetch(vr, vb, E, D, grp * 64, Lk, tid);
+  if (tid < 64) br = key_bias(mb, grp * 64 + tid, Lk);
   I::commit(Kimg[0], kr, D, tid);
   I::commit(Vimg[0], vr, D, tid);
   if (tid < 64) Bias[0][tid] = br;
   __syncthreads();
   int cur = 0;
-  for (int key0 = 0; key0 < Lk; key0 += 64) {
-    const bool more = key0 + 64 < Lk;
+  for (int it = 0; it < iters; ++it) {
+    const int key0 = (it * NG + grp) * 64;
+    const bool more = it + 1 < iters;
     if (more) {
-      I::fetch(kr, kb, E, D, key0 + 64, Lk, tid);
-      I::fetch(vr, vb, E, D, key0 + 64, Lk, tid);
-      if (tid < 64) br = key_bias(mb, key0 + 64 + tid, Lk);
+      I::fetch(kr, kb, E, D, key0 + NG * 64, Lk, tid);
+      I::fetch(vr, vb, E, D, key0 + NG * 64, Lk, tid);
+      if (tid < 64) br = key_bias(mb, key0 + NG * 64 + tid, Lk);
     }
     if (live) {
       f32x4 st[4];
@@ -1141,6 +1152,35 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(
     __syncthreads();
     cur ^= 1;
   }
+  if constexpr (NG == 2) {
+    constexpr int kX = 4 * NT + 2;
+    float *xch = &KimgG[0][0][0][0];   // free after the loop's last barrier
+    static_assert(sizeof(float) * 256 * kX <= sizeof(KimgG[0]), "exchange area");
+    if (grp == 1 && live) {
+      float *px = xch + (wave * 64 + lane) * kX;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) px[nt * 4 + i] = o[nt][i];
+      px[4 * NT] = m;
+      px[4 * NT + 1] = l;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    if (live) {
+      const float *px = xch + (wave * 64 + lane) * kX;
+      const float m1 = px[4 * NT], l1 = px[4 * NT + 1];
+      const float m_new = fmaxf(m, m1);
+      const bool dead = m_new == kNegInf;
+      const float a0 = dead ? 1.f : __expf(m - m_new), a1 = dead ? 1.f : __expf(m1 - m_new);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[nt][i] = o[nt][i] * a0 + px[nt * 4 + i] * a1;
+      l = l * a0 + l1 * a1;
+      m = m_new;
+    }
+  }
   if (live) {
     l = quad_sum(l);
     if (qi < Lq) {
@@ -1161,18 +1201,22 @@ __global__ __launch_bounds__(kAttnThreads) void attn_fwd_kernel(
 // dQ: same walk as the forward with K and V swapping roles.  Also produces
 // delta[b,h,q] = sum_n dO[q][n] * O[q][n]  (each query row belongs to exactly one wave here) for the
 // dK/dV kernel that is launched next -- it used to be a launch of its own.
-template <int NS, int NT>
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
+template <int NS, int NT, int NG>
+__global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
     float *__restrict__ dq, long ldo, float dq_scale,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
-  __shared__ __attribute__((aligned(16))) float Kimg[2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float Vimg[2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float Bias[2][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float KimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float VimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
+  const int grp = threadIdx.x / kAttnThreads;   // key-tile group, see attn_fwd_kernel
+  float(*Kimg)[64][I::LD] = KimgG[grp];
+  float(*Vimg)[64][I::LD] = VimgG[grp];
+  float(*Bias)[64] = BiasG[grp];
+  const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const long E = (long)H * D;
@@ -1201,7 +1245,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
 #pragma unroll
     for (int s = 0; s < NS; ++s) part += gf[s] * of[s];
     my_delta = quad_sum(part);   // the four lanes of a query hold disjoint d-groups
-    if (fg == 0 && qi < Lq) delta[((long)b * H + h) * Lq + qi] = my_delta;
+    if (grp == 0 && fg == 0 && qi < Lq) delta[((long)b * H + h) * Lq + qi] = my_delta;
   }
   int kcol[NT];
   bool kok[NT];
@@ -1215,22 +1259,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // key tiles of this wave group: grp, grp + NG, ... (a tile past Lk stages zeros with -inf bias and
+  // contributes nothing, so both groups run the same number of iterations and barriers)
+  const int iters = ((Lk + 63) / 64 + NG - 1) / NG;
   typename I::Regs kr, vr;
   float br = 0.f;
-  I::fetch(kr, kb, E, D, 0, Lk, tid);
-  I::fetch(vr, vb, E, D, 0, Lk, tid);
-  if (tid < 64) br = key_bias(mb, tid, Lk);
+  I::fetch(kr, kb, E, D, grp * 64, Lk, tid);
+  I::fetch(vr, vb, E, D, grp * 64, Lk, tid);
+  if (tid < 64) br = key_bias(mb, grp * 64 + tid, Lk);
   I::commit(Kimg[0], kr, D, tid);
   I::commit(Vimg[0], vr, D, tid);
   if (tid < 64) Bias[0][tid] = br;
   __syncthreads();
   int cur = 0;
-  for (int key0 = 0; key0 < Lk; key0 += 64) {
-    const bool more = key0 + 64 < Lk;
+  for (int it = 0; it < iters; ++it) {
+    const int key0 = (it * NG + grp) * 64;
+    const bool more = it + 1 < iters;
     if (more) {
-      I::fetch(kr, kb, E, D, key0 + 64, Lk, tid);
-      I::fetch(vr, vb, E, D, key0 + 64, Lk, tid);
-      if (tid < 64) br = key_bias(mb, key0 + 64 + tid, Lk);
+      I::fetch(kr, kb, E, D, key0 + NG * 64, Lk, tid);
+      I::fetch(vr, vb, E, D, key0 + NG * 64, Lk, tid);
+      if (tid < 64) br = key_bias(mb, key0 + NG * 64 + tid, Lk);
     }
     if (live) {
       f32x4 ds[4];
@@ -1279,6 +1327,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dq_kernel(
     }
     __syncthreads();
     cur ^= 1;
+  }
+  if constexpr (NG == 2) {   // dQ is a plain sum over the key tiles: add the second group's share
+    float *xch = &KimgG[0][0][0][0];
+    static_assert(sizeof(float) * 256 * 4 * NT <= sizeof(KimgG[0]), "exchange area");
+    if (grp == 1 && live) {
+      float *px = xch + (wave * 64 + lane) * (4 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) px[nt * 4 + i] = acc[nt][i];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    if (live) {
+      const float *px = xch + (wave * 64 + lane) * (4 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[nt][i] += px[nt * 4 + i];
+    }
   }
   if (live && qi < Lq) {
     float *ob = dq + ((long)b * Lq + qi) * ldo + h * D;
@@ -1446,6 +1514,28 @@ extern "C" {
     else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<12, 3>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__);          \
   } while (0)
+// kernels with the key-group parameter: NG = 2 for grids that leave the SIMDs a single wave each
+#define ATTN_DISPATCH_G(KERNEL, split, grid, ...)                                                   \
+  do {                                                                                              \
+    if (split) {                                                                                    \
+      const dim3 blk(kAttnThreads * 2);                                                             \
+      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 2>), grid, blk, 0, s, __VA_ARGS__);             \
+      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 2>), grid, blk, 0, s, __VA_ARGS__);        \
+      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 2>), grid, blk, 0, s, __VA_ARGS__);        \
+      else hipLaunchKernelGGL((KERNEL<12, 3, 2>), grid, blk, 0, s, __VA_ARGS__);                    \
+    } else {                                                                                        \
+      const dim3 blk(kAttnThreads);                                                                 \
+      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 1>), grid, blk, 0, s, __VA_ARGS__);             \
+      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 1>), grid, blk, 0, s, __VA_ARGS__);        \
+      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 1>), grid, blk, 0, s, __VA_ARGS__);        \
+      else hipLaunchKernelGGL((KERNEL<12, 3, 1>), grid, blk, 0, s, __VA_ARGS__);                    \
+    }                                                                                               \
+  } while (0)
+static bool split_keys(const dim3 &g, int Lk) {
+  static const int forced = getenv("BUTD_ATTN_SPLIT") ? atoi(getenv("BUTD_ATTN_SPLIT")) : -1;
+  if (forced >= 0) return forced != 0 && Lk > 64;
+  return (long)g.x * g.y * g.z <= 512 && Lk >= 128;
+}
 
 int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
                        const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
@@ -1455,7 +1545,7 @@ int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
   if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((Lq + 63) / 64, H, B);
-  ATTN_DISPATCH(attn_fwd_kernel, grid, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p,
+  ATTN_DISPATCH_G(attn_fwd_kernel, split_keys(grid, Lk), grid, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p,
                 dropout_site, rng_counter);
   return (int)hipGetLastError();
 }
@@ -1472,7 +1562,7 @@ int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
   if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
-  ATTN_DISPATCH(attn_bwd_dq_kernel, gq, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq,
+  ATTN_DISPATCH_G(attn_bwd_dq_kernel, split_keys(gq, Lk), gq, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq,
                 ld_dq, dq_scale, dropout_p, dropout_site, rng_counter);
   ATTN_DISPATCH(attn_bwd_dkv_kernel, gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
                 dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter);
