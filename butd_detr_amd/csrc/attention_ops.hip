@@ -1364,19 +1364,26 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
 // through LDS images of Q and dO; tiles are NOT transposed here:  S[q][key] has C-layout
 // lane (c = key, g) -> q = 4g+i, which is the B fragment of
 // dV^T[n][key] += dO^T[n][q] P[q][key]  and  dK^T[d][key] += Q^T[d][q] dS[q][key].
-template <int NS, int NT>
-__global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(
+// NG = 2 (few key tiles: cross-attention to 80 tokens / 132 boxes is 128-192 workgroups): two wave
+// groups walk the even / odd QUERY tiles and add their dK / dV shares through LDS at the end.
+template <int NS, int NT, int NG>
+__global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ dout,
     const float *__restrict__ lse, const float *__restrict__ delta, float *__restrict__ dk,
     float *__restrict__ dv, long ldo, float p_drop, uint32_t site,
     const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
-  __shared__ __attribute__((aligned(16))) float Qimg[2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float Gimg[2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float Lse[2][64];
-  __shared__ __attribute__((aligned(16))) float Del[2][64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ __attribute__((aligned(16))) float QimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float GimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float LseG[NG][2][64];
+  __shared__ __attribute__((aligned(16))) float DelG[NG][2][64];
+  const int grp = threadIdx.x / kAttnThreads;
+  float(*Qimg)[64][I::LD] = QimgG[grp];
+  float(*Gimg)[64][I::LD] = GimgG[grp];
+  float(*Lse)[64] = LseG[grp];
+  float(*Del)[64] = DelG[grp];
+  const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int b = blockIdx.z, h = blockIdx.y;
   const long E = (long)H * D;
@@ -1422,20 +1429,24 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(
     if (tid < 64) Lse[buf][tid] = sr;
     else if (tid < 128) Del[buf][tid - 64] = sr;
   };
-  I::fetch(qr, qb, E, D, 0, Lq, tid);
-  I::fetch(gr, gb, E, D, 0, Lq, tid);
-  fetch_stats(0);
+  // query tiles of this wave group: grp, grp + NG, ... (a tile past Lq stages zeros with lse = +inf:
+  // every probability is 0, so both groups run the same number of iterations and barriers)
+  const int iters = ((Lq + 63) / 64 + NG - 1) / NG;
+  I::fetch(qr, qb, E, D, grp * 64, Lq, tid);
+  I::fetch(gr, gb, E, D, grp * 64, Lq, tid);
+  fetch_stats(grp * 64);
   I::commit(Qimg[0], qr, D, tid);
   I::commit(Gimg[0], gr, D, tid);
   commit_stats(0);
   __syncthreads();
   int cur = 0;
-  for (int qs = 0; qs < Lq; qs += 64) {
-    const bool more = qs + 64 < Lq;
+  for (int it = 0; it < iters; ++it) {
+    const int qs = (it * NG + grp) * 64;
+    const bool more = it + 1 < iters;
     if (more) {
-      I::fetch(qr, qb, E, D, qs + 64, Lq, tid);
-      I::fetch(gr, gb, E, D, qs + 64, Lq, tid);
-      fetch_stats(qs + 64);
+      I::fetch(qr, qb, E, D, qs + NG * 64, Lq, tid);
+      I::fetch(gr, gb, E, D, qs + NG * 64, Lq, tid);
+      fetch_stats(qs + NG * 64);
     }
     if (live) {
 #pragma unroll
@@ -1487,6 +1498,32 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(
     __syncthreads();
     cur ^= 1;
   }
+  if constexpr (NG == 2) {
+    float *xch = &QimgG[0][0][0][0];
+    static_assert(sizeof(float) * 256 * 8 * NT <= sizeof(QimgG[0]), "exchange area");
+    if (grp == 1 && live) {
+      float *px = xch + (wave * 64 + lane) * (8 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          px[nt * 8 + i] = ak[nt][i];
+          px[nt * 8 + 4 + i] = av[nt][i];
+        }
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    if (live) {
+      const float *px = xch + (wave * 64 + lane) * (8 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ak[nt][i] += px[nt * 8 + i];
+          av[nt][i] += px[nt * 8 + 4 + i];
+        }
+    }
+  }
   if (live && ki < Lk) {
     float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
     float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
@@ -1507,13 +1544,6 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_dkv_kernel(
 
 extern "C" {
 
-#define ATTN_DISPATCH(KERNEL, grid, ...)                                                            \
-  do {                                                                                              \
-    if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__);   \
-    else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__); \
-    else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<12, 3>), grid, dim3(kAttnThreads), 0, s, __VA_ARGS__);          \
-  } while (0)
 // kernels with the key-group parameter: NG = 2 for grids that leave the SIMDs a single wave each
 #define ATTN_DISPATCH_G(KERNEL, split, grid, ...)                                                   \
   do {                                                                                              \
@@ -1534,7 +1564,8 @@ extern "C" {
 static bool split_keys(const dim3 &g, int Lk) {
   static const int forced = getenv("BUTD_ATTN_SPLIT") ? atoi(getenv("BUTD_ATTN_SPLIT")) : -1;
   if (forced >= 0) return forced != 0 && Lk > 64;
-  return (long)g.x * g.y * g.z <= 512 && Lk >= 128;
+  static const long limit = getenv("BUTD_ATTN_SPLIT_MAX") ? atol(getenv("BUTD_ATTN_SPLIT_MAX")) : 512;
+  return (long)g.x * g.y * g.z <= limit && Lk >= 128;
 }
 
 int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
@@ -1564,7 +1595,7 @@ int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
   const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
   ATTN_DISPATCH_G(attn_bwd_dq_kernel, split_keys(gq, Lk), gq, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq,
                 ld_dq, dq_scale, dropout_p, dropout_site, rng_counter);
-  ATTN_DISPATCH(attn_bwd_dkv_kernel, gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
+  ATTN_DISPATCH_G(attn_bwd_dkv_kernel, split_keys(gk, Lq), gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
                 dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter);
   return (int)hipGetLastError();
 }
