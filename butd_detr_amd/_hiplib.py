@@ -50,7 +50,7 @@ class GemmProblem(ctypes.Structure):
                 ("a_drop_p", _c_float), ("a_drop_site", _c_u32),
                 ("b_drop_p", _c_float), ("b_drop_site", _c_u32),
                 ("col_sum", _c_void_p), ("col_sumsq", _c_void_p),
-                ("c_add", _c_int), ("c2", _c_void_p)]
+                ("c_add", _c_int), ("c2", _c_void_p), ("col_slots", _c_int), ("col_slot_stride", _c_long)]
 
 
 ATTENTION_SYMBOLS = {
@@ -68,7 +68,7 @@ _P = _c_void_p
 SA_SYMBOLS = {
     "butd_sa_group": (_c_int, [_c_int] * 5 + [_P, _P, _P, _c_long, _P, _c_float, _c_int, _P, _c_int, _P]),
     "butd_sa_colstats": (_c_int, [_c_long, _c_int, _P, _P, _P, _c_int, _P, _P, _P, _P, _P]),
-    "butd_sa_bn_finalize": (_c_int, [_c_int, _c_long, _P, _P, _P, _P, _c_float, _c_float, _c_int]
+    "butd_sa_bn_finalize": (_c_int, [_c_int, _c_long, _P, _P, _c_int, _c_long, _P, _P, _c_float, _c_float, _c_int]
                             + [_P] * 7 + [_P]),
     "butd_sa_pool_finalize": (_c_int, [_c_int] * 3 + [_P] * 10 + [_P]),
     "butd_sa_pool_bwd_stats": (_c_int, [_c_int] * 3 + [_P] * 8 + [_P]),

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmBatch batch,
         double acc = 0.0;
 #pragma unroll
         for (int r = 0; r < kRowPhases; ++r) acc += (double)red[(which * kRowPhases + r) * kBN + col];
-        if (n0 + col < pN) atomicAdd((which ? col_sumsq : col_sum) + n0 + col, acc);
+        const long slot_off = P.col_slots > 1 ? (long)(blockIdx.x & (P.col_slots - 1)) * P.col_slot_stride : 0;
+        if (n0 + col < pN) atomicAdd((which ? col_sumsq : col_sum) + slot_off + n0 + col, acc);
       }
     }
     return;
@@ -860,6 +861,7 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
     if (p.split_k > 1 && !p.accumulate) return (int)hipErrorInvalidValue;
     if ((p.col_sum != nullptr || p.c_add || p.c2 != nullptr) && (p.accumulate || p.ones_col || p.split_k > 1))
       return (int)hipErrorInvalidValue;
+    if (p.col_slots > 1 && (p.col_slots & (p.col_slots - 1))) return (int)hipErrorInvalidValue;
     if (fast_eligible(p)) fast_idx[nf++] = i; else slow_idx[ns++] = i;
   }
   int err = launch_group(problems, fast_idx, nf, true, rng_counter, (hipStream_t)stream);

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(kThreads) void sa_colstats_kernel(
 }
 
 __global__ void sa_bn_finalize_kernel(int C, long count, const double *__restrict__ sum,
-                                      const double *__restrict__ sumsq, const float *__restrict__ gamma,
+                                      const double *__restrict__ sumsq, int slots, long slot_stride,
+                                      const float *__restrict__ gamma,
                                       const float *__restrict__ beta, float eps, float momentum,
                                       int training, float *__restrict__ running_mean,
                                       float *__restrict__ running_var, int64_t *__restrict__ nbt,
@@ -126,8 +127,13 @@ __global__ void sa_bn_finalize_kernel(int C, long count, const double *__restric
   if (c >= C) return;
   float mu, var;
   if (training) {
-    const double m = sum[c] / (double)count;
-    double v = sumsq[c] / (double)count - m * m;
+    double s1 = 0.0, s2 = 0.0;
+    for (int k = 0; k < (slots > 1 ? slots : 1); ++k) {
+      s1 += sum[c + k * slot_stride];
+      s2 += sumsq[c + k * slot_stride];
+    }
+    const double m = s1 / (double)count;
+    double v = s2 / (double)count - m * m;
     if (v < 0.0) v = 0.0;
     mu = (float)m;
     var = (float)v;
@@ -374,13 +380,14 @@ int butd_sa_colstats(long P, int C, const float *Z, double *sum, double *sumsq, 
   return (int)hipGetLastError();
 }
 
-int butd_sa_bn_finalize(int C, long count, const double *sum, const double *sumsq, const float *gamma,
-                        const float *beta, float eps, float momentum, int training, float *running_mean,
+int butd_sa_bn_finalize(int C, long count, const double *sum, const double *sumsq, int slots,
+                        long slot_stride, const float *gamma, const float *beta, float eps, float momentum, int training, float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float *mean, float *rstd,
                         float *scale, float *shift, butd_stream_t stream) {
   if (C <= 0) return 0;
   hipLaunchKernelGGL(sa_bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C,
-                     count, sum, sumsq, gamma, beta, eps, momentum, training, running_mean, running_var,
+                     count, sum, sumsq, slots, slot_stride, gamma, beta, eps, momentum, training, running_mean,
+                     running_var,
                      num_batches_tracked, mean, rstd, scale, shift);
   return (int)hipGetLastError();
 }

@@ -116,7 +116,7 @@ def _ptr(t):
 def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.0, bias=None,
              bias_grad=None, scale=1.0, relu=False, accumulate=False, ones_col=False, split_k=1,
              dropout_p=0.0, site=0, a_affine=None, b_affine=None, a_drop=(0.0, 0), b_drop=(0.0, 0),
-             col_stats=None, c_add=False, c2=None):
+             col_stats=None, c_add=False, c2=None, col_slots=(0, 0)):
     asc, ash = a_affine if a_affine is not None else (None, None)
     bsc, bsh = b_affine if b_affine is not None else (None, None)
     return GemmProblem(_ptr(a), _ptr(a2), _ptr(b), _ptr(bias), _ptr(c), _ptr(bias_grad), M, N, K,
@@ -126,7 +126,7 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                        float(a_drop[0]), int(a_drop[1]), float(b_drop[0]), int(b_drop[1]),
                        _ptr(col_stats[0]) if col_stats is not None else None,
                        _ptr(col_stats[1]) if col_stats is not None else None,
-                       int(c_add), _ptr(c2))
+                       int(c_add), _ptr(c2), int(col_slots[0]), int(col_slots[1]))
 
 
 def _gemm(problems, ref):

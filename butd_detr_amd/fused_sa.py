@@ -55,7 +55,10 @@ class _SAMlpPool(torch.autograd.Function):
         _call("butd_sa_group", xyz, B, N, np_, ns, C, xyz.data_ptr(), new_xyz.data_ptr(), fptr,
               feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr(), Kp)
 
-        stats = zeros((3, 2, max(C1, C2, C3)), dtype=torch.float64, device=dev)
+        Cm = max(C1, C2, C3)
+        SLOTS = 1      # (256 slotted copies of the sums were measured for the 10^6-row layers: the
+        #                 per-tile epilogue work costs more than the separate 256-row-chunk pass)
+        stats = zeros((3, SLOTS, 2, Cm), dtype=torch.float64, device=dev)
         aff = torch.empty((3, 4, max(C1, C2, C3)), device=dev)  # per layer: mean, rstd, scale, shift
         layers = ((g1, b1, rm1, rv1, nbt1, eps1), (g2, b2, rm2, rv2, nbt2, eps2),
                   (g3, b3, rm3, rv3, nbt3, eps3))
@@ -65,23 +68,23 @@ class _SAMlpPool(torch.autograd.Function):
         for li, (Cl, w) in enumerate(zip((C1, C2, C3), ws)):
             Z = torch.empty((P, Cl), device=dev)
             last = li == 2
-            # BatchNorm sums straight from the GEMM epilogue -- while the row count is moderate: every
-            # 64-row tile ends in 2 double atomics per column on the SAME addresses, and at 10^6 rows that
-            # contention costs more than the separate streaming pass (which reduces 256 rows first)
-            in_gemm_stats = training and not last and P <= int(__import__("os").environ.get("BUTD_SA_EPI_ROWS", 131072))
+            # BatchNorm sums straight from the GEMM epilogue while the row count is moderate (every tile
+            # ends in 2 double atomics per column); the last layer's pass also takes the pooling extrema
+            in_gemm_stats = training and not last and P <= 131072
             _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff,
-                        col_stats=(stats[li, 0], stats[li, 1]) if in_gemm_stats else None)], xyz)
+                        col_stats=(stats[li, 0, 0], stats[li, 0, 1]) if in_gemm_stats else None,
+                        col_slots=(SLOTS, 2 * Cm) if in_gemm_stats else (0, 0))], xyz)
             if last:
                 zmax = torch.empty((G, Cl), device=dev)
                 zmin = torch.empty((G, Cl), device=dev)
                 amax = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
                 amin = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
             if last or (training and not in_gemm_stats):
-                _call("butd_sa_colstats", xyz, P, Cl, Z.data_ptr(), stats[li, 0].data_ptr(),
-                      stats[li, 1].data_ptr(), ns if last else 0, _p(zmax), _p(zmin), _p(amax), _p(amin))
+                _call("butd_sa_colstats", xyz, P, Cl, Z.data_ptr(), stats[li, 0, 0].data_ptr(),
+                      stats[li, 0, 1].data_ptr(), ns if last else 0, _p(zmax), _p(zmin), _p(amax), _p(amin))
             g, b, rm, rv, nbt, eps = layers[li]
-            _call("butd_sa_bn_finalize", xyz, Cl, P, stats[li, 0].data_ptr(), stats[li, 1].data_ptr(),
-                  g.data_ptr(), b.data_ptr(), float(eps), float(momentum), int(training), rm.data_ptr(),
+            _call("butd_sa_bn_finalize", xyz, Cl, P, stats[li, 0, 0].data_ptr(), stats[li, 0, 1].data_ptr(),
+                  SLOTS if in_gemm_stats else 1, 2 * Cm, g.data_ptr(), b.data_ptr(), float(eps), float(momentum), int(training), rm.data_ptr(),
                   rv.data_ptr(), _p(nbt), aff[li, 0].data_ptr(), aff[li, 1].data_ptr(),
                   aff[li, 2].data_ptr(), aff[li, 3].data_ptr())
             prev_aff = (aff[li, 2], aff[li, 3])

@@ -66,6 +66,12 @@ typedef struct {
    * tensors afterwards.  No other problem of the same launch may write C (c_add) or C2. */
   int c_add;
   float *c2;
+  /* Column statistics spread over col_slots (a power of two, 0/1 = one) copies of the sum arrays,
+   * slot s at col_sum + s * col_slot_stride: a workgroup adds into slot (its linear index mod
+   * col_slots), so 10^4..10^5 row tiles do not serialise on the same 2*N addresses; the consumer sums
+   * the slots (butd_sa_bn_finalize). */
+  int col_slots;
+  long col_slot_stride;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).

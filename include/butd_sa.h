@@ -37,11 +37,13 @@ int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const f
 int butd_sa_colstats(long P, int C, const float *Z, double *sum, double *sumsq, int pool_ns,
                      float *zmax, float *zmin, uint8_t *amax, uint8_t *amin, butd_stream_t stream);
 
-/* BatchNorm bookkeeping of one layer (training): from sum/sumsq over `count` rows ->
+/* BatchNorm bookkeeping of one layer (training): from sum/sumsq over `count` rows (given as `slots`
+ * partial copies `slot_stride` doubles apart, slots <= 1: one copy) ->
  * mean[c], rstd[c] = 1/sqrt(var_biased+eps), scale[c] = gamma*rstd, shift[c] = beta - mean*scale;
  * running_mean/var <- (1-momentum)*running + momentum*(mean / var_unbiased); num_batches_tracked += 1.
  * training == 0: scale/shift from the running statistics, nothing updated. */
-int butd_sa_bn_finalize(int C, long count, const double *sum, const double *sumsq, const float *gamma,
+int butd_sa_bn_finalize(int C, long count, const double *sum, const double *sumsq, int slots,
+                        long slot_stride, const float *gamma,
                         const float *beta, float eps, float momentum, int training, float *running_mean,
                         float *running_var, int64_t *num_batches_tracked, float *mean, float *rstd,
                         float *scale, float *shift, butd_stream_t stream);
