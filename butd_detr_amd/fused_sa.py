@@ -165,10 +165,10 @@ class _SAMlpPool(torch.autograd.Function):
             _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp)], X)
         dW1 = dW1[:, :Cin]
         Sf = S.float()
-        dgs = [Sf[l, 1, :c].contiguous() if training else None for l, c in ((0, C1), (1, C2), (2, C3))]
-        dbs = [Sf[l, 0, :c].contiguous() if training else None for l, c in ((0, C1), (1, C2), (2, C3))]
-        if not training:   # eval-mode BN: y = gamma*(z-rm)*rs+beta -> parameter grads not produced here
-            dgs = dbs = [None, None, None]
+        # S1 = sum g, S2 = sum g*zhat with zhat from the statistics the forward used (batch or running):
+        # dbeta and dgamma in training AND eval mode
+        dgs = [Sf[l, 1, :c].contiguous() for l, c in ((0, C1), (1, C2), (2, C3))]
+        dbs = [Sf[l, 0, :c].contiguous() for l, c in ((0, C1), (1, C2), (2, C3))]
         return (None, d_feats, None, None, None, None, None, None,
                 dW1.reshape(s1), dgs[0], dbs[0], None, None, None, None,
                 dW2.view(s2), dgs[1], dbs[1], None, None, None, None,
