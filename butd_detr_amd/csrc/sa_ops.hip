@@ -290,9 +290,9 @@ __global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
 }
 
 __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
-    long P, int C, float *__restrict__ dH, const float *__restrict__ Z, const float *__restrict__ scale,
-    const float *__restrict__ shift, const float *__restrict__ mean, const float *__restrict__ rstd,
-    double *__restrict__ S1, double *__restrict__ S2, int chunk) {
+    long P, int C, const float *__restrict__ dH, const float *__restrict__ Z,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ rstd, double *__restrict__ S1, double *__restrict__ S2, int chunk) {
   __shared__ float red[2][kThreads][4];
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
   for (long r = sub; r < rows; r += tpg) {
     const long o = (row0 + r) * C + cq * 4;
     const float4 z4 = *reinterpret_cast<const float4 *>(Z + o);
-    float4 g4 = *reinterpret_cast<const float4 *>(dH + o);
+    const float4 g4 = *reinterpret_cast<const float4 *>(dH + o);
     const float z[4] = {z4.x, z4.y, z4.z, z4.w};
     float g[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
@@ -316,8 +316,7 @@ __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
       if (!(sc[e] * z[e] + sh[e] > 0.f)) g[e] = 0.f;
       s1[e] += g[e];
       s2[e] += g[e] * (z[e] - mu[e]) * rs[e];
-    }
-    *reinterpret_cast<float4 *>(dH + o) = make_float4(g[0], g[1], g[2], g[3]);
+    }   // read-only pass: butd_sa_dz_mid re-derives the mask from Z instead of reading a stored g
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -339,18 +338,19 @@ __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
 
 __global__ __launch_bounds__(kThreads) void sa_dz_mid_kernel(
     long P, int C, float *__restrict__ g, const float *__restrict__ Z, const float *__restrict__ gamma,
-    const float *__restrict__ scale, const float *__restrict__ mean, const float *__restrict__ rstd,
-    const double *__restrict__ S1, const double *__restrict__ S2, int training, int chunk) {
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const double *__restrict__ S1, const double *__restrict__ S2,
+    int training, int chunk) {
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
   const long row0 = (long)blockIdx.x * chunk;
   const long rows = min((long)chunk, P - row0);
   const double invP = 1.0 / (double)P;
-  float sc[4], mu[4], rs[4], ga[4], a1[4], a2[4];
+  float sc[4], sh[4], mu[4], rs[4], ga[4], a1[4], a2[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int c = cq * 4 + e;
-    sc[e] = scale[c]; mu[e] = mean[c]; rs[e] = rstd[c]; ga[e] = gamma[c];
+    sc[e] = scale[c]; sh[e] = shift[c]; mu[e] = mean[c]; rs[e] = rstd[c]; ga[e] = gamma[c];
     a1[e] = (float)(S1[c] * invP);
     a2[e] = (float)(S2[c] * invP);
   }
@@ -358,11 +358,14 @@ __global__ __launch_bounds__(kThreads) void sa_dz_mid_kernel(
     const long o = (row0 + r) * C + cq * 4;
     const float4 z4 = *reinterpret_cast<const float4 *>(Z + o);
     const float4 g4 = *reinterpret_cast<const float4 *>(g + o);
-    const float z[4] = {z4.x, z4.y, z4.z, z4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+    const float z[4] = {z4.x, z4.y, z4.z, z4.w};
+    float gv[4] = {g4.x, g4.y, g4.z, g4.w};
     float out[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
+    for (int e = 0; e < 4; ++e) {
+      if (!(sc[e] * z[e] + sh[e] > 0.f)) gv[e] = 0.f;   // ReLU mask, as butd_sa_mask_stats applied it
       out[e] = training ? ga[e] * rs[e] * (gv[e] - a1[e] - (z[e] - mu[e]) * rs[e] * a2[e]) : sc[e] * gv[e];
+    }
     *reinterpret_cast<float4 *>(g + o) = make_float4(out[0], out[1], out[2], out[3]);
   }
 }
@@ -467,7 +470,7 @@ int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_p
   return (int)hipGetLastError();
 }
 
-int butd_sa_mask_stats(long P, int C, float *dH, const float *Z, const float *scale,
+int butd_sa_mask_stats(long P, int C, const float *dH, const float *Z, const float *scale,
                        const float *shift, const float *mean, const float *rstd, double *S1,
                        double *S2, butd_stream_t stream) {
   if (P <= 0) return 0;
@@ -480,14 +483,14 @@ int butd_sa_mask_stats(long P, int C, float *dH, const float *Z, const float *sc
 }
 
 int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, const float *scale,
-                   const float *mean, const float *rstd, const double *S1, const double *S2,
+                   const float *shift, const float *mean, const float *rstd, const double *S1, const double *S2,
                    int training, butd_stream_t stream) {
   if (P <= 0) return 0;
   if (!cols_ok(C)) return (int)hipErrorInvalidValue;
   const int chunk = chunk_rows(P);
   hipLaunchKernelGGL(sa_dz_mid_kernel, dim3((unsigned)((P + chunk - 1) / chunk)),
-                     dim3(kThreads), 0, (hipStream_t)stream, P, C, g, Z, gamma, scale, mean, rstd, S1, S2,
-                     training, chunk);
+                     dim3(kThreads), 0, (hipStream_t)stream, P, C, g, Z, gamma, scale, shift, mean, rstd,
+                     S1, S2, training, chunk);
   return (int)hipGetLastError();
 }
 

@@ -142,7 +142,7 @@ class _SAMlpPool(torch.autograd.Function):
               shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(),
               S[1, 1].data_ptr())
         _call("butd_sa_dz_mid", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), g2.data_ptr(), scale(1).data_ptr(),
-              mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
+              shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
         dZ2 = dH2
         dH1 = torch.empty((P, C1), device=dev)
         _gemm([_wgrad(dZ2, Z1, dW2, None, P, C2, C1, b_affine=(scale(0), shift(0))),
@@ -152,7 +152,7 @@ class _SAMlpPool(torch.autograd.Function):
               shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
               S[0, 1].data_ptr())
         _call("butd_sa_dz_mid", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), g1.data_ptr(), scale(0).data_ptr(),
-              mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), tr)
+              shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), tr)
         dZ1 = dH1
         d_feats = None
         if need_dfeat:

@@ -73,15 +73,16 @@ int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_p
                     const float *mean, const float *rstd, const double *S1, const double *S2,
                     int training, butd_stream_t stream);
 
-/* Hidden layers, part 1, in place on dH (P x C): g = dH * [scale*z+shift > 0];
+/* Hidden layers, part 1 (read-only pass over dH, Z (P x C)): with g = dH * [scale*z+shift > 0],
  * S1[c] += sum_p g, S2[c] += sum_p g*zhat (double, caller zero-fills). */
-int butd_sa_mask_stats(long P, int C, float *dH, const float *Z, const float *scale,
+int butd_sa_mask_stats(long P, int C, const float *dH, const float *Z, const float *scale,
                        const float *shift, const float *mean, const float *rstd, double *S1,
                        double *S2, butd_stream_t stream);
 
-/* part 2, in place on g -> dZ = gamma*rstd*(g - S1/P - zhat*S2/P)   (training == 0: dZ = scale*g). */
+/* part 2, in place on dH -> dZ = gamma*rstd*(g - S1/P - zhat*S2/P) with g re-derived from dH and Z as in
+ * part 1 (training == 0: dZ = scale*g). */
 int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, const float *scale,
-                   const float *mean, const float *rstd, const double *S1, const double *S2,
+                   const float *shift, const float *mean, const float *rstd, const double *S1, const double *S2,
                    int training, butd_stream_t stream);
 
 /* d_feats_pm[b, idx[p], c] += dX[p, 3 + c]  (dX: P rows of ldx >= 3+C floats, d_feats_pm (B,N,C)
