@@ -1,0 +1,59 @@
+"""-m gpu: the bench's multi-rank step (hipGraph replay of forward+backward -> ONE all-reduce of the packed
+gradient buffer -> hipGraph replay of clip + packed AdamW, with the sampling chain and the language model
+prefetched) run by TWO processes.  The box has one GPU, so both ranks sit on cuda:0 and talk over gloo
+(RCCL refuses two ranks on one device; the collective is the only thing that differs from the 8-GPU
+launch, torch.distributed semantics are the same).  After every step the ranks must hold bit-identical
+averaged gradients and parameters, although they train on different scenes."""
+import os
+import sys
+import tempfile
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, init_file, out_dir):
+    sys.path.insert(0, ROOT)
+    import warnings
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from butd_detr_amd.offline_text import offline_factory
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, synthetic_batch
+    dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    attention_blocks.set_backend("hip")
+    torch.manual_seed(0)                       # same initial weights on both ranks
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=32,
+                           num_decoder_layers=1, num_encoder_layers=1, self_position_embedding="loc_learned",
+                           contrastive_align_loss=True, butd=True, self_attend=True,
+                           text_encoder_factory=offline_factory(0)).to(dev).train()
+    opt = FlatAdamW(model)
+    step = GraphedTrainStep(model, opt, warmup=1)
+    batches = [synthetic_batch(2, dev, seed=11 + 5 * i, n_points=4096, tokens=16, rank=rank) for i in range(3)]
+    losses = []
+    for i, (inp, tgt) in enumerate(batches):
+        nxt = batches[i + 1][0] if i + 1 < len(batches) else None
+        losses.append(float(step(inp, tgt, next_inputs=nxt)))
+    torch.cuda.synchronize()
+    torch.save({"flat_p": opt.flat_p.cpu(), "flat_g": opt.flat_g.cpu(), "losses": losses},
+               os.path.join(out_dir, f"r{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_stay_in_lockstep():
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "init")
+        mp.spawn(_worker, args=(2, init_file, tmp), nprocs=2, join=True)
+        r0, r1 = (torch.load(os.path.join(tmp, f"r{r}.pt")) for r in (0, 1))
+    assert r0["losses"] != r1["losses"]                     # different scenes per rank
+    assert torch.equal(r0["flat_g"], r1["flat_g"])          # identical averaged gradients
+    assert torch.equal(r0["flat_p"], r1["flat_p"])          # identical parameters after the updates
+    assert torch.isfinite(r0["flat_p"]).all()
