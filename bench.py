@@ -49,16 +49,10 @@ def build_model(args, device):
     from butd_detr_amd import attention_blocks
     from butd_detr_amd.bdetr import BeaUTyDETR
     from butd_detr_amd.offline_text import offline_factory
-    backend = args.backend
-    if backend == "auto":
-        try:
-            attention_blocks.set_backend("hip")
-            backend = "hip"
-        except Exception:
-            attention_blocks.set_backend("torch")
-            backend = "torch"
-    else:
-        attention_blocks.set_backend(backend)
+    # "auto" IS the hand-written gfx950 path: a missing / incomplete HIP library raises here (no silent
+    # fallback); the stock-torch blocks only run when asked for by name (--backend torch, the A/B leg)
+    backend = "hip" if args.backend == "auto" else args.backend
+    attention_blocks.set_backend(backend)
     torch.manual_seed(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
