@@ -249,12 +249,10 @@ class GraphedTrainStep:
         self._announced = None
         self._tok_cache = None
         self.arena = None
-        if zero_arena:
-            try:
-                from .fused_attention import ZeroArena
-                self.arena = ZeroArena(next(model.parameters()).device)
-            except Exception:       # torch backend without the HIP library: stock zero fills
-                self.arena = None
+        from . import attention_blocks
+        if zero_arena and attention_blocks.get_backend() == "hip":   # only the fused blocks draw from it
+            from .fused_attention import ZeroArena
+            self.arena = ZeroArena(next(model.parameters()).device)
         self.flat_opt = isinstance(optimizer, FlatAdamW)
         self.flat = (_OptimizerGradients(optimizer) if self.flat_opt else
                      FlatGradients([p for g in optimizer.param_groups for p in g["params"]]))
