@@ -67,6 +67,7 @@ ATTENTION_SYMBOLS = {
 _P = _c_void_p
 SA_SYMBOLS = {
     "butd_sa_group": (_c_int, [_c_int] * 5 + [_P, _P, _P, _c_long, _P, _c_float, _c_int, _P, _c_int, _P]),
+    "butd_sa_thin_conv": (_c_int, [_c_long, _c_int, _c_int, _P, _c_int, _P, _P, _P, _P, _P]),
     "butd_sa_colstats": (_c_int, [_c_long, _c_int, _P, _P, _P, _c_int, _P, _P, _P, _P, _P]),
     "butd_sa_bn_finalize": (_c_int, [_c_int, _c_long, _P, _P, _c_int, _c_long, _P, _P, _c_float, _c_float, _c_int]
                             + [_P] * 7 + [_P]),

@@ -149,6 +149,61 @@ __global__ __launch_bounds__(kThreads) void sa_colstats_kernel(
   }
 }
 
+// ------------------------------------------------------------------ first layer of SA1 (thin input)
+// Z[p, c] = sum_k X[p, k] * W[c, k] for K <= 8 input channels (xyz + colour + padding) and the column
+// sums of Z in the same pass.  As a 64x64-tile GEMM this product is one mostly-empty K slab per tile
+// (140 us for 10^6 rows, plus 128 us for the separate statistics pass); it is a pure HBM stream:
+// 32 B in, 4*C B out per row.
+__global__ __launch_bounds__(kThreads) void sa_thin_conv_kernel(
+    long P, int C, int K, const float *__restrict__ X, int ldx, const float *__restrict__ W,
+    float *__restrict__ Z, double *__restrict__ sum, double *__restrict__ sumsq, int chunk) {
+  __shared__ float red[2][kThreads][4];
+  const int c4n = C >> 2, tpg = kThreads / c4n;
+  const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
+  const long row0 = (long)blockIdx.x * chunk;
+  const long rows = min((long)chunk, P - row0);
+  float w[4][8];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w[e][k] = k < K ? W[(long)(cq * 4 + e) * K + k] : 0.f;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+  for (long r = sub; r < rows; r += tpg) {
+    const float *xr = X + (row0 + r) * ldx;
+    const float4 x0 = *reinterpret_cast<const float4 *>(xr);
+    const float4 x1 = *reinterpret_cast<const float4 *>(xr + 4);
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    float z[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += x[k] * w[e][k];
+      z[e] = a;
+      s[e] += a;
+      q[e] += a * a;
+    }
+    *reinterpret_cast<float4 *>(Z + (row0 + r) * C + cq * 4) = make_float4(z[0], z[1], z[2], z[3]);
+  }
+  if (sum == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[0][threadIdx.x][e] = s[e];
+    red[1][threadIdx.x][e] = q[e];
+  }
+  __syncthreads();
+  if (threadIdx.x < C) {
+    const int cq2 = threadIdx.x >> 2, e = threadIdx.x & 3;
+    double a = 0.0, b = 0.0;
+    for (int t = 0; t < tpg; ++t) {
+      a += (double)red[0][cq2 + t * c4n][e];
+      b += (double)red[1][cq2 + t * c4n][e];
+    }
+    atomicAdd(sum + threadIdx.x, a);
+    atomicAdd(sumsq + threadIdx.x, b);
+  }
+}
+
 __global__ void sa_bn_finalize_kernel(int C, long count, const double *__restrict__ sum,
                                       const double *__restrict__ sumsq, int slots, long slot_stride,
                                       const float *__restrict__ gamma,
@@ -403,6 +458,17 @@ int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const f
   if (total <= 0) return 0;
   hipLaunchKernelGGL(sa_group_kernel, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream,
                      N, np, ns, C, xyz, new_xyz, feats, feat_stride, idx, radius, normalize, X, ldx, total);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_thin_conv(long P, int C, int K, const float *X, int ldx, const float *W, float *Z,
+                      double *sum, double *sumsq, butd_stream_t stream) {
+  if (P <= 0) return 0;
+  if (!cols_ok(C) || K < 1 || K > 8 || ldx != 8 || ((sum == nullptr) != (sumsq == nullptr)))
+    return (int)hipErrorInvalidValue;
+  const int chunk = chunk_rows(P);
+  hipLaunchKernelGGL(sa_thin_conv_kernel, dim3((unsigned)((P + chunk - 1) / chunk)), dim3(kThreads), 0,
+                     (hipStream_t)stream, P, C, K, X, ldx, W, Z, sum, sumsq, chunk);
   return (int)hipGetLastError();
 }
 

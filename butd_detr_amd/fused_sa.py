@@ -71,9 +71,16 @@ class _SAMlpPool(torch.autograd.Function):
             # BatchNorm sums straight from the GEMM epilogue while the row count is moderate (every tile
             # ends in 2 double atomics per column); the last layer's pass also takes the pooling extrema
             in_gemm_stats = training and not last and P <= 131072
-            _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff,
-                        col_stats=(stats[li, 0, 0], stats[li, 0, 1]) if in_gemm_stats else None,
-                        col_slots=(SLOTS, 2 * Cm) if in_gemm_stats else (0, 0))], xyz)
+            thin = li == 0 and Kp == 8      # SA1: xyz + colour -> one HBM pass does the product AND the sums
+            if thin:
+                _call("butd_sa_thin_conv", xyz, P, Cl, Kp, X.data_ptr(), Kp, w.data_ptr(), Z.data_ptr(),
+                      stats[li, 0, 0].data_ptr() if training else None,
+                      stats[li, 0, 1].data_ptr() if training else None)
+                in_gemm_stats = training
+            else:
+                _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff,
+                            col_stats=(stats[li, 0, 0], stats[li, 0, 1]) if in_gemm_stats else None,
+                            col_slots=(SLOTS, 2 * Cm) if in_gemm_stats else (0, 0))], xyz)
             if last:
                 zmax = torch.empty((G, Cl), device=dev)
                 zmin = torch.empty((G, Cl), device=dev)

@@ -30,6 +30,13 @@ int butd_sa_group(int B, int N, int np, int ns, int C, const float *xyz, const f
                   const float *feats, long feat_stride, const int *idx, float radius, int normalize,
                   float *X, int ldx, butd_stream_t stream);
 
+/* First shared-MLP layer on a THIN grouped input (K <= 8 channels: SA1's xyz + colour): Z[p,c] =
+ * sum_k X[p,k]*W[c,k] (X rows of exactly 8 floats, columns K..7 zero; W (C,K) row-major; no bias) and,
+ * when sum/sumsq != NULL, the BatchNorm column sums of Z (double atomics, caller zero-fills) in the same
+ * HBM pass.  Replaces a one-slab GEMM + butd_sa_colstats for this layer. */
+int butd_sa_thin_conv(long P, int C, int K, const float *X, int ldx, const float *W, float *Z,
+                      double *sum, double *sumsq, butd_stream_t stream);
+
 /* Column statistics of Z (P x C): sum[c] += sum_p z, sumsq[c] += sum_p z^2 (double, atomically
  * accumulated: caller zero-fills).  If pool_ns > 0 also the per-group (pool_ns consecutive rows)
  * extrema of every column: zmax/zmin (P/pool_ns x C) and the row offset inside the group of their
