@@ -1,0 +1,88 @@
+"""-m gpu: butd_gemm_grouped on randomly drawn problems -- all three operand layouts (forward, data
+gradient, weight gradient), ragged sizes, bias / ReLU / scale epilogues, per-channel affine prologues,
+split-K accumulation with the ones-column bias gradient, c_add / c2 accumulation, column statistics --
+against float64 torch.matmul.  Sizes straddle the tile-configuration thresholds (32x32 vs 64x64 tiles,
+fast vs generic instantiation)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol=2e-4, what=""):
+    a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+    scale = max(np.abs(b).max(), 1e-6)
+    err = np.abs(a - b).max() / scale
+    assert err <= tol, f"{what}: {err:.3e}"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_group(seed):
+    from butd_detr_amd import fused_attention as fa
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    r = lambda *s: torch.randn(*s, device=dev, generator=g)
+    probs, checks, descr, keep = [], [], [], []   # keep: the problems hold raw pointers, not references
+    for _ in range(int(rng.integers(1, 5))):
+        kind = rng.choice(["fwd", "dgrad", "wgrad"])
+        M = int(rng.choice([1, 7, 33, 64, 100, 257, 640, 2048, 5000]))
+        N = int(rng.choice([3, 4, 32, 64, 100, 132, 288]))
+        K = int(rng.choice([3, 6, 8, 36, 64, 131, 132, 288]))
+        descr.append((str(kind), M, N, K))
+        if kind == "fwd":
+            x, w, y = r(M, K), r(N, K), torch.full((M, N), float("nan"), device=dev)
+            bias = r(N) if rng.random() < 0.5 else None
+            relu = bool(rng.random() < 0.3)
+            scale = float(rng.choice([1.0, 0.5]))
+            aff = (torch.rand(K, device=dev, generator=g) + 0.5, r(K)) if rng.random() < 0.3 else None
+            c_add = bool(rng.random() < 0.3)
+            c2 = r(M, N) if rng.random() < 0.3 else None
+            stats = torch.zeros(2, N, dtype=torch.float64, device=dev) if (rng.random() < 0.3) else None
+            if c_add:
+                y = r(M, N)
+            y0, c20 = y.clone(), None if c2 is None else c2.clone()
+            keep += [x, w, y, bias, aff, c2, stats]
+            probs.append(fa._fwd(x, w, y, M, N, K, bias=bias, relu=relu, scale=scale, a_affine=aff, c_add=c_add,
+                                 c2=c2, col_stats=None if stats is None else (stats[0], stats[1])))
+            xa = x.double() if aff is None else torch.relu(x.double() * aff[0].double() + aff[1].double())
+            ref = xa @ w.double().t()
+            if bias is not None:
+                ref = ref + bias.double()
+            ref = ref * scale
+            if relu:
+                ref = torch.relu(ref)
+
+            def check(y=y, ref=ref, c_add=c_add, y0=y0, c2=c2, c20=c20, stats=stats):
+                _close(y, ref + y0.double() if c_add else ref)
+                if c2 is not None:
+                    _close(c2, c20.double() + ref)
+                if stats is not None:
+                    _close(stats[0], ref.sum(0), 1e-3)
+                    _close(stats[1], (ref * ref).sum(0), 1e-3)
+            checks.append(check)
+        elif kind == "dgrad":
+            dy, w, dx = r(M, N), r(N, K), torch.full((M, K), float("nan"), device=dev)
+            keep += [dy, w, dx]
+            probs.append(fa._dgrad(dy, w, dx, M, N, K))
+            checks.append(lambda dx=dx, dy=dy, w=w: _close(dx, dy.double() @ w.double()))
+        else:
+            dy, x = r(M, N), r(M, K)
+            dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
+            with_bias = bool(rng.random() < 0.6)
+            keep += [dy, x, dw, db]
+            probs.append(fa._wgrad(dy, x, dw, db if with_bias else None, M, N, K))
+
+            def check(dw=dw, db=db, dy=dy, x=x, with_bias=with_bias):
+                _close(dw, dy.double().t() @ x.double(), 5e-4)
+                if with_bias:
+                    _close(db, dy.double().sum(0), 5e-4)
+            checks.append(check)
+    fa._gemm(probs, torch.empty(1, device=dev))
+    torch.cuda.synchronize()
+    for c, d in zip(checks, descr):
+        try:
+            c()
+        except AssertionError as e:
+            raise AssertionError(f"{d} (group {descr}): {e}") from None
