@@ -25,6 +25,8 @@ POINTNET2_SYMBOLS = {
     "butd_gather_points": (_c_int, [_c_int] * 4 + [_c_void_p] * 4),
     "butd_gather_points_grad": (_c_int, [_c_int] * 4 + [_c_void_p] * 4),
     "butd_ball_query": (_c_int, [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 4),
+    "butd_ball_query_workspace_bytes": (_c_size_t, [_c_int] * 3),
+    "butd_ball_query_ws": (_c_int, [_c_int] * 3 + [_c_float, _c_int] + [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
     "butd_group_points": (_c_int, [_c_int] * 5 + [_c_void_p] * 4),
     "butd_group_points_grad": (_c_int, [_c_int] * 5 + [_c_void_p] * 4),
     "butd_three_nn": (_c_int, [_c_int] * 3 + [_c_void_p] * 5),

@@ -25,6 +25,7 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE,
 TU_FLAGS = {
     "pointnet2_ops.hip": ["-ffp-contract=off"],
     "fps_pruned.hip": ["-ffp-contract=off"],
+    "ball_query_grid.hip": ["-ffp-contract=off"],
     "attention_ops.hip": [],
 }
 

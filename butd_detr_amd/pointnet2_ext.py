@@ -126,8 +126,17 @@ def ball_query(new_xyz, xyz, radius, nsample):
     n = xyz.size(1)
     nsample = int(nsample)
     idx = torch.empty((b, m, nsample), dtype=torch.int32, device=new_xyz.device)
-    _run("butd_ball_query", new_xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(),
-         xyz.data_ptr(), idx.data_ptr())
+    lib = _hiplib.load()
+    ws_bytes = int(lib.butd_ball_query_workspace_bytes(b, n, m))
+    if ws_bytes:  # large clouds: the grid-pruned path (same indices, bit for bit)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=new_xyz.device)
+        with torch.cuda.device(new_xyz.device):
+            err = lib.butd_ball_query_ws(b, n, m, float(radius), nsample, new_xyz.data_ptr(), xyz.data_ptr(),
+                                         idx.data_ptr(), ws.data_ptr(), ws_bytes, _stream(new_xyz))
+        _hiplib.check(err, "butd_ball_query_ws")
+    else:
+        _run("butd_ball_query", new_xyz, b, n, m, float(radius), nsample, new_xyz.data_ptr(),
+             xyz.data_ptr(), idx.data_ptr())
     return idx
 
 

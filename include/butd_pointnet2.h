@@ -72,6 +72,16 @@ int butd_gather_points_grad(int b, int c, int n, int npoints, const float *grad_
 int butd_ball_query(int b, int n, int m, float radius, int nsample, const float *new_xyz,
                     const float *xyz, int *idx, butd_stream_t stream);
 
+/* Spatially pruned variant for large clouds (uniform grid + per-centre hit bitmap; same results, bit for
+ * bit).  butd_ball_query_workspace_bytes: bytes of device workspace it wants for (b, n, m), 0 = the
+ * streaming kernel is the better one for this shape.  butd_ball_query_ws takes the pruned path whenever
+ * the workspace is 16-byte aligned and holds >= 24*b*n + 264192*b bytes and n <= 2^18; otherwise it is
+ * butd_ball_query. */
+size_t butd_ball_query_workspace_bytes(int b, int n, int m);
+int butd_ball_query_ws(int b, int n, int m, float radius, int nsample, const float *new_xyz,
+                       const float *xyz, int *idx, void *workspace, size_t workspace_bytes,
+                       butd_stream_t stream);
+
 /* Replaces group_points_kernel_wrapper (src/group_points.cpp:9-11, group_points_gpu.cu:35-44).
  * points (b,c,n), idx (b,npoints,nsample) -> out (b,c,npoints,nsample). */
 int butd_group_points(int b, int c, int n, int npoints, int nsample, const float *points,
