@@ -102,11 +102,16 @@ MLP_SYMBOLS = {
     "butd_mlp_bn_relu_apply": (_c_int, [_c_long, _c_int, _c_long, _P, _P, _P, _P, _P]),
 }
 
+LSAP_SYMBOLS = {
+    "butd_hungarian_match": (_c_int, [_c_int] * 3 + [_P] * 4 + [_P]),
+}
+
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
 ALL_SYMBOLS.update(ATTENTION_SYMBOLS)
 ALL_SYMBOLS.update(SA_SYMBOLS)
 ALL_SYMBOLS.update(OPTIM_SYMBOLS)
 ALL_SYMBOLS.update(MLP_SYMBOLS)
+ALL_SYMBOLS.update(LSAP_SYMBOLS)
 
 _lib = None
 

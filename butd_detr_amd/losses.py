@@ -1,0 +1,370 @@
+"""The reference's training criterion (models/losses.py) without its host round trips.
+
+Reference flow (losses.py:546-617, 516-543, 257-331): for each of the 7 prefixes (proposal, 5 intermediate
+heads, last) build the (B*Q, sum n_b) cost matrix, move it to the host (`.cpu()`: a device sync), run
+scipy's linear_sum_assignment once per scene, move the index lists back, gather/scatter with them
+(data-dependent shapes), and `.item()` the all-reduced box count: 7 stalls per step that no hipGraph can
+hold.  This module computes the same numbers with STATIC shapes and no synchronisation:
+
+* targets stay in their padded (B, G) slots with `box_label_mask` as a validity mask (ascending slot order
+  = the reference's compacted order);
+* the cost tensors of all prefixes are built at once in the (P, B, G, Q) orientation (the transpose scipy
+  solves internally) and every (prefix, scene) problem is solved on the device by one wavefront
+  (`butd_hungarian_match`, include/butd_lsap.h) -> `match (P, B, G)`: query of every valid slot, -1 else;
+* the four loss terms are masked dense expressions of `match` evaluated once on the stacked (P, B, Q, .)
+  head outputs; the box count stays a device scalar (all-reduced as a tensor under torch.distributed).
+
+Public names mirror the reference so `train_dist_mod.py`'s calls read the same: `HungarianMatcher`
+(:226), `SetCriterion` (:334), `compute_hungarian_loss` (:546), `compute_points_obj_cls_loss_hard_topk`
+(:161), `generalized_box_iou3d` (:70), `box_cxcyczwhd_to_xyzxyz` (:27), `SigmoidFocalClassificationLoss`
+(:94).  The list-of-dict `targets` API of the reference is kept on `HungarianMatcher.forward` /
+`SetCriterion.forward` (it has to build Python lists, so it synchronises); the dense entry points are what
+the step uses.  The assignment has no CPU fallback: without the HIP library the matcher raises.
+"""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import _hiplib
+
+PREFIX_ORDER_DOC = "['proposal_', 'last_', '0head_', ..., f'{L-2}head_'] (losses.py:549-550)"
+
+
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+# ------------------------------------------------------------------------------------------ boxes
+def box_cxcyczwhd_to_xyzxyz(x):
+    """(..., 6) centre + size -> (..., 6) min / max corners, sizes clamped at 1e-6 (losses.py:27-37)."""
+    c, s = x[..., :3], torch.clamp(x[..., 3:], min=1e-6)
+    return torch.cat([c - 0.5 * s, c + 0.5 * s], dim=-1)
+
+
+def _volume(b):
+    return (b[..., 3] - b[..., 0]) * (b[..., 4] - b[..., 1]) * (b[..., 5] - b[..., 2])
+
+
+def _giou_broadcast(a, b):
+    """Generalised IoU of corner boxes with broadcasting leading dims (losses.py:40-91 arithmetic)."""
+    lo = torch.maximum(a[..., :3], b[..., :3])
+    hi = torch.minimum(a[..., 3:], b[..., 3:])
+    edge = torch.clamp(hi - lo, min=0)
+    inter = edge[..., 0] * edge[..., 1] * edge[..., 2]
+    union = _volume(a) + _volume(b) - inter
+    iou = inter / union
+    hull = torch.clamp(torch.maximum(a[..., 3:], b[..., 3:]) - torch.minimum(a[..., :3], b[..., :3]), min=0)
+    vol = hull[..., 0] * hull[..., 1] * hull[..., 2]
+    return iou - (vol - union) / vol
+
+
+def generalized_box_iou3d(boxes1, boxes2):
+    """(N, 6), (M, 6) corner boxes -> (N, M) pairwise GIoU (losses.py:70-91)."""
+    return _giou_broadcast(boxes1[:, None, :], boxes2[None, :, :])
+
+
+# ------------------------------------------------------------------------------------------ focal
+class SigmoidFocalClassificationLoss(nn.Module):
+    """losses.py:94-158 (Group-Free's sigmoid focal loss)."""
+
+    def __init__(self, gamma=2.0, alpha=0.25):
+        super().__init__()
+        self.alpha, self.gamma = alpha, gamma
+
+    @staticmethod
+    def sigmoid_cross_entropy_with_logits(input, target):
+        return torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-torch.abs(input)))
+
+    def forward(self, input, target, weights):
+        p = torch.sigmoid(input)
+        alpha_weight = target * self.alpha + (1 - target) * (1 - self.alpha)
+        pt = target * (1.0 - p) + (1.0 - target) * p
+        loss = alpha_weight * torch.pow(pt, self.gamma) * self.sigmoid_cross_entropy_with_logits(input, target)
+        loss = loss.squeeze(-1)
+        assert weights.dim() == loss.dim()
+        return loss * weights
+
+
+def compute_points_obj_cls_loss_hard_topk(end_points, topk):
+    """Seed objectness loss (losses.py:161-223): the `topk` seeds closest (size-normalised) to each valid
+    ground-truth centre among the seeds that belong to that object are positives."""
+    mask = end_points["box_label_mask"]                                  # (B, G)
+    seed_inds = end_points["seed_inds"].long()                           # (B, K)
+    seed_xyz = end_points["seed_xyz"]                                    # (B, K, 3)
+    logits = end_points["seeds_obj_cls_logits"]                          # (B, 1, K)
+    gt_center = end_points["center_label"][:, :, :3]
+    gt_size = end_points["size_gts"][:, :, :3]
+    B, K, G = gt_center.shape[0], seed_xyz.shape[1], gt_center.shape[1]
+
+    seed_obj = torch.gather(end_points["point_instance_label"], 1, seed_inds)  # (B, K), < 0 = background
+    owner = torch.where(seed_obj < 0, torch.full_like(seed_obj, G - 1), seed_obj)
+    owned = owner[:, None, :] == torch.arange(G, device=owner.device)[None, :, None]  # (B, G, K)
+    delta = (seed_xyz[:, None, :, :] - gt_center[:, :, None, :]) / (gt_size[:, :, None, :] + 1e-6)
+    d = torch.sqrt(torch.sum(delta ** 2, dim=-1) + 1e-6)                # (B, G, K)
+    d = torch.where(owned, d, torch.full_like(d, 100.0))
+    near = torch.topk(d, topk, largest=False)[1]                         # (B, G, topk)
+    near = torch.where(mask[:, :, None] > 0, near, torch.full_like(near, K))  # padded boxes -> spare column
+    label = torch.zeros((B, K + 1), dtype=torch.long, device=seed_xyz.device)
+    label.scatter_(1, near.reshape(B, -1), 1)
+    label = label[:, :K] * (seed_obj >= 0).long()
+
+    weights = torch.full((B, K), 1.0 / max(K, 1), device=seed_xyz.device)
+    loss = SigmoidFocalClassificationLoss()(logits.reshape(B, K, 1), label.unsqueeze(-1).float(), weights)
+    return loss.sum() / B
+
+
+# ------------------------------------------------------------------------------------------ matcher
+def hungarian_match(cost, valid):
+    """cost (..., G, Q) fp32 CUDA, valid (..., G) bool/uint8 -> match (..., G) int32 (-1 = not a target)
+    and status (...) int32 (include/butd_lsap.h).  Asynchronous on the current stream."""
+    if not cost.is_cuda:
+        raise RuntimeError("hungarian_match: CPU not supported (the assignment runs in butd_hungarian_match)")
+    lead, (G, Q) = cost.shape[:-2], cost.shape[-2:]
+    cost = cost.detach().contiguous().float()
+    valid_u8 = valid.expand(*lead, G).to(torch.uint8).contiguous()
+    count = 1
+    for s in lead:
+        count *= s
+    match = torch.empty((*lead, G), dtype=torch.int32, device=cost.device)
+    status = torch.empty(lead, dtype=torch.int32, device=cost.device)
+    lib = _hiplib.load()
+    with torch.cuda.device(cost.device):
+        err = lib.butd_hungarian_match(count, Q, G, cost.data_ptr(), valid_u8.data_ptr(), match.data_ptr(),
+                                       status.data_ptr(), torch.cuda.current_stream(cost.device).cuda_stream)
+    _hiplib.check(err, "butd_hungarian_match")
+    return match, status
+
+
+class HungarianMatcher(nn.Module):
+    """losses.py:226-331.  `match_dense` is the synchronisation-free form; `forward` keeps the reference's
+    (outputs, list-of-dict targets) -> list of (index_i, index_j) contract."""
+
+    def __init__(self, cost_class=1, cost_bbox=5, cost_giou=2, soft_token=False):
+        super().__init__()
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0
+        self.cost_class, self.cost_bbox, self.cost_giou = cost_class, cost_bbox, cost_giou
+        self.soft_token = soft_token
+
+    @torch.no_grad()
+    def cost(self, pred_logits, pred_boxes, tgt_boxes, positive_map, labels=None):
+        """pred_logits (..., B, Q, C), pred_boxes (..., B, Q, 6), tgt_boxes (B, G, 6), positive_map
+        (B, G, C') -> C (..., B, G, Q): losses.py:285-312 for every target slot."""
+        prob = pred_logits.softmax(-1)
+        if self.soft_token:
+            pm = positive_map[..., :prob.shape[-1]] if positive_map.shape[-1] != prob.shape[-1] else positive_map
+            cost_class = -torch.matmul(pm, prob.transpose(-1, -2))                        # (..., B, G, Q)
+        else:
+            idx = labels.long()[..., :, None].expand(*prob.shape[:-2], labels.shape[-1], prob.shape[-2])
+            cost_class = -torch.gather(prob.transpose(-1, -2), -2, idx)
+        cost_bbox = (tgt_boxes[..., :, None, :] - pred_boxes[..., None, :, :]).abs().sum(-1)
+        cost_giou = -_giou_broadcast(box_cxcyczwhd_to_xyzxyz(tgt_boxes)[..., :, None, :],
+                                     box_cxcyczwhd_to_xyzxyz(pred_boxes)[..., None, :, :])
+        return self.cost_bbox * cost_bbox + self.cost_class * cost_class + self.cost_giou * cost_giou
+
+    @torch.no_grad()
+    def match_dense(self, pred_logits, pred_boxes, tgt_boxes, positive_map, valid, labels=None):
+        return hungarian_match(self.cost(pred_logits, pred_boxes, tgt_boxes, positive_map, labels), valid)[0]
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        tgt_boxes, pm, labels, valid = _pad_targets(targets, outputs["pred_logits"].shape[-1])
+        match = self.match_dense(outputs["pred_logits"], outputs["pred_boxes"], tgt_boxes, pm, valid, labels)
+        return _match_to_indices(match, valid)
+
+
+def _pad_targets(targets, n_class):
+    """list of {'labels' (n,), 'boxes' (n,6), 'positive_map' (n,C)} -> padded (B,G,.) tensors + mask."""
+    G = max(1, max(len(t["boxes"]) for t in targets))
+    dev = targets[0]["boxes"].device
+    B = len(targets)
+    boxes = torch.zeros((B, G, 6), device=dev)
+    boxes[..., 3:] = 1.0
+    width = targets[0]["positive_map"].shape[-1] if "positive_map" in targets[0] else n_class
+    pm = torch.zeros((B, G, width), device=dev)
+    labels = torch.zeros((B, G), dtype=torch.long, device=dev)
+    valid = torch.zeros((B, G), dtype=torch.bool, device=dev)
+    for b, t in enumerate(targets):
+        n = len(t["boxes"])
+        boxes[b, :n] = t["boxes"]
+        if "positive_map" in t:
+            pm[b, :n] = t["positive_map"]
+        labels[b, :n] = t["labels"]
+        valid[b, :n] = True
+    return boxes, pm, labels, valid
+
+
+def _match_to_indices(match, valid):
+    """match (B, G) -> the reference's list of (queries ascending, targets) int64 CPU pairs."""
+    out = []
+    match, valid = match.cpu(), valid.cpu()
+    for b in range(match.shape[0]):
+        slots = torch.nonzero(valid[b]).flatten()
+        q = match[b, slots].long()
+        order = torch.argsort(q)
+        compact = torch.arange(len(slots))
+        out.append((q[order], compact[order]))
+    return out
+
+
+# ------------------------------------------------------------------------------------------ criterion
+class SetCriterion(nn.Module):
+    """losses.py:334-543 on dense targets.  `losses` is the reference's list: any of 'boxes', 'labels',
+    'contrastive_align'."""
+
+    def __init__(self, matcher, losses={}, eos_coef=0.1, temperature=0.07):
+        super().__init__()
+        self.matcher, self.eos_coef, self.losses, self.temperature = matcher, eos_coef, losses, temperature
+
+    # -- helpers: rows of a (P, B, Q+1, .) tensor addressed by target slot; invalid slots hit the spare row Q
+    def _scatter_rows(self, base, match, valid, rows):
+        """base (P,B,Q,W) <- rows (B,G,W) [or (P,B,G,W)] at query match[p,b,g] for valid slots."""
+        P, B, Q, W = base.shape
+        idx = torch.where(valid, match.long(), torch.full_like(match, Q, dtype=torch.long))  # (P,B,G)
+        padded = torch.cat([base, base.new_zeros(P, B, 1, W)], dim=2)
+        src = rows if rows.dim() == 4 else rows[None].expand(P, -1, -1, -1)
+        padded = padded.scatter(2, idx[..., None].expand(-1, -1, -1, W), src.to(base.dtype))
+        return padded[:, :, :Q]
+
+    def _matched_mask(self, match, valid, Q):
+        P, B, G = match.shape
+        idx = torch.where(valid, match.long(), torch.full_like(match, Q, dtype=torch.long))
+        m = torch.zeros((P, B, Q + 1), dtype=torch.bool, device=match.device)
+        return m.scatter(2, idx, torch.ones_like(idx, dtype=torch.bool))[:, :, :Q]
+
+    def loss_labels_st(self, out, tgt, match, num_boxes):
+        logits = out["pred_logits"].log_softmax(-1)                               # (P,B,Q,C)
+        P, B, Q, C = logits.shape
+        valid = tgt["valid"][None].expand(P, -1, -1)
+        target_sim = torch.zeros_like(logits)
+        target_sim[..., -1] = 1
+        target_sim = self._scatter_rows(target_sim, match, valid, tgt["positive_map"][..., :C])
+        entropy = torch.log(target_sim + 1e-6) * target_sim
+        loss_ce = (entropy - logits * target_sim).sum(-1)                         # (P,B,Q)
+        matched = self._matched_mask(match, valid, Q)
+        weight = torch.where(matched, torch.ones_like(loss_ce), torch.full_like(loss_ce, self.eos_coef))
+        return {"loss_ce": (loss_ce * weight).sum((1, 2)) / num_boxes}
+
+    def loss_boxes(self, out, tgt, match, num_boxes):
+        P = match.shape[0]
+        valid = tgt["valid"][None].expand(P, -1, -1)
+        idx = match.long().clamp(min=0)
+        src = torch.gather(out["pred_boxes"], 2, idx[..., None].expand(-1, -1, -1, 6))   # (P,B,G,6)
+        box = tgt["boxes"][None].expand(P, -1, -1, -1)
+        l1 = (src[..., :3] - box[..., :3]).abs().sum(-1) + 0.2 * (src[..., 3:] - box[..., 3:]).abs().sum(-1)
+        zero = torch.zeros_like(l1)
+        giou = _giou_broadcast(box_cxcyczwhd_to_xyzxyz(src), box_cxcyczwhd_to_xyzxyz(box))
+        return {"loss_bbox": torch.where(valid, l1, zero).sum((1, 2)) / num_boxes,
+                "loss_giou": torch.where(valid, 1 - giou, zero).sum((1, 2)) / num_boxes}
+
+    def loss_contrastive_align(self, out, tgt, match, num_boxes):
+        tok, que = out["proj_tokens"], out["proj_queries"]                        # (B,L,D), (P,B,Q,D)
+        logits = torch.matmul(que, tok.transpose(-1, -2)) / self.temperature      # (P,B,Q,L)
+        P, B, Q, L = logits.shape
+        valid = tgt["valid"][None].expand(P, -1, -1)
+        # 'not mentioned': the last two real tokens (python indexing: -1 wraps to the last column)
+        inds = out["tokenized"]["attention_mask"].to(logits.device).sum(1) - 1    # (B,)
+        cols = torch.arange(L, device=logits.device)[None, :]
+        base = ((cols == inds[:, None]) | (cols == torch.remainder(inds[:, None] - 1, L))).to(logits.dtype) * 0.5
+        pmap = base[None, :, None, :].expand(P, -1, Q, -1)
+        pm_rows = tgt["positive_map"][..., :L]
+        if pm_rows.shape[-1] < L:
+            pm_rows = torch.nn.functional.pad(pm_rows, (0, L - pm_rows.shape[-1]))
+        positive = self._scatter_rows(pmap.contiguous(), match, valid, pm_rows) > 0
+        matched = self._matched_mask(match, valid, Q)
+        mask = torch.where(matched, torch.ones((), device=logits.device),
+                           torch.full((), self.eos_coef, device=logits.device))   # (P,B,Q)
+        tmask = torch.where(cols == inds[:, None], torch.ones((), device=logits.device),
+                            torch.full((), self.eos_coef, device=logits.device))  # (B,L)
+
+        positive_logits = -logits.masked_fill(~positive, 0)
+
+        def side(dim, weights):
+            has_pos = positive.any(dim)
+            pos_term = positive_logits.sum(dim)
+            neg_term = logits.logsumexp(dim)
+            nb_pos = positive.sum(dim) + 1e-6
+            entropy = -torch.log(nb_pos + 1e-6) / nb_pos
+            per = (entropy + pos_term / nb_pos + neg_term).masked_fill(~has_pos, 0)
+            return (per * weights).sum((1, 2))
+
+        box_to_token = side(3, mask)
+        token_to_box = side(2, tmask[None])
+        return {"loss_contrastive_align": (box_to_token + token_to_box) / 2 / num_boxes}
+
+    def get_loss(self, loss, out, tgt, match, num_boxes):
+        table = {"labels": self.loss_labels_st, "boxes": self.loss_boxes,
+                 "contrastive_align": self.loss_contrastive_align}
+        assert loss in table, f"do you really want to compute {loss} loss?"
+        return table[loss](out, tgt, match, num_boxes)
+
+    def num_boxes(self, valid):
+        """losses.py:527-534 as a device scalar: matched pairs of this rank, averaged over ranks, >= 1."""
+        n = valid.sum().to(torch.float32).reshape(1)
+        world = 1
+        if is_dist_avail_and_initialized():
+            dist.all_reduce(n)
+            world = dist.get_world_size()
+        return torch.clamp(n / world, min=1)
+
+    def dense_forward(self, out, tgt, match=None):
+        """out: 'pred_logits' (P,B,Q,C), 'pred_boxes' (P,B,Q,6) [, 'proj_queries' (P,B,Q,D), 'proj_tokens'
+        (B,L,D), 'tokenized'];  tgt: 'boxes' (B,G,6), 'positive_map' (B,G,C), 'labels' (B,G), 'valid' (B,G)
+        bool.  Returns ({name: (P,) tensor}, match (P,B,G)).  `match` may be supplied (tests)."""
+        if match is None:
+            match = self.matcher.match_dense(out["pred_logits"], out["pred_boxes"], tgt["boxes"],
+                                             tgt["positive_map"], tgt["valid"], tgt.get("labels"))
+        num_boxes = self.num_boxes(tgt["valid"])
+        losses = {}
+        for name in self.losses:
+            losses.update(self.get_loss(name, out, tgt, match, num_boxes))
+        return losses, match
+
+    def forward(self, outputs, targets):
+        """The reference's call: one prefix, list-of-dict targets -> (losses, indices)."""
+        boxes, pm, labels, valid = _pad_targets(targets, outputs["pred_logits"].shape[-1])
+        out = {k: (v[None] if k in ("pred_logits", "pred_boxes", "proj_queries") else v) for k, v in outputs.items()}
+        losses, match = self.dense_forward(out, {"boxes": boxes, "positive_map": pm, "labels": labels,
+                                                 "valid": valid})
+        return {k: v[0] for k, v in losses.items()}, _match_to_indices(match[0], valid)
+
+
+def hungarian_prefixes(num_decoder_layers):
+    return ["proposal_", "last_"] + [f"{i}head_" for i in range(num_decoder_layers - 1)]
+
+
+def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_points_obj_topk=5, match=None):
+    """losses.py:546-617: same keys written into `end_points`, same weighting; every prefix evaluated in one
+    stacked pass."""
+    prefixes = hungarian_prefixes(num_decoder_layers)
+    valid = end_points["box_label_mask"].bool()
+    tgt = {"boxes": torch.cat([end_points["center_label"][:, :, 0:3], end_points["size_gts"]], dim=-1),
+           "positive_map": end_points["positive_map"], "labels": end_points["sem_cls_label"], "valid": valid}
+    stack = lambda key: torch.stack([end_points[f"{p}{key}"] for p in prefixes])
+    out = {"pred_logits": stack("sem_cls_scores"),
+           "pred_boxes": torch.cat([stack("center"), stack("pred_size")], dim=-1)}
+    if "proj_tokens" in end_points:
+        out["proj_tokens"] = end_points["proj_tokens"]
+        out["proj_queries"] = stack("proj_queries")
+        out["tokenized"] = end_points["tokenized"]
+    losses, match = set_criterion.dense_forward(out, tgt, match)
+    for key, per_prefix in losses.items():
+        for i, p in enumerate(prefixes):
+            end_points[f"{p}_{key}"] = per_prefix[i]
+    zero = out["pred_boxes"].new_zeros(())
+    loss_ce = losses["loss_ce"].sum() if "loss_ce" in losses else zero
+    loss_bbox = losses["loss_bbox"].sum()
+    loss_giou = losses["loss_giou"].sum() if "loss_giou" in losses else zero
+    loss_align = losses["loss_contrastive_align"].sum() if "proj_tokens" in end_points else zero
+    if "seeds_obj_cls_logits" in end_points:
+        generation = compute_points_obj_cls_loss_hard_topk(end_points, query_points_obj_topk)
+    else:
+        generation = zero
+    loss = 8 * generation + 1.0 / (num_decoder_layers + 1) * (loss_ce + 5 * loss_bbox + loss_giou + loss_align)
+    end_points["loss_ce"] = loss_ce
+    end_points["loss_bbox"] = loss_bbox
+    end_points["loss_giou"] = loss_giou
+    end_points["query_points_generation_loss"] = generation
+    end_points["loss_constrastive_align"] = loss_align
+    end_points["loss"] = loss
+    end_points["hungarian_match"] = match
+    return loss, end_points

@@ -1,0 +1,133 @@
+"""-m gpu: the device-side Hungarian matching (butd_hungarian_match, include/butd_lsap.h) against scipy's
+linear_sum_assignment -- the third-party routine HungarianMatcher.forward calls (models/losses.py:314-319) --
+and the complete criterion on the GPU against vectors captured from the reference's models/losses.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_losses_cpu import GOLD, check_outputs, load_case  # noqa: E402
+
+
+def scipy_match(cost_gq, valid):
+    """Dense form of what the reference does with one scene: compact, solve (queries x targets), scatter."""
+    from scipy.optimize import linear_sum_assignment
+    match = -np.ones(valid.shape[0], dtype=np.int32)
+    slots = np.nonzero(valid)[0]
+    if slots.size:
+        q, t = linear_sum_assignment(cost_gq[slots].T)
+        match[slots[t]] = q
+    return match
+
+
+def run_match(cost, valid):
+    from butd_detr_amd import losses as L
+    match, status = L.hungarian_match(torch.from_numpy(cost).cuda(), torch.from_numpy(valid).cuda())
+    torch.cuda.synchronize()
+    return match.cpu().numpy(), status.cpu().numpy()
+
+
+@pytest.mark.parametrize("G,Q", [(132, 256), (7, 24), (1, 1), (64, 64), (200, 1000), (3, 5)])
+def test_match_equals_scipy_on_random_costs(G, Q):
+    rng = np.random.default_rng(G * 1000 + Q)
+    count = 12
+    cost = rng.standard_normal((count, G, Q)).astype(np.float32) * 3
+    valid = rng.random((count, G)) < rng.uniform(0.05, 0.9, (count, 1))
+    valid[0] = True
+    valid[1] = False
+    valid[:, min(G, Q):] &= G <= Q            # never more targets than queries in these cases
+    got, status = run_match(cost, valid)
+    assert not status.any()
+    for p in range(count):
+        np.testing.assert_array_equal(got[p], scipy_match(cost[p], valid[p]), err_msg=f"problem {p}")
+
+
+def test_match_equals_scipy_on_tie_heavy_costs():
+    """Integer / constant / partly infinite matrices: ties everywhere, the scan order decides -- the
+    kernel follows rectangular_lsap.cpp's rule, so even these come out identical."""
+    rng = np.random.default_rng(5)
+    count, G, Q = 24, 20, 40
+    cost = rng.integers(0, 3, (count, G, Q)).astype(np.float32)
+    cost[0] = 0.0
+    cost[1] = 7.5
+    cost[2:8][rng.random((6, G, Q)) < 0.3] = np.inf
+    cost[8] = -0.0
+    valid = rng.random((count, G)) < 0.7
+    valid[0] = valid[1] = True
+    got, status = run_match(cost, valid)
+    for p in range(count):
+        try:
+            want = scipy_match(cost[p], valid[p])
+        except ValueError:                      # infeasible for scipy -> status 1, all -1
+            assert status[p] == 1 and (got[p] == -1).all()
+            continue
+        assert status[p] == 0
+        np.testing.assert_array_equal(got[p], want, err_msg=f"problem {p}")
+
+
+def test_match_rejects_what_scipy_rejects():
+    cost = np.zeros((4, 3, 5), dtype=np.float32)
+    cost[0, 1, 2] = np.nan
+    cost[1, 0, 0] = -np.inf
+    cost[2, 2, :] = np.inf                      # a target no query can take: infeasible
+    valid = np.ones((4, 3), dtype=bool)
+    got, status = run_match(cost, valid)
+    assert status.tolist() == [1, 1, 1, 0]
+    assert (got[:3] == -1).all() and sorted(got[3].tolist()) == [0, 1, 2]
+    cost2 = np.zeros((1, 6, 4), dtype=np.float32)   # more valid targets than queries
+    got, status = run_match(cost2, np.ones((1, 6), dtype=bool))
+    assert status.tolist() == [1] and (got == -1).all()
+    cost[0, 1, 2] = 0.0                         # a NaN in a row that is not valid does not matter
+    cost[0, 0, 3] = np.nan
+    valid[0, 0] = False
+    got, status = run_match(cost, valid)
+    assert status[0] == 0 and got[0, 0] == -1
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[p.split("losses_")[-1][:-4] for p in GOLD])
+def test_criterion_on_gpu_reproduces_the_reference(path):
+    from butd_detr_amd import losses as L
+    z, ep, leaves, crit = load_case(path, device="cuda", grad=True)
+    layers = int(z["meta_layers"])
+    loss, out = L.compute_hungarian_loss(ep, layers, crit, int(z["meta_topk"]))
+    np.testing.assert_array_equal(out["hungarian_match"].cpu().numpy(), z["out_match"])
+    check_outputs(z, {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in out.items()
+                      if k != "tokenized"}, L.hungarian_prefixes(layers), tol=5e-5)
+    loss.backward()
+    for name, t in leaves.items():
+        want = z["grad_" + name]
+        got = t.grad.cpu().numpy() if t.grad is not None else np.zeros_like(want)
+        np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6 + 1e-3 * np.abs(want).max(), err_msg=name)
+
+
+def test_reference_style_api_returns_scipy_indices():
+    """HungarianMatcher.forward / SetCriterion.forward with the reference's list-of-dict targets."""
+    from scipy.optimize import linear_sum_assignment
+    from butd_detr_amd import losses as L
+    torch.manual_seed(0)
+    B, Q, C = 3, 32, 40
+    outputs = {"pred_logits": torch.randn(B, Q, C, device="cuda"),
+               "pred_boxes": torch.cat([torch.rand(B, Q, 3, device="cuda") * 4, torch.rand(B, Q, 3, device="cuda") + 0.1], -1)}
+    targets = []
+    for n in (4, 0, 9):
+        pm = torch.zeros(n, C, device="cuda")
+        if n:
+            pm[torch.arange(n), torch.randint(1, C - 1, (n,))] = 1.0
+        targets.append({"labels": torch.randint(0, C, (n,), device="cuda"), "positive_map": pm,
+                        "boxes": torch.cat([torch.rand(n, 3, device="cuda") * 4, torch.rand(n, 3, device="cuda") + 0.1], -1)})
+    for soft in (True, False):
+        matcher = L.HungarianMatcher(1, 5, 2, soft)
+        indices = matcher(outputs, targets)
+        tgt_boxes, pm, labels, valid = L._pad_targets(targets, C)
+        cost = matcher.cost(outputs["pred_logits"], outputs["pred_boxes"], tgt_boxes, pm, labels).cpu().numpy()
+        for b, (qi, ti) in enumerate(indices):
+            n = len(targets[b]["boxes"])
+            want_q, want_t = linear_sum_assignment(cost[b, :n].T)
+            assert qi.dtype == torch.int64 and ti.dtype == torch.int64
+            np.testing.assert_array_equal(qi.numpy(), want_q)
+            np.testing.assert_array_equal(ti.numpy(), want_t)
+    crit = L.SetCriterion(L.HungarianMatcher(1, 0, 2, True), losses=["boxes", "labels"])
+    losses, indices = crit(outputs, targets)
+    assert set(losses) == {"loss_ce", "loss_bbox", "loss_giou"} and len(indices) == B
+    assert all(torch.isfinite(v) for v in losses.values())
