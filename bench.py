@@ -38,6 +38,9 @@ def parse():
     ap.add_argument("--tokens", type=int, default=80)
     ap.add_argument("--backend", default=os.environ.get("BUTD_ATTENTION_BACKEND", "auto"),
                     choices=["auto", "torch", "hip"])
+    ap.add_argument("--criterion", default="hungarian", choices=["hungarian", "surrogate"],
+                    help="hungarian: the reference's criterion (models/losses.py) with the assignment on the "
+                         "device; surrogate: dense stand-in without matching")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="plain eager launches + DDP instead of hipGraph replay")
     ap.add_argument("--cpu-scenes", type=int, default=1)
@@ -240,11 +243,15 @@ def cpu_baseline(args, scenes):
         opt = make_optimizer(model)
         inputs, targets = synthetic_batch(scenes, torch.device("cpu"), n_points=args.points,
                                           tokens=args.tokens)
-        train_step(model, opt, inputs, targets)      # warm-up
+        criterion = make_criterion(args)
+        if criterion is not None:   # cpu_baseline leg only: scipy on the host, as the reference does it
+            from oracle import lsap_oracle
+            criterion.set_criterion.matcher.match_dense = lsap_oracle.scipy_match_dense(criterion.set_criterion.matcher)
+        train_step(model, opt, inputs, targets, criterion=criterion)      # warm-up
         t0 = time.perf_counter()
         reps = 2
         for _ in range(reps):
-            train_step(model, opt, inputs, targets)
+            train_step(model, opt, inputs, targets, criterion=criterion)
         dt = (time.perf_counter() - t0) / reps
     finally:
         pointnet2_utils._ext = prev_ext
@@ -252,6 +259,13 @@ def cpu_baseline(args, scenes):
     return {"value": round(scenes / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
             "sample": f"{reps} timed fwd+bwd+optimizer steps of {scenes} scene(s) x {args.points} points "
                       f"after 1 warm-up, oracle C ops (OpenMP) + torch CPU fp32"}
+
+
+def make_criterion(args):
+    if args.criterion == "surrogate":
+        return None
+    from butd_detr_amd.train_step import HungarianCriterion
+    return HungarianCriterion(num_decoder_layers=6, use_contrastive_align=True, use_soft_token_loss=True)
 
 
 def main():
@@ -273,16 +287,17 @@ def main():
     model, backend = build_model(args, device)
     inputs, targets = synthetic_batch(args.batch, device, n_points=args.points, tokens=args.tokens,
                                       rank=rank)
+    criterion = make_criterion(args)
     if args.eager:
         ddp = wrap_data_parallel(model, device)
         opt = make_optimizer(model)
 
         def train_step(_m, _o, i, t):
-            return eager_step(ddp, opt, i, t)
+            return eager_step(ddp, opt, i, t, criterion=criterion)
     else:
         from butd_detr_amd.train_step import FlatAdamW
         opt = FlatAdamW(model)
-        graphed = GraphedTrainStep(model, opt)
+        graphed = GraphedTrainStep(model, opt, criterion=criterion)
         ddp = model
 
         def train_step(_m, _o, i, t):
@@ -316,11 +331,14 @@ def main():
             "config": {"workload": f"BASELINE configs[2]/[3]: {args.batch} scenes/GPU x {args.points} "
                                    f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "
                                    "3 encoder + 6 decoder layers, fwd+loss+bwd+clip+AdamW, train mode",
+                       "criterion": ("compute_hungarian_loss (matcher 1/0/2, soft token + contrastive align, "
+                                     "assignment on the device)" if criterion is not None else "dense surrogate"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "attention_backend": backend, "launch": "eager+DDP+torch AdamW" if args.eager else "hipGraph replay (FPS chain of the next batch prefetched on a forked stream) + flat-gradient all-reduce + packed AdamW", "final_loss": round(float(loss), 4)},
         }
         if backend == "hip":
-            out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, targets))
+            out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, targets,
+                                                                   criterion=criterion))
             out["roofline_ball_query"] = ball_query_roofline(inputs)
             out["roofline_attention"] = attention_roofline(args.batch)
         else:

@@ -106,12 +106,23 @@ LSAP_SYMBOLS = {
     "butd_hungarian_match": (_c_int, [_c_int] * 3 + [_P] * 4 + [_P]),
 }
 
+CRITERION_SYMBOLS = {
+    "butd_match_cost": (_c_int, [_c_int] * 4 + [_P] * 4 + [_c_float] * 3 + [_P, _P]),
+    "butd_box_loss": (_c_int, [_c_int] * 4 + [_P] * 5 + [_P]),
+    "butd_box_loss_bwd": (_c_int, [_c_int] * 4 + [_P] * 4 + [_P]),
+    "butd_soft_token_ce": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _c_float, _P, _P, _P]),
+    "butd_contrastive_rows": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P, _P]),
+    "butd_seed_objectness": (_c_int, [_c_int] * 5 + [_P] * 10 + [_P]),
+    "butd_contrastive_cols": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P]),
+}
+
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
 ALL_SYMBOLS.update(ATTENTION_SYMBOLS)
 ALL_SYMBOLS.update(SA_SYMBOLS)
 ALL_SYMBOLS.update(OPTIM_SYMBOLS)
 ALL_SYMBOLS.update(MLP_SYMBOLS)
 ALL_SYMBOLS.update(LSAP_SYMBOLS)
+ALL_SYMBOLS.update(CRITERION_SYMBOLS)
 
 _lib = None
 

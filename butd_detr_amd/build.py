@@ -26,6 +26,7 @@ TU_FLAGS = {
     "pointnet2_ops.hip": ["-ffp-contract=off"],
     "fps_pruned.hip": ["-ffp-contract=off"],
     "ball_query_grid.hip": ["-ffp-contract=off"],
+    "criterion_ops.hip": ["-ffp-contract=off"],
     "attention_ops.hip": [],
 }
 

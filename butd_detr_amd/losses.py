@@ -95,6 +95,9 @@ def compute_points_obj_cls_loss_hard_topk(end_points, topk):
     gt_center = end_points["center_label"][:, :, :3]
     gt_size = end_points["size_gts"][:, :, :3]
     B, K, G = gt_center.shape[0], seed_xyz.shape[1], gt_center.shape[1]
+    if _fused(logits):
+        return _SeedObjectness.apply(logits, seed_xyz, end_points["seed_inds"], end_points["point_instance_label"],
+                                     gt_center, gt_size, mask, topk)
 
     seed_obj = torch.gather(end_points["point_instance_label"], 1, seed_inds)  # (B, K), < 0 = background
     owner = torch.where(seed_obj < 0, torch.full_like(seed_obj, G - 1), seed_obj)
@@ -111,6 +114,167 @@ def compute_points_obj_cls_loss_hard_topk(end_points, topk):
     weights = torch.full((B, K), 1.0 / max(K, 1), device=seed_xyz.device)
     loss = SigmoidFocalClassificationLoss()(logits.reshape(B, K, 1), label.unsqueeze(-1).float(), weights)
     return loss.sum() / B
+
+
+# ------------------------------------------------------------------------------------------ fused terms
+_BACKEND = "hip"
+
+
+def set_backend(name):
+    """'hip' (default): CUDA tensors take the fused kernels of include/butd_criterion.h; 'torch': the dense
+    torch expressions below everywhere (the A/B leg; CPU tensors always take them -- they are what the
+    CPU tests check against the reference's vectors)."""
+    global _BACKEND
+    assert name in ("hip", "torch")
+    _BACKEND = name
+
+
+def _fused(t):
+    return _BACKEND == "hip" and t.is_cuda
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _f32c(t):
+    return t.detach().contiguous().float()
+
+
+def _pad_last(t, width):
+    return t if t.shape[-1] >= width else torch.nn.functional.pad(t, (0, width - t.shape[-1]))
+
+
+class _BoxLoss(torch.autograd.Function):
+    """butd_box_loss: (P,2) sums of the L1 and the 1-GIoU terms over the matched pairs."""
+
+    @staticmethod
+    def forward(ctx, pred_boxes, tgt_boxes, match):
+        P, B, Q, _ = pred_boxes.shape
+        G = tgt_boxes.shape[1]
+        pred, tgt, match = _f32c(pred_boxes), _f32c(tgt_boxes), match.contiguous()
+        sums = torch.empty((P, 2), device=pred.device)
+        grad = torch.empty((P, B, G, 12), device=pred.device)
+        lib = _hiplib.load()
+        with torch.cuda.device(pred.device):
+            _hiplib.check(lib.butd_box_loss(P, B, Q, G, pred.data_ptr(), tgt.data_ptr(), match.data_ptr(),
+                                            sums.data_ptr(), grad.data_ptr(), _stream(pred)), "butd_box_loss")
+        ctx.save_for_backward(match, grad)
+        ctx.dims = (P, B, Q, G)
+        return sums
+
+    @staticmethod
+    def backward(ctx, g):
+        match, grad = ctx.saved_tensors
+        P, B, Q, G = ctx.dims
+        w = _f32c(g)
+        out = torch.empty((P, B, Q, 6), device=grad.device)
+        lib = _hiplib.load()
+        with torch.cuda.device(grad.device):
+            _hiplib.check(lib.butd_box_loss_bwd(P, B, Q, G, match.data_ptr(), grad.data_ptr(), w.data_ptr(),
+                                                out.data_ptr(), _stream(grad)), "butd_box_loss_bwd")
+        return out, None, None
+
+
+class _SoftTokenCE(torch.autograd.Function):
+    """butd_soft_token_ce: (P,) weighted soft-token cross entropy summed over scenes and queries."""
+
+    @staticmethod
+    def forward(ctx, logits, match, positive_map, eos_coef):
+        P, B, Q, C = logits.shape
+        x, pm, match = _f32c(logits), _f32c(_pad_last(positive_map, C)), match.contiguous()
+        G = pm.shape[1]
+        rows = torch.empty((P, B, Q), device=x.device)
+        dx = torch.empty_like(x)
+        lib = _hiplib.load()
+        with torch.cuda.device(x.device):
+            _hiplib.check(lib.butd_soft_token_ce(P, B, Q, G, C, x.data_ptr(), match.data_ptr(), pm.data_ptr(),
+                                                 pm.shape[-1], float(eos_coef), rows.data_ptr(), dx.data_ptr(),
+                                                 _stream(x)), "butd_soft_token_ce")
+        ctx.save_for_backward(dx)
+        return rows.sum((1, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g[:, None, None, None], None, None, None
+
+
+class _ContrastiveAlign(torch.autograd.Function):
+    """butd_contrastive_rows + _cols: (P,) (box-to-token + token-to-box) / 2."""
+
+    @staticmethod
+    def forward(ctx, logits, match, positive_map, last, eos_coef):
+        P, B, Q, L = logits.shape
+        x, pm, match = _f32c(logits), _f32c(_pad_last(positive_map, L)), match.contiguous()
+        last = last.to(torch.int32).contiguous()
+        G = pm.shape[1]
+        rows = torch.empty((P, B, Q), device=x.device)
+        cols = torch.empty((P, B, L), device=x.device)
+        owner = torch.empty((P, B, Q), dtype=torch.int32, device=x.device)
+        dx = torch.empty_like(x)
+        lib = _hiplib.load()
+        with torch.cuda.device(x.device):
+            _hiplib.check(lib.butd_contrastive_rows(P, B, Q, G, L, x.data_ptr(), match.data_ptr(), pm.data_ptr(),
+                                                    pm.shape[-1], last.data_ptr(), float(eos_coef),
+                                                    rows.data_ptr(), dx.data_ptr(), owner.data_ptr(), _stream(x)),
+                          "butd_contrastive_rows")
+            _hiplib.check(lib.butd_contrastive_cols(P, B, Q, G, L, x.data_ptr(), owner.data_ptr(), pm.data_ptr(),
+                                                    pm.shape[-1], last.data_ptr(), float(eos_coef),
+                                                    cols.data_ptr(), dx.data_ptr(), _stream(x)),
+                          "butd_contrastive_cols")
+        ctx.save_for_backward(dx)
+        return rows.sum((1, 2)) + cols.sum((1, 2))
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return dx * g[:, None, None, None], None, None, None, None
+
+
+class _SeedObjectness(torch.autograd.Function):
+    """butd_seed_objectness: scalar loss of compute_points_obj_cls_loss_hard_topk."""
+
+    @staticmethod
+    def forward(ctx, logits, seed_xyz, seed_inds, pil, gt_center, gt_size, mask, topk):
+        B, K = seed_xyz.shape[:2]
+        G, N = gt_center.shape[1], pil.shape[1]
+        x = _f32c(logits).reshape(B, K)
+        xyz, gc, gs, bm = _f32c(seed_xyz), _f32c(gt_center), _f32c(gt_size), _f32c(mask)
+        inds, pil = seed_inds.to(torch.int32).contiguous(), pil.to(torch.int64).contiguous()
+        label = torch.empty((B, K), dtype=torch.uint8, device=x.device)
+        elem, dx = torch.empty_like(x), torch.empty_like(x)
+        lib = _hiplib.load()
+        with torch.cuda.device(x.device):
+            _hiplib.check(lib.butd_seed_objectness(B, K, G, N, int(topk), xyz.data_ptr(), inds.data_ptr(),
+                                                   pil.data_ptr(), gc.data_ptr(), gs.data_ptr(), bm.data_ptr(),
+                                                   x.data_ptr(), label.data_ptr(), elem.data_ptr(), dx.data_ptr(),
+                                                   _stream(x)), "butd_seed_objectness")
+        ctx.save_for_backward(dx)
+        ctx.shape, ctx.B = logits.shape, B
+        return elem.sum() / B
+
+    @staticmethod
+    def backward(ctx, g):
+        (dx,) = ctx.saved_tensors
+        return (dx * (g / ctx.B)).reshape(ctx.shape), None, None, None, None, None, None, None
+
+
+def _fused_cost(pred_boxes, tgt_boxes, valid, class_cost, w_bbox, w_class, w_giou):
+    """butd_match_cost: pred_boxes (P,B,Q,6), class_cost (P,B,G,Q) or None -> cost (P,B,G,Q)."""
+    P, B, Q, _ = pred_boxes.shape
+    G = tgt_boxes.shape[1]
+    pred, tgt = _f32c(pred_boxes), _f32c(tgt_boxes)
+    ok = valid.to(torch.uint8).contiguous()
+    cc = _f32c(class_cost) if class_cost is not None else None
+    cost = torch.empty((P, B, G, Q), device=pred.device)
+    lib = _hiplib.load()
+    with torch.cuda.device(pred.device):
+        _hiplib.check(lib.butd_match_cost(P, B, Q, G, pred.data_ptr(), tgt.data_ptr(), ok.data_ptr(),
+                                          cc.data_ptr() if cc is not None else None, float(w_bbox),
+                                          float(w_class), float(w_giou), cost.data_ptr(), _stream(pred)),
+                      "butd_match_cost")
+    return cost
 
 
 # ------------------------------------------------------------------------------------------ matcher
@@ -146,10 +310,21 @@ class HungarianMatcher(nn.Module):
         self.soft_token = soft_token
 
     @torch.no_grad()
-    def cost(self, pred_logits, pred_boxes, tgt_boxes, positive_map, labels=None):
+    def cost(self, pred_logits, pred_boxes, tgt_boxes, positive_map, labels=None, valid=None):
         """pred_logits (..., B, Q, C), pred_boxes (..., B, Q, 6), tgt_boxes (B, G, 6), positive_map
         (B, G, C') -> C (..., B, G, Q): losses.py:285-312 for every target slot."""
         prob = pred_logits.softmax(-1)
+        if _fused(pred_logits) and pred_logits.dim() == 4:
+            if self.soft_token:
+                pm = positive_map[..., :prob.shape[-1]] if positive_map.shape[-1] != prob.shape[-1] else positive_map
+                affinity = torch.matmul(pm, prob.transpose(-1, -2))                          # = -cost_class
+            else:
+                idx = labels.long()[..., :, None].expand(*prob.shape[:-2], labels.shape[-1], prob.shape[-2])
+                affinity = torch.gather(prob.transpose(-1, -2), -2, idx)
+            if valid is None:   # rows of slots that are not targets are skipped (written as zeros)
+                valid = torch.ones(tgt_boxes.shape[:2], dtype=torch.uint8, device=tgt_boxes.device)
+            return _fused_cost(pred_boxes, tgt_boxes, valid, affinity, self.cost_bbox, -self.cost_class,
+                               self.cost_giou)
         if self.soft_token:
             pm = positive_map[..., :prob.shape[-1]] if positive_map.shape[-1] != prob.shape[-1] else positive_map
             cost_class = -torch.matmul(pm, prob.transpose(-1, -2))                        # (..., B, G, Q)
@@ -163,7 +338,7 @@ class HungarianMatcher(nn.Module):
 
     @torch.no_grad()
     def match_dense(self, pred_logits, pred_boxes, tgt_boxes, positive_map, valid, labels=None):
-        return hungarian_match(self.cost(pred_logits, pred_boxes, tgt_boxes, positive_map, labels), valid)[0]
+        return hungarian_match(self.cost(pred_logits, pred_boxes, tgt_boxes, positive_map, labels, valid), valid)[0]
 
     @torch.no_grad()
     def forward(self, outputs, targets):
@@ -232,6 +407,9 @@ class SetCriterion(nn.Module):
         return m.scatter(2, idx, torch.ones_like(idx, dtype=torch.bool))[:, :, :Q]
 
     def loss_labels_st(self, out, tgt, match, num_boxes):
+        if _fused(out["pred_logits"]):
+            ce = _SoftTokenCE.apply(out["pred_logits"], match, tgt["positive_map"], self.eos_coef)
+            return {"loss_ce": ce / num_boxes}
         logits = out["pred_logits"].log_softmax(-1)                               # (P,B,Q,C)
         P, B, Q, C = logits.shape
         valid = tgt["valid"][None].expand(P, -1, -1)
@@ -245,6 +423,9 @@ class SetCriterion(nn.Module):
         return {"loss_ce": (loss_ce * weight).sum((1, 2)) / num_boxes}
 
     def loss_boxes(self, out, tgt, match, num_boxes):
+        if _fused(out["pred_boxes"]):
+            sums = _BoxLoss.apply(out["pred_boxes"], tgt["boxes"], match)
+            return {"loss_bbox": sums[:, 0] / num_boxes, "loss_giou": sums[:, 1] / num_boxes}
         P = match.shape[0]
         valid = tgt["valid"][None].expand(P, -1, -1)
         idx = match.long().clamp(min=0)
@@ -263,6 +444,9 @@ class SetCriterion(nn.Module):
         valid = tgt["valid"][None].expand(P, -1, -1)
         # 'not mentioned': the last two real tokens (python indexing: -1 wraps to the last column)
         inds = out["tokenized"]["attention_mask"].to(logits.device).sum(1) - 1    # (B,)
+        if _fused(logits):
+            align = _ContrastiveAlign.apply(logits, match, tgt["positive_map"], inds, self.eos_coef)
+            return {"loss_contrastive_align": align / num_boxes}
         cols = torch.arange(L, device=logits.device)[None, :]
         base = ((cols == inds[:, None]) | (cols == torch.remainder(inds[:, None] - 1, L))).to(logits.dtype) * 0.5
         pmap = base[None, :, None, :].expand(P, -1, Q, -1)
@@ -313,7 +497,7 @@ class SetCriterion(nn.Module):
         if match is None:
             match = self.matcher.match_dense(out["pred_logits"], out["pred_boxes"], tgt["boxes"],
                                              tgt["positive_map"], tgt["valid"], tgt.get("labels"))
-        num_boxes = self.num_boxes(tgt["valid"])
+        num_boxes = tgt["num_boxes"] if tgt.get("num_boxes") is not None else self.num_boxes(tgt["valid"])
         losses = {}
         for name in self.losses:
             losses.update(self.get_loss(name, out, tgt, match, num_boxes))
@@ -338,7 +522,8 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     prefixes = hungarian_prefixes(num_decoder_layers)
     valid = end_points["box_label_mask"].bool()
     tgt = {"boxes": torch.cat([end_points["center_label"][:, :, 0:3], end_points["size_gts"]], dim=-1),
-           "positive_map": end_points["positive_map"], "labels": end_points["sem_cls_label"], "valid": valid}
+           "positive_map": end_points["positive_map"], "labels": end_points["sem_cls_label"], "valid": valid,
+           "num_boxes": end_points.get("num_boxes")}   # optional: precomputed rank-averaged count (device)
     stack = lambda key: torch.stack([end_points[f"{p}{key}"] for p in prefixes])
     out = {"pred_logits": stack("sem_cls_scores"),
            "pred_boxes": torch.cat([stack("center"), stack("pred_size")], dim=-1)}

@@ -1,12 +1,15 @@
 """Benchmark-side training step: synthetic batch, surrogate loss, optimiser, data-parallel wrap.
 
 The reference's step is ``model(inputs) -> compute_hungarian_loss -> backward -> clip_grad_norm_(0.1)
--> AdamW.step`` (main_utils.py:415-438).  The Hungarian criterion (models/losses.py, scipy on the
-host, 7 D2H syncs per step) is outside the hot path this repo builds, so
-the timed step uses a dense on-device surrogate that reads EVERY head output of every prefix --
-box L1, size L1, soft-token cross-entropy, query/token contrastive logits, seed objectness -- so all
-21.4 M trainable parameters receive gradients exactly as in the reference step (DDP without
-``find_unused_parameters``), followed by the same clip + AdamW update.
+-> AdamW.step`` (main_utils.py:415-438).  Two criteria are available:
+
+* ``HungarianCriterion`` -- the reference's criterion (models/losses.py) as rebuilt in ``losses.py``: the
+  assignment runs on the device (``butd_hungarian_match``), every term is a static-shape dense expression,
+  so the whole step stays inside the hipGraph (the reference stalls 7 times per
+  step on ``.cpu()`` + scipy);
+* ``surrogate_loss`` -- a dense stand-in without matching that reads EVERY head output of every prefix
+  (box L1, size L1, soft-token cross-entropy, query/token contrastive logits, seed objectness), kept as
+  the minimal "all 21.4 M trainable parameters receive gradients" driver for kernel work.
 """
 import numpy as np
 import os
@@ -32,6 +35,8 @@ def synthetic_batch(batch, device, *, seed=1184, n_points=50000, tokens=80, rank
         "gt_token": torch.from_numpy(rng.integers(1, tokens - 1, (batch,))).to(device),
         "seed_label": torch.from_numpy((rng.random((batch, 1024)) < 0.1).astype(np.float32)).to(device),
     }
+    targets.update({k: torch.from_numpy(v).to(device)
+                    for k, v in synthetic_ground_truth(pc, rng, tokens=tokens).items()})
     inputs = {
         "point_clouds": torch.from_numpy(pc).to(device),
         "text": synthetic_utterances(batch, tokens=tokens, seed=base),
@@ -40,6 +45,67 @@ def synthetic_batch(batch, device, *, seed=1184, n_points=50000, tokens=80, rank
         "det_class_ids": torch.from_numpy(cls).to(device),
     }
     return inputs, targets
+
+
+GROUND_TRUTH_KEYS = ("center_label", "size_gts", "sem_cls_label", "positive_map", "box_label_mask",
+                     "point_instance_label")
+
+
+def synthetic_ground_truth(pc, rng, tokens=80, slots=132, n_class=256):
+    """The criterion's batch keys as joint_det_dataset.py:740-766 emits them, for synthetic scenes:
+    1-16 target boxes per scene centred on scene points (`center_label`, `size_gts` (B,132,3),
+    `box_label_mask` (B,132)), the instance id of every point inside a target box, -1 elsewhere
+    (`point_instance_label` (B,N) int64), a class id and a normalised 1-3 token span per target
+    (`sem_cls_label` (B,132) int64, `positive_map` (B,132,256))."""
+    B, N = pc.shape[0], pc.shape[1]
+    out = {"center_label": np.zeros((B, slots, 3), np.float32), "size_gts": np.zeros((B, slots, 3), np.float32),
+           "sem_cls_label": np.zeros((B, slots), np.int64), "positive_map": np.zeros((B, slots, n_class), np.float32),
+           "box_label_mask": np.zeros((B, slots), np.float32),
+           "point_instance_label": -np.ones((B, N), np.int64)}
+    for b in range(B):
+        n = int(rng.integers(1, 17))
+        centres = pc[b, rng.integers(0, N, n), :3]
+        sizes = rng.uniform(0.4, 1.6, (n, 3)).astype(np.float32)
+        out["center_label"][b, :n], out["size_gts"][b, :n], out["box_label_mask"][b, :n] = centres, sizes, 1.0
+        out["sem_cls_label"][b, :n] = rng.integers(0, 485, n)
+        for t in range(n):
+            start = int(rng.integers(1, max(2, tokens - 4)))
+            width = int(rng.integers(1, 4))
+            out["positive_map"][b, t, start:start + width] = 1.0 / width
+            inside = np.all(np.abs(pc[b, :, :3] - centres[t]) <= 0.5 * sizes[t], axis=1)
+            out["point_instance_label"][b, inside & (out["point_instance_label"][b] < 0)] = t
+    return out
+
+
+class HungarianCriterion:
+    """The reference's criterion as the training loop wires it (main_utils.py:243-251, 381-387, 423-428):
+    batch keys merged into ``end_points``, ``compute_hungarian_loss`` with matcher weights (1, 0, 2).
+    Call ``prepare(targets)`` outside a captured region: it adds the rank-averaged box count
+    (losses.py:527-534) so that no collective sits inside the graph."""
+
+    def __init__(self, num_decoder_layers=6, use_contrastive_align=True, use_soft_token_loss=True,
+                 query_points_obj_topk=4):
+        from . import losses
+        self._losses = losses
+        names = ["boxes", "labels"] + (["contrastive_align"] if use_contrastive_align else [])
+        self.set_criterion = losses.SetCriterion(
+            matcher=losses.HungarianMatcher(1, 0, 2, use_soft_token_loss), losses=names, eos_coef=0.1,
+            temperature=0.07)
+        self.num_decoder_layers, self.topk = num_decoder_layers, query_points_obj_topk
+
+    def prepare(self, targets):
+        targets = dict(targets)
+        targets["num_boxes"] = self.set_criterion.num_boxes(targets["box_label_mask"] > 0)
+        return targets
+
+    def __call__(self, end_points, targets):
+        for k in GROUND_TRUTH_KEYS:
+            end_points[k] = targets[k]
+        if "num_boxes" in targets:
+            end_points["num_boxes"] = targets["num_boxes"]
+        loss, _ = self._losses.compute_hungarian_loss(end_points, self.num_decoder_layers, self.set_criterion,
+                                                      self.topk)
+        return loss
 
 
 def surrogate_loss(end_points, targets, prefixes=None):
@@ -85,10 +151,13 @@ def make_optimizer(model, lr=1e-4, lr_backbone=1e-3, text_encoder_lr=1e-5, weigh
                              fused=True if capturable else None)
 
 
-def train_step(model, optimizer, inputs, targets, clip_norm=0.1):
-    """One reference-shaped iteration (main_utils.py:421-436) with the surrogate criterion."""
+def train_step(model, optimizer, inputs, targets, clip_norm=0.1, criterion=None):
+    """One reference-shaped iteration (main_utils.py:421-436); ``criterion(end_points, targets)`` defaults
+    to the surrogate."""
     end_points = model(inputs)
-    loss = surrogate_loss(end_points, targets)
+    if criterion is not None and hasattr(criterion, "prepare"):
+        targets = criterion.prepare(targets)
+    loss = (criterion or surrogate_loss)(end_points, targets)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     if clip_norm:
@@ -240,8 +309,9 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
-                 zero_arena=True, prefetch_text=True):
+                 zero_arena=True, prefetch_text=True, criterion=None):
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
+        self.criterion = criterion or surrogate_loss
         self.warmup = warmup
         self.prefetch_sampling = prefetch_sampling
         self.prefetch_text = bool(prefetch_text and hasattr(self._module(), "text_encoder_is_frozen")
@@ -293,7 +363,7 @@ class GraphedTrainStep:
             with torch.cuda.stream(self._text_stream):
                 self._encode_text_into_next()
         end_points = self.model.forward_tokenized(self.s_inputs, self.s_tok)
-        loss = surrogate_loss(end_points, self.s_targets)
+        loss = self.criterion(end_points, self.s_targets)
         self.flat.detach()                      # fresh .grad tensors: no per-parameter accumulate
         loss.backward()
         self.flat.gather([p.grad for p in self.flat.params])
@@ -373,6 +443,8 @@ class GraphedTrainStep:
         else:
             tok = self.model.tokenize(inputs)
         self._tok_cache = None
+        if hasattr(self.criterion, "prepare"):                 # collectives of the criterion: outside the graph
+            targets = self.criterion.prepare(targets)
         sig = (tuple(inputs["point_clouds"].shape), tuple(tok["input_ids"].shape))
         if sig != self._sig:
             self._capture(inputs, targets, tok)

@@ -10,7 +10,7 @@ rectangular shortest-augmenting-path variant of Jonker-Volgenant (scipy/optimize
 rectangular_lsap.cpp); `solve` below restates it in pure Python (small cases only).
 
 Pinning.  scipy itself is importable here and on the GPU box, so the restatement and the HIP kernel are both
-checked against scipy's own answers (tests/test_lsap_oracle.py, tests/test_gpu_losses.py), and the complete
+checked against scipy's own answers (tests/test_losses_cpu.py, tests/test_gpu_losses.py), and the complete
 criterion against outputs of the reference's losses.py captured by tests/golden/make_losses_golden.py.
 """
 import math
@@ -107,3 +107,25 @@ def match_targets(cost_gq, valid):
     rows, cols = solve(np.ascontiguousarray(cost_gq[slots].T))   # rows = queries, cols = compacted targets
     match[slots[cols]] = rows.astype(np.int32)
     return match
+
+
+def scipy_match_dense(matcher):
+    """bench.py cpu_baseline leg / tests only: a drop-in for HungarianMatcher.match_dense that does what the
+    reference does -- cost to the host, scipy.optimize.linear_sum_assignment per (prefix, scene)."""
+    import torch
+    from scipy.optimize import linear_sum_assignment
+
+    def match_dense(pred_logits, pred_boxes, tgt_boxes, positive_map, valid, labels=None):
+        cost = matcher.cost(pred_logits, pred_boxes, tgt_boxes, positive_map, labels).detach().cpu().numpy()
+        ok = valid.cpu().numpy().astype(bool)
+        lead = cost.shape[:-2]
+        flat = cost.reshape((-1,) + cost.shape[-2:])
+        okf = np.broadcast_to(ok, lead + ok.shape[-1:]).reshape(-1, ok.shape[-1])
+        match = -np.ones(okf.shape, dtype=np.int32)
+        for p in range(flat.shape[0]):
+            slots = np.nonzero(okf[p])[0]
+            if slots.size:
+                q, t = linear_sum_assignment(flat[p][slots].T)
+                match[p, slots[t]] = q
+        return torch.from_numpy(match.reshape(lead + ok.shape[-1:])).to(pred_logits.device)
+    return match_dense

@@ -131,3 +131,89 @@ def test_reference_style_api_returns_scipy_indices():
     losses, indices = crit(outputs, targets)
     assert set(losses) == {"loss_ce", "loss_bbox", "loss_giou"} and len(indices) == B
     assert all(torch.isfinite(v) for v in losses.values())
+
+
+def _north_star_case(seed=0, P=7, B=8, Q=256, C=256, Lt=80, D=64, N=20000):
+    from butd_detr_amd.train_step import synthetic_ground_truth
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    pc = rng.uniform(-3, 3, (B, N, 3)).astype(np.float32)
+    gt = {k: torch.from_numpy(v).cuda() for k, v in synthetic_ground_truth(pc, rng).items()}
+    lens = torch.randint(Lt // 2, Lt + 1, (B,))
+    out = {"pred_logits": torch.randn(P, B, Q, C, device="cuda") * 2,
+           "pred_boxes": torch.cat([torch.rand(P, B, Q, 3, device="cuda") * 6 - 3,
+                                    torch.rand(P, B, Q, 3, device="cuda") * 1.5 + 0.05], -1),
+           "proj_queries": torch.nn.functional.normalize(torch.randn(P, B, Q, D, device="cuda"), dim=-1),
+           "proj_tokens": torch.nn.functional.normalize(torch.randn(B, Lt, D, device="cuda"), dim=-1),
+           "tokenized": {"attention_mask": (torch.arange(Lt)[None] < lens[:, None]).long().cuda()}}
+    tgt = {"boxes": torch.cat([gt["center_label"], gt["size_gts"]], -1), "positive_map": gt["positive_map"],
+           "labels": gt["sem_cls_label"] % C, "valid": gt["box_label_mask"] > 0}
+    return out, tgt
+
+
+@pytest.mark.parametrize("weights,soft", [((1, 0, 2), True), ((1, 5, 2), True), ((2, 5, 2), False)])
+def test_fused_terms_equal_the_dense_torch_expressions(weights, soft):
+    """The kernels of include/butd_criterion.h vs the dense torch expressions (which the CPU tests pin to the
+    reference's vectors), at the bench shape: cost tensor, assignment, every loss term, every gradient."""
+    from butd_detr_amd import losses as L
+    out, tgt = _north_star_case()
+    crit = L.SetCriterion(L.HungarianMatcher(*weights, soft), ["boxes", "labels", "contrastive_align"])
+    res = {}
+    for backend in ("torch", "hip"):
+        L.set_backend(backend)
+        try:
+            leaves = {k: out[k].clone().requires_grad_(True) for k in ("pred_logits", "pred_boxes", "proj_queries",
+                                                                       "proj_tokens")}
+            o = dict(out, **leaves)
+            cost = crit.matcher.cost(o["pred_logits"], o["pred_boxes"], tgt["boxes"], tgt["positive_map"],
+                                     tgt["labels"], tgt["valid"])
+            losses, match = crit.dense_forward(o, tgt)
+            probe = torch.linspace(0.5, 1.5, 7, device="cuda")
+            sum((v * probe).sum() for v in losses.values()).backward()
+            res[backend] = (cost, match, {k: v.detach() for k, v in losses.items()},
+                            {k: v.grad for k, v in leaves.items()})
+        finally:
+            L.set_backend("hip")
+    (c0, m0, l0, g0), (c1, m1, l1, g1) = res["torch"], res["hip"]
+    ok = tgt["valid"][None, :, :, None].expand_as(c0)
+    assert torch.allclose(c1[ok], c0[ok], rtol=1e-5, atol=1e-5)
+    assert (m0 == m1).float().mean() > 0.999          # a near-tie may flip under 1e-7 cost differences
+    if not torch.equal(m0, m1):
+        pytest.skip("assignment differs on a near-tie: loss comparison would not be like for like")
+    for k in l0:
+        assert torch.allclose(l1[k], l0[k], rtol=2e-4, atol=1e-5), k
+    for k in g0:
+        scale = g0[k].abs().max()
+        assert (g1[k] - g0[k]).abs().max() <= 2e-4 * scale + 1e-7, k
+
+
+def test_fused_seed_objectness_equals_the_dense_expression():
+    from butd_detr_amd import losses as L
+    torch.manual_seed(3)
+    B, K, G, N, topk = 8, 1024, 132, 50000, 4
+    n_valid = [1, 16, 5, 0, 30, 2, 9, 12]
+    mask = torch.zeros(B, G, device="cuda")
+    pil = torch.full((B, N), -1, dtype=torch.long, device="cuda")
+    seed_inds = torch.stack([torch.randperm(N, device="cuda")[:K] for _ in range(B)]).int()
+    for b, nv in enumerate(n_valid):
+        mask[b, :nv] = 1
+        owners = torch.randint(-1, max(nv, 1), (K,), device="cuda") if nv else torch.full((K,), -1, device="cuda")
+        if nv:
+            owners[: nv * topk] = torch.arange(nv, device="cuda").repeat_interleave(topk)   # >= topk members each
+        pil[b, seed_inds[b].long()] = owners
+    ep = {"box_label_mask": mask, "seed_inds": seed_inds, "seed_xyz": torch.rand(B, K, 3, device="cuda") * 6 - 3,
+          "center_label": torch.rand(B, G, 3, device="cuda") * 6 - 3, "size_gts": torch.rand(B, G, 3, device="cuda") + 0.3,
+          "point_instance_label": pil}
+    base = torch.randn(B, 1, K, device="cuda")
+    res = {}
+    for backend in ("torch", "hip"):
+        L.set_backend(backend)
+        try:
+            x = base.clone().requires_grad_(True)
+            loss = L.compute_points_obj_cls_loss_hard_topk(dict(ep, seeds_obj_cls_logits=x), topk)
+            (loss * 3.0).backward()
+            res[backend] = (loss.detach(), x.grad)
+        finally:
+            L.set_backend("hip")
+    assert torch.allclose(res["hip"][0], res["torch"][0], rtol=1e-5, atol=1e-7)
+    assert (res["hip"][1] - res["torch"][1]).abs().max() <= 1e-5 * res["torch"][1].abs().max()
