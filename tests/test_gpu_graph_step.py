@@ -60,3 +60,30 @@ def test_prefetched_sampling_trains_like_inline_sampling():
         assert torch.equal(pre.s_inds_cur, want)
     finally:
         attention_blocks.set_backend("torch")
+
+
+def test_hungarian_criterion_inside_the_graph_equals_the_eager_step():
+    """The reference's criterion (losses.compute_hungarian_loss: device-side assignment, static shapes) is
+    captured in the hipGraph; replays over DIFFERENT batches (different numbers of targets, so different
+    assignments) must give the losses of the plain eager evaluation of the same model and batch."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, HungarianCriterion, synthetic_batch
+    try:
+        dev = torch.device("cuda", 0)
+        batches = [synthetic_batch(2, dev, seed=300 + 11 * i, n_points=4096, tokens=24) for i in range(3)]
+        model = _model()
+        crit = HungarianCriterion(num_decoder_layers=2)
+        eager = []
+        model.eval()                        # no BatchNorm statistics update between the two evaluations
+        for inp, tgt in batches:
+            with torch.no_grad():
+                eager.append(float(crit(model(inp), crit.prepare(tgt))))
+        step = GraphedTrainStep(model, FlatAdamW(model, lr=0.0, lr_backbone=0.0), warmup=1, criterion=crit)
+        graphed = [float(step(inp, tgt)) for inp, tgt in batches]
+        assert len({round(l, 3) for l in eager}) == len(eager)
+        for a, b in zip(graphed, eager):
+            assert abs(a - b) <= 2e-4 * max(abs(b), 1.0), (graphed, eager)
+        n_boxes = [int((t["box_label_mask"] > 0).sum()) for _, t in batches]
+        assert len(set(n_boxes)) > 1, n_boxes
+    finally:
+        attention_blocks.set_backend("torch")

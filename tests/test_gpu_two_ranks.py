@@ -23,7 +23,7 @@ def _worker(rank, world, init_file, out_dir):
     from butd_detr_amd import attention_blocks
     from butd_detr_amd.bdetr import BeaUTyDETR
     from butd_detr_amd.offline_text import offline_factory
-    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, synthetic_batch
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, HungarianCriterion, synthetic_batch
     dist.init_process_group("gloo", init_method=f"file://{init_file}", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -36,7 +36,8 @@ def _worker(rank, world, init_file, out_dir):
                            contrastive_align_loss=True, butd=True, self_attend=True,
                            text_encoder_factory=offline_factory(0)).to(dev).train()
     opt = FlatAdamW(model)
-    step = GraphedTrainStep(model, opt, warmup=1)
+    # the reference's criterion: its box count is averaged over the ranks (losses.py:527-534) outside the graph
+    step = GraphedTrainStep(model, opt, warmup=1, criterion=HungarianCriterion(num_decoder_layers=1))
     batches = [synthetic_batch(2, dev, seed=11 + 5 * i, n_points=4096, tokens=16, rank=rank) for i in range(3)]
     losses = []
     for i, (inp, tgt) in enumerate(batches):
