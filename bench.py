@@ -212,7 +212,7 @@ def ball_query_roofline(inputs, steps=20):
     return {"kernel": ("butd_ball_query_ws: bq_grid_bbox/count/scan/scatter/query" if pruned else "ball_query_kernel")
                       + " (SA1: 2048 centres x %d points, nsample 64, B=%d)" % (n, b),
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None if pruned else _pmc_traffic("ball_query_kernel"),
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("bq_grid_query" if pruned else "ball_query_kernel"),  # pruned: the query kernel only
             "avg_launch_ms": round(ms, 5), "algorithmic_bytes_per_launch": alg_bytes,
             "note": "logical M*N*12-byte stream of SURVEY section 8(d).  The grid-pruned path reads only the 27 "
                     "cells around a centre, the streaming kernel loads each 64-point tile once per 8 centres: "

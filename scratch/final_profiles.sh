@@ -11,3 +11,5 @@ head -12 gpurun_out/final/r01_hip_one_step_summary.txt | cut -c1-120
 bash scratch/pmc.sh > gpurun_out/final/pmc.log 2>&1
 cp gpurun_out/pmc/*.json gpurun_out/final/
 cat gpurun_out/pmc/FETCH_SIZE.json
+timeout 600 python bench.py > gpurun_out/final/r01_bench_default.json 2> gpurun_out/final/bench_default.err
+tail -1 gpurun_out/final/r01_bench_default.json | cut -c1-400

@@ -13,7 +13,7 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     if r.get("Counter_Name") != "$C": continue
     name = r["Kernel_Name"]
-    key = "gemm_kernel" if "gemm_kernel" in name else "ball_query_kernel" if "ball_query_kernel" in name else "attn_fwd_kernel" if "attn_fwd_kernel" in name else "fps_pruned_kernel" if "fps_pruned" in name else None
+    key = "gemm_kernel" if "gemm_kernel" in name else "ball_query_kernel" if "ball_query_kernel" in name else "attn_fwd_kernel" if "attn_fwd_kernel" in name else "fps_pruned_kernel" if "fps_pruned" in name else "bq_grid_query" if "bq_grid_query" in name else "lsap_kernel" if "lsap_kernel" in name else None
     if key:
         agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
 out = {k: {"launches": c, "avg_$C": v / c} for k, (c, v) in agg.items()}
