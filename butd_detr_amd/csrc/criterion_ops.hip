@@ -306,8 +306,9 @@ __global__ __launch_bounds__(kWave * kRowsPerBlock) void contrastive_rows_kernel
   }
 }
 
-// losses.py:476-487 ("Loss 2"); one workgroup per (p,b); thread = (column l, one of kParts query strides)
-constexpr int kColThreads = 256;
+// losses.py:476-487 ("Loss 2"); one workgroup per (p,b) and 64-column chunk; thread = (column l, one of 16
+// query strides), partial (max, sum-exp, count, sum) merged through LDS
+constexpr int kColThreads = 1024;
 
 __global__ __launch_bounds__(kColThreads) void contrastive_cols_kernel(
     int Q, int G, int L, int B, const float *__restrict__ logits, const int *__restrict__ owner,
@@ -321,9 +322,10 @@ __global__ __launch_bounds__(kColThreads) void contrastive_cols_kernel(
   const int *own = owner + (size_t)pb * Q;
   const float *pm_b = positive_map + (size_t)b * G * ldpm;
   float *dx = dlogits + (size_t)pb * Q * L;
-  for (int l0 = 0; l0 < L; l0 += 64) {
+  {
+    const int l0 = blockIdx.y * 64;               // one 64-column chunk per workgroup
     const int cols = (L - l0) < 64 ? (L - l0) : 64;
-    const int parts = kColThreads / 64;           // 4 query strides
+    const int parts = kColThreads / 64;           // 16 query strides
     const int lc = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int l = l0 + lc;
     const bool active = lc < cols;
@@ -520,7 +522,7 @@ int butd_contrastive_cols(int P, int B, int Q, int G, int L, const float *logits
                           float *col_loss, float *dlogits, butd_stream_t stream) {
   if (P * B <= 0 || L <= 0 || Q <= 0) return 0;
   if (ldpm < L) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(contrastive_cols_kernel, dim3((unsigned)(P * B)), dim3(kColThreads),
+  hipLaunchKernelGGL(contrastive_cols_kernel, dim3((unsigned)(P * B), (unsigned)((L + 63) / 64)), dim3(kColThreads),
                      sizeof(float) * 4 * kColThreads, (hipStream_t)stream, Q, G, L, B, logits, owner,
                      positive_map, ldpm, last, eos_coef, col_loss, dlogits);
   return status();

@@ -30,6 +30,9 @@ def prof(name, fn):
         fn(); torch.cuda.synchronize()
     ev = [e for e in p.events() if e.device_type.name == "CUDA"]
     print(f"{name:28s} kernels {len(ev):4d}  device time {sum(e.device_time for e in ev)/1e3:7.3f} ms")
+    if name.startswith("contrastive") or name.startswith("cost") or name.startswith("labels"):
+        for e in sorted(ev, key=lambda e: -e.device_time)[:8]:
+            print(f"      {e.device_time:7.1f} us  {e.name[:90]}")
 def bw(x): x.sum().backward()
 with torch.no_grad():
     prof("cost (torch)", lambda: crit.matcher.cost(logits, boxes, tgt["boxes"], tgt["positive_map"]))
