@@ -903,7 +903,10 @@ int butd_add_dropout_layernorm_bwd(int rows, int cols, const float *dy, const fl
   // one row per wave while that still leaves workgroups for every CU to spare (a 2048-row call is 128
   // workgroups); several rows per wave only for very tall inputs, where it trims the dgamma/dbeta atomics
   static const int forced = getenv("BUTD_LN_RPW") ? atoi(getenv("BUTD_LN_RPW")) : 0;
-  const int rpw = forced ? forced : (rows >= 65536 ? kLnRowsPerWave : 1);
+  // (measured: the column-sum atomics are half of the kernel's time at 8192 rows -- 512 workgroups on the same
+  // 576 addresses; two rows per wave halve them there: 21.2 -> 18.4 us.  Folding private copies with a
+  // last-workgroup ticket needs an agent-scope release per workgroup = an L2 write-back each: 159 us.)
+  const int rpw = forced ? forced : (rows >= 65536 ? kLnRowsPerWave : rows >= 8192 ? 2 : 1);
   const int rows_per_block = (kLnBwdThreads / 64) * rpw;
   const dim3 grid((rows + rows_per_block - 1) / rows_per_block);
   LN_DISPATCH_T(kLnBwdThreads, ln_bwd_kernel, rows, cols, dy, x, residual, gamma, mean, rstd, dx, d_residual, dgamma,
