@@ -6,6 +6,8 @@ running-stat update) or eval (running statistics) mode.  Activations are positio
 matrices; each 1x1 conv is one MFMA GEMM launch whose operand load applies the previous layer's
 BatchNorm+ReLU, so no NCHW tensor, transpose, BN-apply or ReLU pass ever touches HBM.
 """
+import os
+
 import torch
 
 from . import _hiplib
@@ -56,8 +58,11 @@ class _SAMlpPool(torch.autograd.Function):
               feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr(), Kp)
 
         Cm = max(C1, C2, C3)
-        SLOTS = 1      # (256 slotted copies of the sums were measured for the 10^6-row layers: the
-        #                 per-tile epilogue work costs more than the separate 256-row-chunk pass)
+        # 16 private copies of the epilogue's column sums (folded by butd_sa_bn_finalize): a 65 536-row product
+        # ends in 1 024 double atomics per column address otherwise (65536x128x128: 64.9 -> 51.3 us).  (256
+        # copies were measured for the 10^6-row layers: the per-tile epilogue work costs more than the
+        # separate chunked pass.)
+        SLOTS = int(os.environ.get("BUTD_SA_SLOTS", "16"))
         stats = zeros((3, SLOTS, 2, Cm), dtype=torch.float64, device=dev)
         aff = torch.empty((3, 4, max(C1, C2, C3)), device=dev)  # per layer: mean, rstd, scale, shift
         layers = ((g1, b1, rm1, rv1, nbt1, eps1), (g2, b2, rm2, rv2, nbt2, eps2),
