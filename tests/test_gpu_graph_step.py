@@ -87,3 +87,21 @@ def test_hungarian_criterion_inside_the_graph_equals_the_eager_step():
         assert len(set(n_boxes)) > 1, n_boxes
     finally:
         attention_blocks.set_backend("torch")
+
+
+def test_training_on_a_fixed_batch_reduces_the_hungarian_loss():
+    """End-to-end sanity of the gradients through the criterion and the fused blocks: 25 graph-replayed steps on
+    one fixed batch must bring the reference criterion's loss down."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, HungarianCriterion, synthetic_batch
+    try:
+        dev = torch.device("cuda", 0)
+        inp, tgt = synthetic_batch(2, dev, seed=77, n_points=4096, tokens=24)
+        model = _model().train()
+        step = GraphedTrainStep(model, FlatAdamW(model, lr=2e-4, lr_backbone=2e-3), warmup=1,
+                                criterion=HungarianCriterion(num_decoder_layers=2))
+        losses = [float(step(inp, tgt, next_inputs=inp)) for _ in range(25)]
+        assert all(l == l for l in losses), losses
+        assert min(losses[-5:]) < 0.85 * losses[0], losses
+    finally:
+        attention_blocks.set_backend("torch")
