@@ -277,9 +277,12 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://")
+        # backend "nccl" IS RCCL on ROCm.  BUTD_BENCH_BACKEND=gloo + BUTD_BENCH_ONE_GPU=1 exist only so that the
+        # N>1 code path can be rehearsed on a one-GPU box (tests/test_gpu_two_ranks.py): RCCL refuses two ranks
+        # on one device
+        dist.init_process_group(backend=os.environ.get("BUTD_BENCH_BACKEND", "nccl"), init_method="env://")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", 0 if os.environ.get("BUTD_BENCH_ONE_GPU") else local_rank)
     torch.cuda.set_device(device)
 
     from butd_detr_amd.train_step import (GraphedTrainStep, make_optimizer, synthetic_batch,
@@ -288,6 +291,9 @@ def main():
     inputs, targets = synthetic_batch(args.batch, device, n_points=args.points, tokens=args.tokens,
                                       rank=rank)
     criterion = make_criterion(args)
+    # a copy of the targets that already carries the rank-averaged box count, for the rank-0-only eager step of
+    # the roofline section (criterion.prepare is a collective: every rank calls it here)
+    local_targets = criterion.prepare(targets) if criterion is not None else targets
     if args.eager:
         ddp = wrap_data_parallel(model, device)
         opt = make_optimizer(model)
@@ -337,7 +343,8 @@ def main():
                        "attention_backend": backend, "launch": "eager+DDP+torch AdamW" if args.eager else "hipGraph replay (FPS chain of the next batch prefetched on a forked stream) + flat-gradient all-reduce + packed AdamW", "final_loss": round(float(loss), 4)},
         }
         if backend == "hip":
-            out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, targets,
+            # rank 0 only from here on: no collective may run (the criterion's box count was all-reduced above)
+            out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, local_targets,
                                                                    criterion=criterion))
             out["roofline_ball_query"] = ball_query_roofline(inputs)
             out["roofline_attention"] = attention_roofline(args.batch)

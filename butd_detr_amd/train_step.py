@@ -94,6 +94,8 @@ class HungarianCriterion:
         self.num_decoder_layers, self.topk = num_decoder_layers, query_points_obj_topk
 
     def prepare(self, targets):
+        if "num_boxes" in targets:          # already prepared (e.g. a rank-local replay of a batch)
+            return targets
         targets = dict(targets)
         targets["num_boxes"] = self.set_criterion.num_boxes(targets["box_label_mask"] > 0)
         return targets

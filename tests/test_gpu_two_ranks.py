@@ -58,3 +58,23 @@ def test_two_ranks_stay_in_lockstep():
     assert torch.equal(r0["flat_g"], r1["flat_g"])          # identical averaged gradients
     assert torch.equal(r0["flat_p"], r1["flat_p"])          # identical parameters after the updates
     assert torch.isfinite(r0["flat_p"]).all()
+
+
+def test_bench_runs_its_multi_rank_path():
+    """bench.py exactly as the driver launches it for N=2 (torch.distributed.run, env:// rendezvous on
+    127.0.0.1, barriers, max-over-ranks timing, flat gradient all-reduce, one JSON line from rank 0) --
+    rehearsed on one GPU over gloo, because RCCL refuses two ranks on one device."""
+    import json
+    import subprocess
+    env = dict(os.environ, BUTD_BENCH_BACKEND="gloo", BUTD_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29653", os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--points", "8192", "--queries", "64",
+           "--tokens", "24"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["config"]["global_batch"] == 4
+    assert rec["value"] > 0 and rec["scaling"] == "weak" and "cpu_baseline" not in rec
