@@ -116,6 +116,20 @@ CRITERION_SYMBOLS = {
     "butd_contrastive_cols": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P]),
 }
 
+class SceneAugment(ctypes.Structure):
+    """ctypes mirror of ``butd_scene_augment`` (include/butd_augment.h)."""
+    _fields_ = [("rz", ctypes.c_double * 9), ("rx", ctypes.c_double * 9), ("ry", ctypes.c_double * 9),
+                ("shift", ctypes.c_double * 3), ("scale", ctypes.c_double),
+                ("flip_yz", ctypes.c_int32), ("flip_xz", ctypes.c_int32)]
+
+
+_c_double, _c_u64 = ctypes.c_double, ctypes.c_uint64
+AUGMENT_SYMBOLS = {
+    "butd_augment_points": (_c_int, [_c_int] * 4 + [_P] * 4 + [_c_double] * 3 + [_c_u64, _P, _P]),
+    "butd_augment_boxes": (_c_int, [_c_int, _c_int, _P, _P, _P, _P]),
+    "butd_instance_boxes": (_c_int, [_c_int] * 4 + [_P] * 6 + [_P]),
+}
+
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
 ALL_SYMBOLS.update(ATTENTION_SYMBOLS)
 ALL_SYMBOLS.update(SA_SYMBOLS)
@@ -123,6 +137,7 @@ ALL_SYMBOLS.update(OPTIM_SYMBOLS)
 ALL_SYMBOLS.update(MLP_SYMBOLS)
 ALL_SYMBOLS.update(LSAP_SYMBOLS)
 ALL_SYMBOLS.update(CRITERION_SYMBOLS)
+ALL_SYMBOLS.update(AUGMENT_SYMBOLS)
 
 _lib = None
 

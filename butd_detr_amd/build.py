@@ -27,6 +27,7 @@ TU_FLAGS = {
     "fps_pruned.hip": ["-ffp-contract=off"],
     "ball_query_grid.hip": ["-ffp-contract=off"],
     "criterion_ops.hip": ["-ffp-contract=off"],
+    "augment_ops.hip": ["-ffp-contract=off"],
     "attention_ops.hip": [],
 }
 
