@@ -6,6 +6,7 @@ top of the gfx950 kernels:
 
     import butd_detr_amd.dropin as dropin; dropin.install()
     from models import BeaUTyDETR            # -> butd_detr_amd.bdetr.BeaUTyDETR
+    from models import HungarianMatcher, SetCriterion, compute_hungarian_loss   # -> butd_detr_amd.losses
     import pointnet2._ext as _ext            # -> butd_detr_amd.pointnet2_ext (the 9 pybind functions)
     import pointnet2_utils                   # -> butd_detr_amd.pointnet2_utils (Function API)
 
@@ -27,7 +28,7 @@ def install(scope="all", attention_backend="hip"):
     sys.modules["pointnet2._ext"] = pointnet2_ext
     if scope == "ops":
         return
-    from . import (attention_blocks, backbone_module, bdetr, encoder_decoder_layers, modules,
+    from . import (attention_blocks, backbone_module, bdetr, encoder_decoder_layers, losses, modules,
                    pointnet2_modules, pointnet2_utils, pytorch_utils)
     for name, mod in (("pointnet2_utils", pointnet2_utils), ("pointnet2.pointnet2_utils", pointnet2_utils),
                       ("pointnet2_modules", pointnet2_modules), ("pointnet2.pointnet2_modules", pointnet2_modules),
@@ -38,8 +39,13 @@ def install(scope="all", attention_backend="hip"):
     models = types.ModuleType("models")
     models.__path__ = []
     models.BeaUTyDETR = bdetr.BeaUTyDETR
+    # main_utils.py:27: `from models import HungarianMatcher, SetCriterion, compute_hungarian_loss`
+    for name in ("HungarianMatcher", "SetCriterion", "compute_hungarian_loss", "generalized_box_iou3d",
+                 "box_cxcyczwhd_to_xyzxyz"):
+        setattr(models, name, getattr(losses, name))
     for name, mod in (("bdetr", bdetr), ("backbone_module", backbone_module),
-                      ("encoder_decoder_layers", encoder_decoder_layers), ("modules", modules)):
+                      ("encoder_decoder_layers", encoder_decoder_layers), ("modules", modules),
+                      ("losses", losses)):
         setattr(models, name, mod)
         sys.modules[f"models.{name}"] = mod
     sys.modules["models"] = models

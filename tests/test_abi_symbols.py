@@ -89,5 +89,13 @@ def test_dropin_registers_reference_module_names(libpath, monkeypatch):
                   "grouping_operation", "ball_query", "QueryAndGroup", "GroupAll"):
             assert hasattr(pointnet2_utils, n)
         assert BeaUTyDETR.__name__ == "BeaUTyDETR" and callable(gather_operation)
+        from models import HungarianMatcher, SetCriterion, compute_hungarian_loss   # main_utils.py:27
+        import inspect
+        assert list(inspect.signature(HungarianMatcher.__init__).parameters)[1:] == [
+            "cost_class", "cost_bbox", "cost_giou", "soft_token"]              # losses.py:238-239
+        assert list(inspect.signature(SetCriterion.__init__).parameters)[1:] == [
+            "matcher", "losses", "eos_coef", "temperature"]                    # losses.py:341
+        assert list(inspect.signature(compute_hungarian_loss).parameters)[:4] == [
+            "end_points", "num_decoder_layers", "set_criterion", "query_points_obj_topk"]   # losses.py:546-547
     finally:
         attention_blocks.set_backend(prev)
