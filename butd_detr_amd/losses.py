@@ -27,9 +27,6 @@ import torch.nn as nn
 
 from . import _hiplib
 
-PREFIX_ORDER_DOC = "['proposal_', 'last_', '0head_', ..., f'{L-2}head_'] (losses.py:549-550)"
-
-
 def is_dist_avail_and_initialized():
     return dist.is_available() and dist.is_initialized()
 
@@ -338,7 +335,11 @@ class HungarianMatcher(nn.Module):
 
     @torch.no_grad()
     def match_dense(self, pred_logits, pred_boxes, tgt_boxes, positive_map, valid, labels=None):
-        return hungarian_match(self.cost(pred_logits, pred_boxes, tgt_boxes, positive_map, labels, valid), valid)[0]
+        """-> match (..., B, G).  ``self.last_status`` keeps the solver's per-problem status tensor (1 where scipy
+        would have raised: NaN / -inf costs, no feasible assignment) for callers that choose to look."""
+        match, self.last_status = hungarian_match(
+            self.cost(pred_logits, pred_boxes, tgt_boxes, positive_map, labels, valid), valid)
+        return match
 
     @torch.no_grad()
     def forward(self, outputs, targets):
@@ -392,11 +393,11 @@ class SetCriterion(nn.Module):
 
     # -- helpers: rows of a (P, B, Q+1, .) tensor addressed by target slot; invalid slots hit the spare row Q
     def _scatter_rows(self, base, match, valid, rows):
-        """base (P,B,Q,W) <- rows (B,G,W) [or (P,B,G,W)] at query match[p,b,g] for valid slots."""
+        """base (P,B,Q,W) <- rows (B,G,W) at query match[p,b,g] for valid slots."""
         P, B, Q, W = base.shape
         idx = torch.where(valid, match.long(), torch.full_like(match, Q, dtype=torch.long))  # (P,B,G)
         padded = torch.cat([base, base.new_zeros(P, B, 1, W)], dim=2)
-        src = rows if rows.dim() == 4 else rows[None].expand(P, -1, -1, -1)
+        src = rows[None].expand(P, -1, -1, -1)
         padded = padded.scatter(2, idx[..., None].expand(-1, -1, -1, W), src.to(base.dtype))
         return padded[:, :, :Q]
 
@@ -552,4 +553,5 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     end_points["loss_constrastive_align"] = loss_align
     end_points["loss"] = loss
     end_points["hungarian_match"] = match
+    end_points["hungarian_status"] = getattr(set_criterion.matcher, "last_status", None)
     return loss, end_points

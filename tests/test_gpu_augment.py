@@ -1,6 +1,5 @@
 """-m gpu: device-side augmentation (include/butd_augment.h, butd_detr_amd/device_augment.py) against vectors
 captured from the reference's dataset code (tests/golden/make_augment_golden.py) and the numpy oracle."""
-import glob
 import os
 
 import numpy as np
