@@ -21,3 +21,14 @@ for r in win:
 print(f"step wall {(t1 - t0) / 1e6:.3f} ms, kernel busy {busy / 1e6:.3f} ms, {len(win)} launches")
 for name, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{d / 1e6:9.3f} ms {100 * d / busy:5.1f}% x{c:<5d} {name[:150]}")
+
+# category totals
+cats = collections.defaultdict(lambda: [0, 0])
+for name, (c, d) in agg.items():
+    k = ("hand-written HIP" if "anonymous namespace)::" in name and "at::native" not in name else
+         "hipBLASLt/rocBLAS" if name.startswith("Cijk") else "runtime copy/fill" if "rocclr" in name else
+         "torch flash attention" if "attn_fwd" == name or "attn_bwd" in name and "anonymous" not in name else "torch elementwise/other")
+    cats[k][0] += c; cats[k][1] += d
+print("category totals:")
+for k, (c, d) in sorted(cats.items(), key=lambda kv: -kv[1][1]):
+    print(f"{d / 1e6:9.3f} ms {100 * d / busy:5.1f}% x{c:<5d} {k}")
