@@ -12,7 +12,6 @@ The reference's step is ``model(inputs) -> compute_hungarian_loss -> backward ->
   the minimal "all 21.4 M trainable parameters receive gradients" driver for kernel work.
 """
 import numpy as np
-import os
 
 import torch
 import torch.nn.functional as F
