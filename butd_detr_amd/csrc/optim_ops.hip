@@ -1,5 +1,6 @@
 // optim_ops.hip -- flat AdamW update (include/butd_optim.h): one float4 stream over p, g, m, v.
 #include <hip/hip_runtime.h>
+#include <stdint.h>
 #include <math.h>
 
 #include "../../include/butd_optim.h"
@@ -35,7 +36,39 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, 
     *reinterpret_cast<float4 *>(v + o) = make_float4(ve[0], ve[1], ve[2], ve[3]);
   }
 }
+// one workgroup = one 4096-float chunk of one segment (binary search over the segments' first workgroups)
+__global__ __launch_bounds__(256) void gather_segments_kernel(int n, const int64_t *__restrict__ table,
+                                                              float *__restrict__ dst) {
+  const int64_t *src_ptr = table, *dst_off = table + n, *numel = table + 2 * n, *blk = table + 3 * n;
+  int lo = 0, hi = n - 1;
+  const long b = blockIdx.x;
+  while (lo < hi) {  // last segment whose first workgroup <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (blk[mid] <= b) lo = mid; else hi = mid - 1;
+  }
+  const long first = (b - blk[lo]) * BUTD_GATHER_CHUNK;
+  const long count = min((long)BUTD_GATHER_CHUNK, numel[lo] - first);
+  const float *src = reinterpret_cast<const float *>(src_ptr[lo]) + first;
+  float *out = dst + dst_off[lo] + first;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0) {
+    const long n4 = count >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256)
+      reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(src)[i];
+    for (long i = (n4 << 2) + threadIdx.x; i < count; i += 256) out[i] = src[i];
+  } else {
+    for (long i = threadIdx.x; i < count; i += 256) out[i] = src[i];
+  }
+}
 }  // namespace
+
+extern "C" int butd_gather_segments(int n, const int64_t *table, float *dst, butd_stream_t stream,
+                                    long total_blocks) {
+  if (n <= 0 || total_blocks <= 0) return 0;
+  if (total_blocks > 0x7fffffffL) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(gather_segments_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, n,
+                     table, dst);
+  return (int)hipGetLastError();
+}
 
 extern "C" int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, long end, float lr,
                                float beta1, float beta2, float eps, float weight_decay, const float *step,

@@ -264,8 +264,45 @@ class FlatGradients:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
 
+    GATHER_CHUNK = 4096      # BUTD_GATHER_CHUNK (include/butd_optim.h)
+
     def gather(self, grads):
-        torch._foreach_copy_(self.views, grads)
+        """flat[view i] = grads[i].  On the device: ONE launch of butd_gather_segments over a pointer table
+        (rebuilt only when the gradients' addresses change -- inside a captured graph they never do; the
+        table's upload from pinned memory is captured with it)."""
+        if not self.flat.is_cuda or any(g is None or g.dtype != torch.float32 for g in grads):
+            torch._foreach_copy_(self.views, grads)
+            return
+        from . import _hiplib
+        grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
+        key = tuple(g.data_ptr() for g in grads)
+        n = len(grads)
+        if getattr(self, "_gather_host", None) is None:
+            # allocated on the first (eager, warm-up) call: pinned allocations are not capturable
+            self._gather_host = torch.empty(4 * n + 1, dtype=torch.int64).pin_memory()
+            self._gather_table = torch.empty(4 * n + 1, dtype=torch.int64, device=self.flat.device)
+            self._gather_key, self._gather_blocks = None, 0
+        if self._gather_key != key:
+            base = self.flat.data_ptr()
+            dst = [(v.data_ptr() - base) // 4 for v in self.views]
+            numel = [g.numel() for g in grads]
+            blk = [0]
+            for m in numel:
+                blk.append(blk[-1] + (m + self.GATHER_CHUNK - 1) // self.GATHER_CHUNK)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not capturing:
+                torch.cuda.current_stream(self.flat.device).synchronize()   # an earlier upload may still read it
+            self._gather_host.copy_(torch.tensor(list(key) + dst + numel + blk, dtype=torch.int64))
+            # captured: the upload becomes a node that re-reads the pinned buffer at every replay, so the
+            # buffer must not change afterwards (replays do not run this code)
+            self._gather_table.copy_(self._gather_host, non_blocking=True)
+            self._gather_key, self._gather_blocks = key, blk[-1]
+        table, total = self._gather_table, self._gather_blocks
+        lib = _hiplib.load()
+        with torch.cuda.device(self.flat.device):
+            err = lib.butd_gather_segments(n, table.data_ptr(), self.flat.data_ptr(),
+                                           torch.cuda.current_stream(self.flat.device).cuda_stream, total)
+        _hiplib.check(err, "butd_gather_segments")
 
     def attach(self):
         for p, v in zip(self.params, self.views):

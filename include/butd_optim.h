@@ -22,6 +22,14 @@ typedef void *butd_stream_t;
 int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, long end, float lr,
                     float beta1, float beta2, float eps, float weight_decay, const float *step,
                     const float *grad_scale, butd_stream_t stream);
+
+/* Gradient packing: dst[dst_off[i] : dst_off[i] + numel[i]) = src[i][0 : numel[i]) for n segments in ONE
+ * launch (the step gathers ~330 freshly produced parameter gradients into the flat all-reduce / AdamW
+ * buffer; torch's multi-tensor copy takes 10 launches and 0.28 ms for the 85.7 MB).  table: device int64
+ * array [src pointers (n) | dst offsets in floats (n) | numel (n) | first workgroup of every segment
+ * (n + 1)], a workgroup copies BUTD_GATHER_CHUNK consecutive floats of one segment. */
+#define BUTD_GATHER_CHUNK 4096
+int butd_gather_segments(int n, const int64_t *table, float *dst, butd_stream_t stream, long total_blocks);
 #ifdef __cplusplus
 }
 #endif

@@ -47,3 +47,24 @@ def test_flat_adamw_matches_torch_adamw():
     for (n, a), (_, b) in zip(ref.named_parameters(), mine.named_parameters()):
         d = (a - b).abs().detach().cpu().numpy()
         assert (d < 1e-5).mean() > 0.9 and d.max() < 1e-3, (n, d.max())
+
+
+def test_gather_segments_equals_multi_tensor_copy():
+    """FlatGradients.gather: one butd_gather_segments launch (include/butd_optim.h) vs torch._foreach_copy_, on
+    odd sizes, unaligned slices and a re-used table."""
+    from butd_detr_amd.train_step import FlatGradients
+    torch.manual_seed(0)
+    shapes = [(288, 288), (864,), (3,), (1,), (5000, 7), (64, 8), (4097,), (288,), (13, 17, 3)]
+    params = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+    fg = FlatGradients(params)
+    slab = torch.randn(sum(p.numel() for p in params) + 7, device="cuda")
+    for rep in range(3):
+        grads, off = [], 1 if rep == 1 else 0          # rep 1: sources at odd float offsets (unaligned)
+        for p in params:
+            grads.append(slab[off:off + p.numel()].view_as(p) * (rep + 1) if rep == 2 else
+                         slab[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        fg.flat.zero_()
+        fg.gather(grads)
+        want = torch.cat([g.reshape(-1) for g in grads])
+        assert torch.equal(fg.flat, want), rep
