@@ -26,7 +26,8 @@ class Log(TorchDispatchMode):
             for fr in reversed(traceback.extract_stack(limit=40)):
                 if "/butd_detr_amd/" in fr.filename and "op_sites" not in fr.filename:
                     site = f"{os.path.basename(fr.filename)}:{fr.lineno}"; break
-            self.rows[(self.phase, name.replace("aten.", ""), site, numel >= 100000)] += 1
+            tag = shp if any(k in name for k in ("copy", "clone", "contiguous", "fill", "zeros", "cat", "stack")) and numel >= 100000 else (numel >= 100000)
+            self.rows[(self.phase, name.replace("aten.", ""), site, tag)] += 1
         return func(*args, **(kwargs or {}))
 log = Log()
 with log:
@@ -38,5 +39,5 @@ torch.cuda.synchronize()
 tot = collections.Counter()
 for (ph, name, site, big), n in log.rows.items(): tot[ph] += n
 print("ops:", dict(tot))
-for (ph, name, site, big), n in sorted(log.rows.items(), key=lambda kv: -kv[1])[:90]:
-    print(f"{n:4d} {ph} {'BIG' if big else '   '} {name:34s} {site}")
+for (ph, name, site, big), n in sorted(log.rows.items(), key=lambda kv: -kv[1]):
+    print(f"{n:4d} {ph} {str(big) if not isinstance(big, bool) else ('BIG' if big else '   '):22s} {name:30s} {site}")
