@@ -258,7 +258,8 @@ def cpu_baseline(args, scenes):
         attention_blocks.set_backend(prev_backend)
     return {"value": round(scenes / dt, 4), "unit": "scenes/s", "cores": cores, "kind": "port",
             "sample": f"{reps} timed fwd+bwd+optimizer steps of {scenes} scene(s) x {args.points} points "
-                      f"after 1 warm-up, oracle C ops (OpenMP) + torch CPU fp32"}
+                      f"after 1 warm-up, oracle C ops (OpenMP) + torch CPU fp32"
+                      + (", reference criterion with scipy's linear_sum_assignment" if criterion is not None else "")}
 
 
 def make_criterion(args):
