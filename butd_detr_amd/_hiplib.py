@@ -57,6 +57,7 @@ class GemmProblem(ctypes.Structure):
 
 ATTENTION_SYMBOLS = {
     "butd_gemm_grouped": (_c_int, [ctypes.POINTER(GemmProblem), _c_int, _c_void_p, _c_void_p]),
+    "butd_gemm_set_tile": (_c_int, [_c_int, _c_int]),
     "butd_attention_fwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_attention_bwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
                            + [_c_float, _c_u32, _c_void_p, _c_void_p]),

@@ -79,6 +79,12 @@ typedef struct {
 int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64_t *rng_counter,
                       butd_stream_t stream);
 
+/* Tuning hook: force the workgroup tile (tile_m x tile_n, an entry of the kernel's menu: 32x32, 64x64,
+ * 32x96, 64x96, 96x32, 128x64, 128x96; (64, -64) = 64x64 on the one-slab-ahead K loop) of every following
+ * butd_gemm_grouped launch; (0, 0) returns to the built-in choice.  Returns 0 or hipErrorInvalidValue.
+ * Not thread-safe. */
+int butd_gemm_set_tile(int tile_m, int tile_n);
+
 /* Scaled-dot-product attention core for head_dim <= 48 (BUTD-DETR: 8 heads x 36).
  * q (B,Lq,H*D) already scaled by 1/sqrt(D) (the projection's epilogue does it), k, v (B,Lk,H*D);
  * key_padding_mask (B,Lk) uint8, nonzero = masked (may be NULL); out (B,Lq,H*D);

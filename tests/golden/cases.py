@@ -55,3 +55,52 @@ def bdetr_inputs():
                      "the lamp on the desk"],
             "det_boxes": torch.from_numpy(boxes), "det_bbox_label_mask": torch.from_numpy(mask),
             "det_class_ids": torch.from_numpy(cls)}
+
+
+# ---- train-mode BeaUTyDETR golden (bdetr_4096_train6.npz): shared by make_golden.py and the tests ----
+TRAIN_GRAD_KEYS = (
+    "backbone_net.sa1.mlp_module.layer0.conv.weight", "backbone_net.fp2.mlp.layer1.conv.weight",
+    "cross_encoder.layers.0.self_attention_visual.self_attn.in_proj_weight",
+    "cross_encoder.layers.2.cross_layer.cross_d.out_proj.weight",
+    "cross_encoder.layers.1.cross_layer.ffn_lv.0.weight",
+    "decoder.0.self_attn.in_proj_weight", "decoder.3.cross_v.in_proj_weight", "decoder.5.ffn.3.weight",
+    "decoder.5.cross_l.out_proj.bias", "prediction_heads.4.center_residual_head.net.0.weight",
+    "proposal_head.size_pred_head.net.8.weight", "contrastive_align_projection_image.0.weight",
+    "text_projector.0.weight", "points_obj_cls.conv2.weight")
+PREFIXES = ("proposal_", "0head_", "1head_", "2head_", "3head_", "4head_", "last_")
+
+
+def zero_dropout(model):
+    """Train mode without randomness: every Dropout p = 0 (the attention modules keep their own p)."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(getattr(m, "dropout", None), float):
+            m.dropout = 0.0
+    return model
+
+
+def by_seed(ep, t):
+    """Rows of a per-query tensor (B, Q, C) re-ordered by the query's seed index: the model orders its queries
+    by objectness (top-k), and two logits within rounding distance of each other may swap places between two
+    fp32 implementations; the decoder is permutation-equivariant over queries, so everything compared or
+    differentiated in this case is expressed per SEED, not per position."""
+    order = torch.argsort(ep["query_points_sample_inds"].long(), dim=1)
+    return torch.gather(t, 1, order[..., None].expand(-1, -1, t.shape[-1]))
+
+
+def train_loss(ep):
+    """Dense scalar touching every head of every prefix: fixed random cotangents attached to the seed a
+    query sits on (see by_seed), so the loss and its gradients do not depend on the order of the queries."""
+    dev = ep["seeds_obj_cls_logits"].device
+    inds = ep["query_points_sample_inds"].long()
+    loss = (ep["seeds_obj_cls_logits"] * probe(ep["seeds_obj_cls_logits"].shape, 40).to(dev)).sum()
+    loss = loss + (ep["proj_tokens"] * probe(ep["proj_tokens"].shape, 41).to(dev)).sum()
+    n_seed = ep["seeds_obj_cls_logits"].shape[-1]
+    for i, pre in enumerate(PREFIXES):
+        for j, k in enumerate(("center", "pred_size", "sem_cls_scores", "proj_queries")):
+            t = ep[pre + k]
+            per_seed = probe((t.shape[0], n_seed, t.shape[-1]), 50 + 4 * i + j).to(dev)
+            cot = torch.gather(per_seed, 1, inds[..., None].expand(-1, -1, t.shape[-1]))
+            loss = loss + (t * cot).sum()
+    return loss

@@ -31,8 +31,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
 from golden import text_stub, weights  # noqa: E402
-from golden.cases import (backbone_inputs, bdetr_inputs, decoder_inputs, encoder_inputs,  # noqa: E402
-                          probe)
+from golden.cases import (PREFIXES, TRAIN_GRAD_KEYS, backbone_inputs, bdetr_inputs, by_seed,  # noqa: E402
+                          decoder_inputs, encoder_inputs, probe, train_loss, zero_dropout)
 
 
 def load_reference():
@@ -154,6 +154,44 @@ def golden_bdetr(bdetr):
     npz("bdetr_4096_eval.npz", **out)
 
 
+def golden_bdetr_train(bdetr):
+    """BeaUTyDETR in TRAIN mode (BatchNorm batch statistics, dropout p = 0), all 6 decoder layers,
+    forward + gradients -- the config-2 architecture on a 4096-point cloud."""
+    tok, txt = text_stub.factory()
+    bdetr.RobertaTokenizerFast = types.SimpleNamespace(from_pretrained=lambda *_a, **_k: tok)
+    bdetr.RobertaModel = types.SimpleNamespace(from_pretrained=lambda *_a, **_k: txt)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        model = bdetr.BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3,
+                                 num_queries=82, num_decoder_layers=6,
+                                 self_position_embedding="loc_learned", contrastive_align_loss=True,
+                                 butd=True, pointnet_ckpt=None, self_attend=True)
+    finally:
+        os.chdir(cwd)
+    weights.fill_(model, seed=15, skip_prefixes=("text_encoder.",))
+    model.train()
+    zero_dropout(model)
+    ep = model(bdetr_inputs())
+    train_loss(ep).backward()
+    out = {"seed_inds": ep["seed_inds"],
+           "query_seeds_sorted": torch.sort(ep["query_points_sample_inds"].long(), dim=1)[0],
+           "seeds_obj_cls_logits": ep["seeds_obj_cls_logits"], "proj_tokens": ep["proj_tokens"],
+           "seed_features_b0": ep["seed_features"][0]}
+    for pre in PREFIXES:
+        out[pre + "center"] = by_seed(ep, ep[pre + "center"])
+        out[pre + "pred_size"] = by_seed(ep, ep[pre + "pred_size"])
+        out[pre + "sem_cls_scores_head"] = by_seed(ep, ep[pre + "sem_cls_scores"])[:, :, :32]
+    out["last_proj_queries"] = by_seed(ep, ep["last_proj_queries"])
+    p = dict(model.named_parameters())
+    missing = [n for n, q in p.items() if q.requires_grad and q.grad is None]
+    assert not missing, missing            # DDP without find_unused_parameters relies on this
+    for k in TRAIN_GRAD_KEYS:
+        out["g_" + k] = p[k].grad
+    out["running_mean_sa2_l1"] = model.backbone_net.sa2.mlp_module.layer1.bn.bn.running_mean
+    npz("bdetr_4096_train6.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     enc_m, bb_m, bdetr_m = load_reference()
@@ -161,3 +199,4 @@ if __name__ == "__main__":
     golden_decoder(enc_m)
     golden_backbone(bb_m)
     golden_bdetr(bdetr_m)
+    golden_bdetr_train(bdetr_m)

@@ -149,3 +149,48 @@ def test_bdetr_state_dict_keys_and_forward_match_reference_golden(cpu_ops):
     # optimizer grouping of main_utils.py:258-280 relies on these substrings
     names = [n for n, _ in model.named_parameters()]
     assert any("backbone_net" in n for n in names)
+
+
+def _check_train6(ep, model, g, out_close, g_close, backbone_tol=None):
+    """Outputs of all 7 prefixes + gradients vs bdetr_4096_train6.npz (reference, train mode, dropout 0)."""
+    from tests.golden.cases import PREFIXES, TRAIN_GRAD_KEYS, by_seed
+    np.testing.assert_array_equal(ep["seed_inds"].cpu().numpy(), g["seed_inds"])
+    # the same SET of seeds becomes queries (their order may differ by swaps of near-equal logits: by_seed)
+    np.testing.assert_array_equal(torch.sort(ep["query_points_sample_inds"].long(), dim=1)[0].cpu().numpy(),
+                                  g["query_seeds_sorted"])
+    for k in ("seeds_obj_cls_logits", "proj_tokens"):
+        out_close(ep[k], g[k])
+    out_close(by_seed(ep, ep["last_proj_queries"]), g["last_proj_queries"])
+    out_close(ep["seed_features"][0], g["seed_features_b0"])
+    for pre in PREFIXES:
+        out_close(by_seed(ep, ep[pre + "center"]), g[pre + "center"])
+        out_close(by_seed(ep, ep[pre + "pred_size"]), g[pre + "pred_size"])
+        out_close(by_seed(ep, ep[pre + "sem_cls_scores"])[:, :, :32], g[pre + "sem_cls_scores_head"])
+    p = dict(model.named_parameters())
+    for k in TRAIN_GRAD_KEYS:
+        if backbone_tol is not None and k.startswith("backbone_net."):
+            backbone_tol(p[k].grad, g["g_" + k])
+        else:
+            g_close(p[k].grad, g["g_" + k])
+    out_close(model.backbone_net.sa2.mlp_module.layer1.bn.bn.running_mean, g["running_mean_sa2_l1"])
+
+
+def test_bdetr_train_mode_six_decoder_layers_matches_reference_golden(cpu_ops):
+    """The config-2 architecture (3 encoder + 6 decoder layers) in TRAIN mode: BatchNorm batch statistics,
+    every prefix's heads, gradients from the backbone to the last decoder layer."""
+    import warnings
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from tests.golden.cases import train_loss, zero_dropout
+    g = load("bdetr_4096_train6.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=82,
+                           num_decoder_layers=6, self_position_embedding="loc_learned",
+                           contrastive_align_loss=True, butd=True, pointnet_ckpt=None, self_attend=True,
+                           text_encoder_factory=text_stub.factory,
+                           class_embeddings_path="/nonexistent/class_embeddings3d.npy")
+    weights.fill_(model, seed=15, skip_prefixes=("text_encoder.",))
+    zero_dropout(model.train())
+    ep = model(bdetr_inputs())
+    train_loss(ep).backward()
+    _check_train6(ep, model, g, close, grad_close)

@@ -17,8 +17,29 @@ def _close(a, b, tol=2e-4, what=""):
     assert err <= tol, f"{what}: {err:.3e}"
 
 
+TILES = [(0, 0), (32, 32), (32, -32), (64, 64), (64, -64), (32, 96), (32, -96), (64, 96), (64, -96), (96, 32), (96, -32),
+         (128, 64), (128, -64), (128, 96), (128, -96)]   # negative: the one-slab-ahead K loop
+
+
+@pytest.fixture(params=TILES, ids=lambda t: "auto" if t == (0, 0) else "tile%dx%d%s" % (t[0], abs(t[1]), "-one-ahead" if t[1] < 0 else ""))
+def tile(request):
+    """Every workgroup tile of the kernel's menu (butd_gemm_set_tile), and the built-in choice."""
+    from butd_detr_amd import _hiplib
+    lib = _hiplib.load()
+    assert lib.butd_gemm_set_tile(*request.param) == 0
+    yield request.param
+    assert lib.butd_gemm_set_tile(0, 0) == 0
+
+
+def test_set_tile_rejects_unknown():
+    from butd_detr_amd import _hiplib
+    lib = _hiplib.load()
+    assert lib.butd_gemm_set_tile(48, 48) != 0
+    assert lib.butd_gemm_set_tile(0, 0) == 0
+
+
 @pytest.mark.parametrize("seed", range(12))
-def test_random_group(seed):
+def test_random_group(seed, tile):
     from butd_detr_amd import fused_attention as fa
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda", 0)
@@ -71,11 +92,14 @@ def test_random_group(seed):
             dy, x = r(M, N), r(M, K)
             dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
             with_bias = bool(rng.random() < 0.6)
-            keep += [dy, x, dw, db]
-            probs.append(fa._wgrad(dy, x, dw, db if with_bias else None, M, N, K))
+            # BatchNorm + ReLU of the producing layer folded into the B operand (channel = column of x)
+            baff = (torch.rand(K, device=dev, generator=g) + 0.5, r(K)) if rng.random() < 0.3 else None
+            keep += [dy, x, dw, db, baff]
+            probs.append(fa._wgrad(dy, x, dw, db if with_bias else None, M, N, K, b_affine=baff))
+            xd = x.double() if baff is None else torch.relu(x.double() * baff[0].double() + baff[1].double())
 
-            def check(dw=dw, db=db, dy=dy, x=x, with_bias=with_bias):
-                _close(dw, dy.double().t() @ x.double(), 5e-4)
+            def check(dw=dw, db=db, dy=dy, x=xd, with_bias=with_bias):
+                _close(dw, dy.double().t() @ x, 5e-4)
                 if with_bias:
                     _close(db, dy.double().sum(0), 5e-4)
             checks.append(check)

@@ -147,3 +147,36 @@ def test_bdetr_golden(backend):
               "last_pred_size", "last_sem_cls_scores", "last_proj_queries"):
         close(ep[k], g[k])
     close(ep["seed_features"][0], g["seed_features_b0"])
+
+
+def test_bdetr_train_six_layers_golden(backend):
+    """Train mode (BatchNorm batch statistics, dropout p = 0), 3 encoder + 6 decoder layers, every prefix,
+    gradients from the backbone to the last decoder layer -- vs the reference (bdetr_4096_train6.npz)."""
+    import warnings
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from tests.golden.cases import train_loss, zero_dropout
+    from tests.test_golden_modules_cpu import _check_train6
+    g = load("bdetr_4096_train6.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=82,
+                           num_decoder_layers=6, self_position_embedding="loc_learned",
+                           contrastive_align_loss=True, butd=True, pointnet_ckpt=None, self_attend=True,
+                           text_encoder_factory=text_stub.factory,
+                           class_embeddings_path="/nonexistent/class_embeddings3d.npy")
+    weights.fill_(model, seed=15, skip_prefixes=("text_encoder.",))
+    zero_dropout(model.cuda().train())
+    ep = model(cuda(bdetr_inputs()))
+    train_loss(ep).backward()
+    # Gradients: two fp32 implementations of this train-mode model differ by more than the forward 1e-3 --
+    # the heads normalise over only 2 x 82 samples (BatchNorm1d batch statistics), whose backward subtracts
+    # batch means (cancellation); stock torch on this GPU lands at 4e-3 of the scale against the CPU-run
+    # reference, the fused path at 1.6e-2 on the last decoder layer (scratch/diag_train6.py).  Bound: 2e-2
+    # max, 5e-3 mean.
+    def grad_close(t, ref):
+        a = t.detach().float().cpu().numpy()
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = np.abs(a - ref) / scale
+        assert err.max() <= 2e-2 and err.mean() <= 5e-3, (err.max(), err.mean())
+
+    _check_train6(ep, model, g, close, grad_close, backbone_tol=grad_close)

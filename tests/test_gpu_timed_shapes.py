@@ -1,0 +1,218 @@
+"""-m gpu: parity AT THE SHAPES bench.py TIMES (BASELINE.json configs[2]: 8 scenes x 50 000 points, 1024
+seeds, 256 queries, 80 tokens, 132 box slots, 3 encoder + 6 decoder layers).
+
+* every (Lq, Lk) of the attention call sites (/root/reference/models/encoder_decoder_layers.py:87-122,
+  356-404) at B = 8, fused gfx950 block vs the stock-torch maths, forward + backward: 1024 x 1024 self +
+  pos, 256 x 1024 cross + pos, 1024 x 132 / 1024 x 80 masked, 80 x 1024, the decoder's 256-query calls --
+  the launches with NG = 1 and >= 3 key tiles, and the NG = 2 ones;
+* the SA1 module at N = 50 000, npoint 2048, nsample 64, B = 8 (P = 2^20 grouped rows) vs the torch module;
+* the whole config-2 model, train mode, dropout 0, hip vs torch: outputs, loss, gradients.
+Tolerance: north_star's 1e-3 (of the tensor's scale) on outputs, 2e-3 on gradients."""
+import copy
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, tol, name="", frac=0.0):
+    a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+    scale = max(np.abs(b).max(), 1e-6)
+    bad = np.abs(a - b) / scale > tol
+    assert bad.mean() <= frac, f"{name}: {bad.sum()}/{bad.size} beyond {tol}; max {np.abs(a - b).max() / scale:.3e}"
+
+
+# (pattern, Lq, Lk, masked): the call sites of one BiEncoderLayer / BiDecoderLayer at config 2
+SITES = [
+    ("self_pos", 1024, 1024, False),   # encoder visual self-attention (a10)
+    ("self", 80, 80, True),            # encoder language self-attention (a11)
+    ("cross", 80, 1024, False),        # cross_lv: text <- seeds
+    ("cross_pos", 1024, 80, True),     # cross_vl: seeds <- text
+    ("cross_pos", 1024, 132, True),    # cross_d: seeds <- boxes
+    ("self_pos", 256, 256, False),     # decoder self-attention
+    ("cross_pos", 256, 80, True),      # decoder cross_l
+    ("cross_pos", 256, 132, True),     # decoder cross_d
+    ("cross_pos", 256, 1024, False),   # decoder cross_v
+]
+
+
+@pytest.mark.parametrize("pattern,Lq,Lk,masked", SITES,
+                         ids=[f"{p}-{q}x{k}" + ("-masked" if m else "") for p, q, k, m in SITES])
+def test_attention_sites_at_batch_8(pattern, Lq, Lk, masked):
+    from butd_detr_amd import attention_blocks as ab
+    from butd_detr_amd.encoder_decoder_layers import MultiheadAttention
+    torch.manual_seed(Lq * 3 + Lk)
+    B, E, H = 8, 288, 8
+    is_self = pattern.startswith("self")
+    attn = MultiheadAttention(E, H, dropout=0.0).cuda().train()
+    norm = torch.nn.LayerNorm(E).cuda()
+    with torch.no_grad():
+        attn.in_proj_bias.uniform_(-0.1, 0.1)
+        attn.out_proj.bias.uniform_(-0.1, 0.1)
+        norm.weight.uniform_(0.8, 1.2)
+        norm.bias.uniform_(-0.1, 0.1)
+    drop = torch.nn.Dropout(0.0)
+    x = torch.randn(B, Lq, E, device="cuda", requires_grad=True)
+    pos = torch.randn(B, Lq, E, device="cuda", requires_grad=True) if pattern.endswith("pos") else None
+    mem = None if is_self else torch.randn(B, Lk, E, device="cuda", requires_grad=True)
+    mask = None
+    if masked:   # 0-30 % right padding like the synthetic batches
+        mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+        for b in range(B):
+            mask[b, Lk - (b * Lk * 3) // (10 * B) - 1:] = True
+    probe = torch.randn(B, Lq, E, device="cuda")
+    leaves = [t for t in (x, pos, mem) if t is not None]
+    params = list(attn.parameters()) + list(norm.parameters())
+
+    def run(backend):
+        ab.set_backend(backend)
+        for t in leaves + params:
+            t.grad = None
+        y = ab.block(attn, drop, norm, x=x, pos=pos, memory=mem, key_padding_mask=mask)
+        (y * probe).sum().backward()
+        return y, [t.grad.clone() for t in leaves + params]
+
+    try:
+        y_ref, g_ref = run("torch")
+        y_hip, g_hip = run("hip")
+    finally:
+        ab.set_backend("torch")
+    _close(y_hip, y_ref, 1e-3, "y")
+    for i, (gh, gr) in enumerate(zip(g_hip, g_ref)):
+        _close(gh, gr, 2e-3, f"grad {i}")
+
+
+def test_ffn_block_at_batch_8():
+    from butd_detr_amd import fused_attention as fa
+    from butd_detr_amd.encoder_decoder_layers import _ffn
+    torch.manual_seed(3)
+    E = 288
+    for L in (1024, 256, 80):
+        ffn = _ffn(E, 256, 0.0).cuda().train()
+        norm = torch.nn.LayerNorm(E).cuda()
+        x = torch.randn(8, L, E, device="cuda", requires_grad=True)
+        probe = torch.randn(8, L, E, device="cuda")
+        params = list(ffn.parameters()) + list(norm.parameters())
+
+        def run(fn):
+            for t in [x] + params:
+                t.grad = None
+            y = fn(x)
+            (y * probe).sum().backward()
+            return y, [t.grad.clone() for t in [x] + params]
+
+        y_ref, g_ref = run(lambda t: norm(t + ffn(t)))
+        y_hip, g_hip = run(lambda t: fa.ffn_block(ffn, norm, t))
+        _close(y_hip, y_ref, 1e-3, f"ffn {L}")
+        for gh, gr in zip(g_hip, g_ref):
+            _close(gh, gr, 2e-3, f"ffn {L} grad")
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_sa1_module_at_full_size(train):
+    """N = 50 000, npoint 2048, nsample 64, B = 8: P = 2^20 grouped rows (the tall-input branches of the SA
+    streaming kernels and the 512-slice weight gradient only run at this size)."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.pointnet2_modules import PointnetSAModuleVotes
+    from butd_detr_amd.train_step import synthetic_batch
+    torch.manual_seed(5 + train)
+    B = 8
+    ref = PointnetSAModuleVotes(npoint=2048, radius=0.2, nsample=64, mlp=[3, 64, 64, 128], use_xyz=True,
+                                normalize_xyz=True).cuda()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.1, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    fused = copy.deepcopy(ref)
+    ref.train(train)
+    fused.train(train)
+    inputs, _ = synthetic_batch(B, torch.device("cuda", 0), seed=1184, n_points=50000, tokens=80)
+    pc = inputs["point_clouds"]
+    xyz = pc[..., :3].contiguous()
+    feats = pc[..., 3:].transpose(1, 2).contiguous()
+    f1 = feats.clone().requires_grad_(True)
+    f2 = feats.clone().requires_grad_(True)
+    probe = torch.randn(B, 128, 2048, device="cuda")
+    attention_blocks.set_backend("torch")
+    x1, y1, i1 = ref(xyz, f1)
+    (y1 * probe).sum().backward()
+    attention_blocks.set_backend("hip")
+    try:
+        x2, y2, i2 = fused(xyz, f2)
+        assert fused.last_features_pm is not None, "fused path not taken"
+        (y2 * probe).sum().backward()
+    finally:
+        attention_blocks.set_backend("torch")
+    assert torch.equal(i1, i2) and torch.equal(x1, x2)
+    _close(y2, y1, 1e-3, "features")
+    _close(f2.grad, f1.grad, 2e-3, "d features", 1e-3)   # arg-max flips between near-equal candidates
+    for (n, p1), (_, p2) in zip(ref.named_parameters(), fused.named_parameters()):
+        if train or "bn" not in n:
+            _close(p2.grad, p1.grad, 1e-2, n, 1e-3)   # sums over 2^20 positions, fp32 reassociation
+    if train:
+        for (n, b1), (_, b2) in zip(ref.named_buffers(), fused.named_buffers()):
+            if "num_batches" not in n:
+                _close(b2, b1, 1e-4, n)
+
+
+def test_config2_model_train_mode_hip_vs_torch():
+    """The benchmarked model itself: 8 x 50 000 points, 3 encoder + 6 decoder layers, 256 queries, 80
+    tokens, train mode (BatchNorm batch statistics), dropout 0: fused gfx950 path vs the stock-torch maths
+    of the same modules -- end points of every prefix, the loss and gradients from every part."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from butd_detr_amd.offline_text import offline_factory
+    from butd_detr_amd.train_step import surrogate_loss, synthetic_batch
+    from tests.golden.cases import zero_dropout
+    try:
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=256,
+                             num_decoder_layers=6, self_position_embedding="loc_learned",
+                             contrastive_align_loss=True, butd=True, self_attend=True,
+                             text_encoder_factory=offline_factory(0)).cuda()
+        zero_dropout(ref.train())
+        fused = copy.deepcopy(ref)
+        inputs, targets = synthetic_batch(8, torch.device("cuda", 0), seed=1184, n_points=50000, tokens=80)
+        assert inputs["point_clouds"].shape == (8, 50000, 6)
+        outs = {}
+        for name, model, backend in (("torch", ref, "torch"), ("hip", fused, "hip")):
+            attention_blocks.set_backend(backend)
+            ep = model(inputs)
+            loss = surrogate_loss(ep, targets)
+            loss.backward()
+            outs[name] = (ep, float(loss.detach()),
+                          {n: p.grad for n, p in model.named_parameters() if p.grad is not None})
+        ep_t, loss_t, g_t = outs["torch"]
+        ep_h, loss_h, g_h = outs["hip"]
+        assert ep_h["last_sem_cls_scores"].shape == (8, 256, 256) and ep_h["text_feats"].shape[1] == 80
+        for key in ("sa1_inds", "sa2_inds", "fp2_inds", "seed_inds"):
+            assert torch.equal(ep_h[key], ep_t[key]), key
+        for key in ("fp2_features", "seed_features", "text_memory", "seeds_obj_cls_logits", "proj_tokens"):
+            _close(ep_h[key], ep_t[key], 1e-3, key)
+        # the 256 queries are the top-k seeds by objectness: two logits within rounding distance may swap,
+        # which replaces whole query rows -- tolerate 1 % of them
+        same = (ep_h["query_points_sample_inds"] == ep_t["query_points_sample_inds"]).float().mean().item()
+        assert same >= 0.98, same
+        for pre in ("proposal_", "0head_", "2head_", "4head_", "last_"):
+            for k in ("center", "pred_size", "sem_cls_scores", "proj_queries"):
+                _close(ep_h[pre + k], ep_t[pre + k], 1e-3, pre + k, frac=1e-2)
+        assert abs(loss_h - loss_t) <= 1e-3 * max(abs(loss_t), 1.0)
+        assert set(g_h) == set(g_t)
+        for n in ("backbone_net.sa1.mlp_module.layer0.conv.weight", "backbone_net.sa2.mlp_module.layer1.conv.weight",
+                  "backbone_net.fp2.mlp.layer0.conv.weight",
+                  "cross_encoder.layers.0.self_attention_visual.self_attn.in_proj_weight",
+                  "cross_encoder.layers.2.cross_layer.ffn_vl.0.weight",
+                  "cross_encoder.layers.1.cross_layer.cross_d.in_proj_weight",
+                  "decoder.0.self_attn.out_proj.weight", "decoder.5.cross_v.in_proj_weight", "decoder.3.ffn.0.weight",
+                  "prediction_heads.4.center_residual_head.net.0.weight", "text_projector.0.weight"):
+            _close(g_h[n], g_t[n], 1e-2 if n.startswith("backbone_net") else 3e-3, n, frac=1e-3)
+    finally:
+        attention_blocks.set_backend("torch")
