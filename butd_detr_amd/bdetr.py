@@ -136,6 +136,8 @@ class BeaUTyDETR(nn.Module):
 
         self.overlap_text_tower = os.environ.get("BUTD_TEXT_OVERLAP", "1") != "0"   # env: debug hook
         self._side_stream = None
+        # gradient boundary between the encoder and the decoder (see cut_at_encoder_output)
+        self._boundary = None
         self.init_bn_momentum()
 
     # ------------------------------------------------------------------ backbones
@@ -242,6 +244,7 @@ class BeaUTyDETR(nn.Module):
                                      device=points_xyz.device),
             text_feats=text_feats, text_padding_mask=text_padding_mask, end_points=end_points,
             detected_feats=detected_feats, detected_mask=detected_mask)
+        vis, text_feats, detected_feats = self._cut(vis, text_feats, detected_feats)
         points_features = vis.transpose(1, 2).contiguous()       # (B, d, V)
         end_points["text_memory"] = text_feats
         end_points["seed_features"] = points_features
@@ -285,6 +288,28 @@ class BeaUTyDETR(nn.Module):
             for i, (prefix, _) in enumerate(proj_inputs):
                 end_points[f"{prefix}proj_queries"] = proj[i]
         return end_points
+
+    # parameters whose gradients are complete only once backward has passed the encoder: everything else
+    # (decoder, heads, query generation, contrastive projections) is done when backward reaches the three
+    # tensors the decoder reads from the encoder side -- the first bucket of an overlapped gradient exchange
+    # (DistributedDataParallel's buckets do the same in reverse registration order, main_utils.py:310-313)
+    pre_boundary_prefixes = ("backbone_net.", "text_encoder.", "text_projector.", "pos_embed.", "box_embeddings.",
+                             "class_embeddings.", "butd_class_embeddings.", "cross_encoder.")
+
+    def cut_at_encoder_output(self, enable=True):
+        """Two-stage backward: with the cut enabled a forward hands the decoder DETACHED copies of the encoder
+        outputs (visual features, text features, box features) and records (outputs, copies) in
+        ``self._boundary``; ``loss.backward()`` then stops at the copies (stage 1: decoder-side gradients
+        final), and ``torch.autograd.backward(outputs, [c.grad for c in copies])`` runs the rest (stage 2)."""
+        self._boundary = [] if enable else None
+
+    def _cut(self, *tensors):
+        if self._boundary is None or not torch.is_grad_enabled():
+            return tensors
+        outs = [t for t in tensors if t is not None and t.requires_grad]
+        copies = {id(t): t.detach().requires_grad_(True) for t in outs}
+        self._boundary.append((outs, [copies[id(t)] for t in outs]))
+        return tuple(copies.get(id(t), t) if t is not None else None for t in tensors)
 
     def init_bn_momentum(self):
         for m in self.modules():

@@ -10,7 +10,12 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, 
                                                          float *__restrict__ m, float *__restrict__ v,
                                                          long begin, long end, float lr, float b1, float b2,
                                                          float eps, float wd, const float *__restrict__ step,
-                                                         const float *__restrict__ grad_scale) {
+                                                         const float *__restrict__ grad_scale,
+                                                         const float *__restrict__ hyper) {
+  if (hyper) {   // {lr, weight_decay} of this group, device-resident: a captured graph follows the scheduler
+    lr = hyper[0];
+    wd = hyper[1];
+  }
   const float t = *step;
   const float gs = grad_scale ? *grad_scale : 1.f;
   const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
@@ -72,13 +77,13 @@ extern "C" int butd_gather_segments(int n, const int64_t *table, float *dst, but
 
 extern "C" int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, long end, float lr,
                                float beta1, float beta2, float eps, float weight_decay, const float *step,
-                               const float *grad_scale, butd_stream_t stream) {
+                               const float *grad_scale, const float *hyper, butd_stream_t stream) {
   if (end <= begin) return 0;
   if ((begin & 3) || (end & 3)) return (int)hipErrorInvalidValue;  // segments are padded to 4 floats
   const long n4 = (end - begin) >> 2;
   long blocks = (n4 + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(adamw_flat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v,
-                     begin, end, lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+                     begin, end, lr, beta1, beta2, eps, weight_decay, step, grad_scale, hyper);
   return (int)hipGetLastError();
 }

@@ -12,12 +12,31 @@ top of the gfx950 kernels:
 
 ``scope='ops'`` registers only the operator layer (``pointnet2._ext``), leaving the reference's own
 Python modules in charge -- the smallest possible swap.
+
+What this package does not re-implement stays the reference's: the ``models`` stand-in keeps the
+reference's ``models/`` directory on its ``__path__`` (``reference_root``, default: a ``models/ap_helper.py``
+found on ``sys.path``), so ``from models import APCalculator, parse_predictions, parse_groundtruths``
+(train_dist_mod.py:24) resolves lazily to the reference's own ``models/ap_helper.py`` instead of being shadowed.
 """
+import importlib
+import os
 import sys
 import types
 
+# names train_dist_mod.py:24 takes from the package that live in the reference's models/ap_helper.py
+_AP_HELPER_NAMES = ("APCalculator", "parse_predictions", "parse_groundtruths")
 
-def install(scope="all", attention_backend="hip"):
+
+def _find_reference_models(reference_root):
+    roots = [reference_root] if reference_root else list(sys.path) + [os.getcwd()]
+    for r in roots:
+        d = os.path.join(r or ".", "models")
+        if os.path.isfile(os.path.join(d, "ap_helper.py")):
+            return d
+    return None
+
+
+def install(scope="all", attention_backend="hip", reference_root=None):
     from . import pointnet2_ext
     pkg = sys.modules.get("pointnet2")
     if pkg is None:
@@ -37,7 +56,19 @@ def install(scope="all", attention_backend="hip"):
     pkg.pointnet2_utils = pointnet2_utils
     pkg.pointnet2_modules = pointnet2_modules
     models = types.ModuleType("models")
-    models.__path__ = []
+    ref_models = _find_reference_models(reference_root)
+    models.__path__ = [ref_models] if ref_models else []
+
+    def _fallthrough(name):   # PEP 562: only consulted for names the stand-in does not define
+        if name in _AP_HELPER_NAMES or name == "ap_helper":
+            if not models.__path__:
+                raise ImportError(f"models.{name} is the reference's (models/ap_helper.py): pass "
+                                  "reference_root= to dropin.install() or run from the reference root")
+            mod = importlib.import_module("models.ap_helper")
+            return mod if name == "ap_helper" else getattr(mod, name)
+        raise AttributeError(f"module 'models' has no attribute {name!r}")
+
+    models.__getattr__ = _fallthrough
     models.BeaUTyDETR = bdetr.BeaUTyDETR
     # main_utils.py:27: `from models import HungarianMatcher, SetCriterion, compute_hungarian_loss`
     for name in ("HungarianMatcher", "SetCriterion", "compute_hungarian_loss", "generalized_box_iou3d",

@@ -55,6 +55,25 @@ def _giou_broadcast(a, b):
     return iou - (vol - union) / vol
 
 
+def _volume_par(box):
+    """(N, 6) xyzxyz boxes -> (N,) volumes (models/losses.py:40-45)."""
+    return (box[:, 3] - box[:, 0]) * (box[:, 4] - box[:, 1]) * (box[:, 5] - box[:, 2])
+
+
+def _intersect_par(box_a, box_b):
+    """Pairwise intersection volumes (N, M) (models/losses.py:48-59)."""
+    lo = torch.max(box_a[:, None, :3], box_b[None, :, :3])
+    hi = torch.min(box_a[:, None, 3:], box_b[None, :, 3:])
+    return (hi - lo).clamp(min=0).prod(-1)
+
+
+def _iou3d_par(box_a, box_b):
+    """Pairwise 3-D IoU and union, as src/grounding_evaluator.py:11 imports it (models/losses.py:62-67)."""
+    inter = _intersect_par(box_a, box_b)
+    union = _volume_par(box_a)[:, None] + _volume_par(box_b)[None, :] - inter
+    return inter / union, union
+
+
 def generalized_box_iou3d(boxes1, boxes2):
     """(N, 6), (M, 6) corner boxes -> (N, M) pairwise GIoU (losses.py:70-91)."""
     return _giou_broadcast(boxes1[:, None, :], boxes2[None, :, :])

@@ -11,6 +11,8 @@ The reference's step is ``model(inputs) -> compute_hungarian_loss -> backward ->
   (box L1, size L1, soft-token cross-entropy, query/token contrastive logits, seed objectness), kept as
   the minimal "all 21.4 M trainable parameters receive gradients" driver for kernel work.
 """
+import os
+
 import numpy as np
 
 import torch
@@ -22,7 +24,7 @@ from .offline_text import synthetic_utterances
 PREFIXES = ("proposal_", "0head_", "1head_", "2head_", "3head_", "4head_", "last_")
 
 
-def synthetic_batch(batch, device, *, seed=1184, n_points=50000, tokens=80, rank=0):
+def synthetic_batch(batch, device, *, seed=1184, n_points=50000, tokens=80, rank=0, max_targets=16):
     """The ``inputs`` dict of train_dist_mod.py:103-110 for ``batch`` scenes (rank-dependent seeds)."""
     base = seed + 1000 * rank
     pc = synthetic_scenes.scene_batch(batch, base, n_points)
@@ -35,7 +37,7 @@ def synthetic_batch(batch, device, *, seed=1184, n_points=50000, tokens=80, rank
         "seed_label": torch.from_numpy((rng.random((batch, 1024)) < 0.1).astype(np.float32)).to(device),
     }
     targets.update({k: torch.from_numpy(v).to(device)
-                    for k, v in synthetic_ground_truth(pc, rng, tokens=tokens).items()})
+                    for k, v in synthetic_ground_truth(pc, rng, tokens=tokens, max_targets=max_targets).items()})
     inputs = {
         "point_clouds": torch.from_numpy(pc).to(device),
         "text": synthetic_utterances(batch, tokens=tokens, seed=base),
@@ -50,9 +52,10 @@ GROUND_TRUTH_KEYS = ("center_label", "size_gts", "sem_cls_label", "positive_map"
                      "point_instance_label")
 
 
-def synthetic_ground_truth(pc, rng, tokens=80, slots=132, n_class=256):
+def synthetic_ground_truth(pc, rng, tokens=80, slots=132, n_class=256, max_targets=16):
     """The criterion's batch keys as joint_det_dataset.py:740-766 emits them, for synthetic scenes:
-    1-16 target boxes per scene centred on scene points (`center_label`, `size_gts` (B,132,3),
+    1..max_targets (16: the grounding splits; 132: the detection split fills every slot) target boxes per scene
+    centred on scene points (`center_label`, `size_gts` (B,132,3),
     `box_label_mask` (B,132)), the instance id of every point inside a target box, -1 elsewhere
     (`point_instance_label` (B,N) int64), a class id and a normalised 1-3 token span per target
     (`sem_cls_label` (B,132) int64, `positive_map` (B,132,256))."""
@@ -62,7 +65,7 @@ def synthetic_ground_truth(pc, rng, tokens=80, slots=132, n_class=256):
            "box_label_mask": np.zeros((B, slots), np.float32),
            "point_instance_label": -np.ones((B, N), np.int64)}
     for b in range(B):
-        n = int(rng.integers(1, 17))
+        n = int(rng.integers(1, 17)) if max_targets <= 16 else int(rng.integers(max_targets // 2, max_targets + 1))
         centres = pc[b, rng.integers(0, N, n), :3]
         sizes = rng.uniform(0.4, 1.6, (n, 3)).astype(np.float32)
         out["center_label"][b, :n], out["size_gts"][b, :n], out["box_label_mask"][b, :n] = centres, sizes, 1.0
@@ -195,12 +198,20 @@ class FlatAdamW:
         self._lib = _hiplib.load()
         self._check = _hiplib.check
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        # inside the first group the decoder-side parameters come first: their gradients are final when
+        # backward reaches the encoder outputs, so [0, boundary_offset) of the flat buffer is the bucket an
+        # overlapped exchange can send while the encoder / backbone gradients are still being computed
+        pre = tuple(getattr(model.module if hasattr(model, "module") else model, "pre_boundary_prefixes", ()))
+        late = lambda n: n.startswith(pre) or n.startswith(tuple("module." + q for q in pre))
+        main = [(n, p) for n, p in named if "backbone_net" not in n and "text_encoder" not in n]
+        first = [p for n, p in main if pre and not late(n)]
         groups = [
-            ([p for n, p in named if "backbone_net" not in n and "text_encoder" not in n], lr),
+            (first + [p for n, p in main if not (pre and not late(n))], lr),
             ([p for n, p in named if "backbone_net" in n], lr_backbone),
             ([p for n, p in named if "text_encoder" in n], text_encoder_lr),
         ]
         groups = [(ps, l) for ps, l in groups if ps]
+        self.n_first = len(first) if main else 0
         dev = named[0][1].device
         pad4 = lambda n: (n + 3) // 4 * 4
         total = sum(pad4(p.numel()) for ps, _ in groups for p in ps)
@@ -221,29 +232,99 @@ class FlatAdamW:
             self.segments.append((begin, off, l))
             self.param_groups.append({"params": ps, "lr": l, "weight_decay": weight_decay})
         self.params = [p for g in self.param_groups for p in g["params"]]
+        # offset (in floats, a multiple of 4) where the gradients of the first `n_first` parameters end
+        self.boundary_offset = ((self.grad_views[self.n_first].data_ptr() - self.flat_g.data_ptr()) // 4
+                                if 0 < self.n_first < len(self.params) else 0)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.step_count = torch.zeros(1, device=dev)
         self.grad_scale = torch.ones(1, device=dev)
+        # {lr, weight_decay} per group on the device: the kernel reads them, so a captured step follows
+        # whatever a scheduler writes into param_groups (main_utils.py:438 steps one every iteration)
+        self.hyper = torch.zeros(len(self.param_groups), 2, device=dev)
+        self._hyper_host = None
+        self._hyper_sent = None
+        self.sync_hyper()
+
+    def sync_hyper(self):
+        """param_groups[i]['lr' / 'weight_decay'] -> the device pair of group i (a no-op while unchanged).
+        Call it before replaying a captured ``step()``; the eager ``step()`` calls it itself."""
+        vals = tuple((float(g["lr"]), float(g["weight_decay"])) for g in self.param_groups)
+        if vals == self._hyper_sent:
+            return
+        if self.hyper.is_cuda:
+            if self._hyper_host is None:
+                self._hyper_host = torch.empty(len(vals), 2).pin_memory()
+            else:
+                torch.cuda.current_stream(self.hyper.device).synchronize()   # an earlier upload may still read it
+            self._hyper_host.copy_(torch.tensor(vals))
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+        else:
+            self.hyper.copy_(torch.tensor(vals))
+        self._hyper_sent = vals
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
             p.grad = None
 
-    def clip_(self, max_norm):
-        """clip_grad_norm_ on the flat gradient buffer: only the coefficient is computed here."""
-        norm = torch.linalg.vector_norm(self.flat_g)
+    def clip_(self, max_norm, grad_div=1.0):
+        """clip_grad_norm_ on the flat gradient buffer: only the coefficient is computed here.  ``grad_div``:
+        the buffer holds the SUM over that many ranks (the all-reduce's division is folded into the
+        coefficient the kernel applies anyway: one pass over the 85.7 MB less)."""
+        norm = torch.linalg.vector_norm(self.flat_g) / grad_div
         torch.clamp(max_norm / (norm + 1e-6), max=1.0, out=self.grad_scale[0])
+        if grad_div != 1.0:
+            self.grad_scale.div_(grad_div)
         return norm
 
-    def step(self):
+    def collect_grads(self):
+        """Eager use (``loss.backward(); opt.step()``): the parameters' ``.grad`` tensors are not the flat
+        views unless a FlatGradients packed them -- copy them in (or fail loudly when one is missing)."""
+        src, dst = [], []
+        for p, v in zip(self.params, self.grad_views):
+            if p.grad is None:
+                raise RuntimeError("FlatAdamW.step(): a trainable parameter has no gradient (the reference "
+                                   "relies on every parameter receiving one, main_utils.py:310-313)")
+            if p.grad.data_ptr() != v.data_ptr():
+                src.append(p.grad)
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+
+    def step(self, packed=False):
+        """``packed=True``: the flat gradient buffer is already filled (GraphedTrainStep); otherwise the
+        parameters' ``.grad`` are gathered first."""
+        if not packed:
+            self.collect_grads()
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
         self.step_count.add_(1.0)
         stream = torch.cuda.current_stream(self.flat_p.device).cuda_stream
-        for begin, end, lr in self.segments:
+        for i, (begin, end, lr) in enumerate(self.segments):
             err = self._lib.butd_adamw_flat(self.flat_p.data_ptr(), self.flat_g.data_ptr(),
                                             self.flat_m.data_ptr(), self.flat_v.data_ptr(), begin, end, lr,
                                             self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                            self.step_count.data_ptr(), self.grad_scale.data_ptr(), stream)
+                                            self.step_count.data_ptr(), self.grad_scale.data_ptr(),
+                                            self.hyper[i].data_ptr(), stream)
             self._check(err, "butd_adamw_flat")
+
+    # -- checkpointing (main_utils.py:144-152 saves optimizer.state_dict(), :131-141 restores it)
+    def state_dict(self):
+        return {"flat_m": self.flat_m.clone(), "flat_v": self.flat_v.clone(),
+                "step_count": self.step_count.clone(),
+                "param_groups": [{"lr": g["lr"], "weight_decay": g["weight_decay"],
+                                  "numel": sum(p.numel() for p in g["params"])} for g in self.param_groups],
+                "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        if [g["numel"] for g in sd["param_groups"]] != [sum(p.numel() for p in g["params"]) for g in self.param_groups]:
+            raise ValueError("FlatAdamW.load_state_dict: parameter groups of a different model")
+        self.flat_m.copy_(sd["flat_m"])
+        self.flat_v.copy_(sd["flat_v"])
+        self.step_count.copy_(sd["step_count"])
+        for g, s_g in zip(self.param_groups, sd["param_groups"]):
+            g["lr"], g["weight_decay"] = s_g["lr"], s_g["weight_decay"]
+        self.betas, self.eps = tuple(sd["betas"]), sd["eps"]
+        self.sync_hyper()
 
 
 class FlatGradients:
@@ -318,17 +399,37 @@ class FlatGradients:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
             self.flat.div_(dist.get_world_size(group))
 
+    def all_reduce_sum(self, group=None, force=False, async_op=False):
+        """SUM only (the division by the world size rides on the optimizer's gradient scale); ``force`` issues
+        the collective at world size 1 too (RCCL + hipGraph coexistence check on a one-GPU box)."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        return None
+
 
 class _OptimizerGradients(FlatGradients):
-    """FlatGradients over a FlatAdamW's own gradient buffer (no second copy)."""
+    """FlatGradients over (a range of the parameters of) a FlatAdamW's own gradient buffer (no second copy)."""
 
-    def __init__(self, opt):
-        self.params, self.flat, self.views = opt.params, opt.flat_g, opt.grad_views
+    def __init__(self, opt, lo=0, hi=None):
+        hi = len(opt.params) if hi is None else hi
+        self.params, self.views = opt.params[lo:hi], opt.grad_views[lo:hi]
+        if hi - lo == len(opt.params):
+            self.flat = opt.flat_g
+        else:
+            begin = (self.views[0].data_ptr() - opt.flat_g.data_ptr()) // 4
+            end = ((opt.grad_views[hi].data_ptr() - opt.flat_g.data_ptr()) // 4 if hi < len(opt.params)
+                   else opt.flat_g.numel())
+            self.flat = opt.flat_g[begin:end]
+
+
+class _Slot:
+    """Everything one captured signature owns: static buffers, streams, graphs."""
 
 
 class GraphedTrainStep:
     """The whole iteration as hipGraph replays: tokenise on the host, copy into static buffers, replay
-    ``forward_tokenized -> surrogate loss -> backward -> gather grads into the flat buffer`` (graph 1),
+    ``forward_tokenized -> loss -> backward -> gather grads into the flat buffer`` (graph 1),
     all-reduce the flat buffer across ranks (outside the graph; skipped at world size 1), replay
     ``clip -> AdamW`` on the flat views (graph 2).
 
@@ -341,21 +442,40 @@ class GraphedTrainStep:
     model (its output depends on the tokens only): batch k+1's RoBERTa pass runs on a forked stream during
     batch k instead of in front of batch k+1's encoder; ignored when the text encoder is trainable.
 
+    Data parallel (``torch.distributed`` initialised, world size N > 1; backend "nccl" is RCCL on ROCm).
+    The gradient exchange is SUM all-reduces of the packed buffer; the division by N rides on the clip
+    coefficient the AdamW kernel applies anyway.  With ``overlap_exchange`` (FlatAdamW + a model that exposes
+    ``cut_at_encoder_output``) graph 1 is captured in two pieces: 1a = forward + loss + backward down to the
+    encoder outputs, 1b = backward through the encoder and the backbone.  The decoder-side bucket (the first
+    ``optimizer.boundary_offset`` floats, ~60 % of the 85.7 MB) is all-reduced asynchronously while 1b
+    replays, the rest after it -- DistributedDataParallel's bucket overlap (main_utils.py:310-313) with two
+    buckets and no per-parameter hooks.
+
+    Shapes are static: every (batch, points, tokens) signature is captured once and cached.  The reference
+    pads the utterances to the longest of the batch (bdetr.py:160-163), and its contrastive loss takes a
+    log-sum-exp over ALL token positions, padding included (losses.py:468-469) -- so the token length is part
+    of the arithmetic and is kept as the reference has it by default; ``token_bucket=k`` rounds it up to a
+    multiple of k (fewer captures, a marginally different contrastive term).  With N > 1 the length is the
+    longest over ALL ranks (one 8-byte MAX all-reduce per step; = the reference's padding if the global
+    batch sat on one GPU), so every rank captures -- and issues the warm-up collectives of -- the same
+    signatures in the same order.  Warm-up steps of a capture do not train: parameters, optimizer state and
+    BatchNorm buffers are restored afterwards.
+
     Eager PyTorch launches ~4 900 kernels per step here and is host-bound ("HIP streams and
     graphs instead of a tracing compiler"); a graph replay removes the launch overhead without
-    changing a single kernel.  Shapes are static: a new (batch, points, tokens) signature re-captures.
+    changing a single kernel.
     """
 
     def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
-                 zero_arena=True, prefetch_text=True, criterion=None):
+                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=True, token_bucket=None):
+        import torch.distributed as dist
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
         self.criterion = criterion or surrogate_loss
         self.warmup = warmup
         self.prefetch_sampling = prefetch_sampling
         self.prefetch_text = bool(prefetch_text and hasattr(self._module(), "text_encoder_is_frozen")
                                   and self._module().text_encoder_is_frozen())
-        self._announced = None
-        self._tok_cache = None
+        self.token_bucket = token_bucket
         self.arena = None
         from . import attention_blocks
         if zero_arena and attention_blocks.get_backend() == "hip":   # only the fused blocks draw from it
@@ -364,12 +484,25 @@ class GraphedTrainStep:
         self.flat_opt = isinstance(optimizer, FlatAdamW)
         self.flat = (_OptimizerGradients(optimizer) if self.flat_opt else
                      FlatGradients([p for g in optimizer.param_groups for p in g["params"]]))
-        self._sig = None
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        # BUTD_FORCE_COLLECTIVE=1: issue the collectives at world size 1 as well (one-GPU rehearsal of RCCL
+        # next to hipGraph replays)
+        self.force_collective = (os.environ.get("BUTD_FORCE_COLLECTIVE", "0") == "1"
+                                 and dist.is_available() and dist.is_initialized())
+        exchanging = self.world > 1 or self.force_collective
+        self.split = bool(overlap_exchange and exchanging and self.flat_opt
+                          and hasattr(self._module(), "cut_at_encoder_output")
+                          and 0 < optimizer.n_first < len(optimizer.params))
+        if self.split:
+            self.flat_a = _OptimizerGradients(optimizer, 0, optimizer.n_first)
+            self.flat_b = _OptimizerGradients(optimizer, optimizer.n_first, None)
+        self._slots, self._slot, self._sig = {}, None, None
 
     # -- pieces shared by the eager warm-up and the captured region
     def _sample_into_next(self):
-        inds = self._backbone().sample(self.s_next_pc)
-        torch.cat([i.reshape(-1) for i in inds], out=self.s_inds_next)
+        s = self._slot
+        inds = self._backbone().sample(s.next_pc)
+        torch.cat([i.reshape(-1) for i in inds], out=s.inds_next)
 
     def _module(self):
         return self.model.module if hasattr(self.model, "module") else self.model
@@ -378,140 +511,282 @@ class GraphedTrainStep:
         return self._module().backbone_net
 
     def _encode_text_into_next(self):
-        self.s_text_next.copy_(self._module().encode_text(self.s_tok_next))
+        s = self._slot
+        s.text_next.copy_(self._module().encode_text(s.tok_next))
+
+    def _with_arena(self, fn, reset):
+        if self.arena is None:
+            return fn()
+        if reset:
+            self.arena.reset()                  # ONE memset for every atomics target of the step
+        with self.arena:
+            return fn()
 
     def _fwd_bwd(self):
-        if self.arena is None:
-            return self._fwd_bwd_body()
-        self.arena.reset()                      # ONE memset for every atomics target of the step
-        with self.arena:
-            return self._fwd_bwd_body()
+        return self._with_arena(self._fwd_bwd_body, True)
 
-    def _fwd_bwd_body(self):
+    def _forward_loss(self):
+        s = self._slot
         if self.prefetch_sampling:
             main = torch.cuda.current_stream()
-            self.s_inds_cur.copy_(self.s_inds_next)          # this batch's samples (prefetched)
-            self._sample_stream.wait_stream(main)            # fork: next batch's chain on 8 CUs
-            with torch.cuda.stream(self._sample_stream):
+            s.inds_cur.copy_(s.inds_next)                    # this batch's samples (prefetched)
+            s.sample_stream.wait_stream(main)                # fork: next batch's chain on 8 CUs
+            with torch.cuda.stream(s.sample_stream):
                 self._sample_into_next()
         if self.prefetch_text:
             main = torch.cuda.current_stream()
-            self.s_text_cur.copy_(self.s_text_next)          # this batch's language features
-            self._text_stream.wait_stream(main)
-            with torch.cuda.stream(self._text_stream):
+            s.text_cur.copy_(s.text_next)                    # this batch's language features
+            s.text_stream.wait_stream(main)
+            with torch.cuda.stream(s.text_stream):
                 self._encode_text_into_next()
-        end_points = self.model.forward_tokenized(self.s_inputs, self.s_tok)
-        loss = self.criterion(end_points, self.s_targets)
+        end_points = self.model.forward_tokenized(s.inputs, s.tok)
+        return self.criterion(end_points, s.targets)
+
+    def _join_side_streams(self):
+        s = self._slot
+        if self.prefetch_sampling:
+            torch.cuda.current_stream().wait_stream(s.sample_stream)   # join
+        if self.prefetch_text:
+            torch.cuda.current_stream().wait_stream(s.text_stream)
+
+    def _fwd_bwd_body(self):
+        loss = self._forward_loss()
         self.flat.detach()                      # fresh .grad tensors: no per-parameter accumulate
         loss.backward()
         self.flat.gather([p.grad for p in self.flat.params])
-        if self.prefetch_sampling:
-            torch.cuda.current_stream().wait_stream(self._sample_stream)   # join
-        if self.prefetch_text:
-            torch.cuda.current_stream().wait_stream(self._text_stream)
+        self._join_side_streams()
         return loss.detach()
+
+    # -- the same in two pieces (overlapped exchange)
+    def _stage1(self):
+        def body():
+            module = self._module()
+            module.cut_at_encoder_output(True)
+            try:
+                loss = self._forward_loss()
+                (outs, copies), = module._boundary
+            finally:
+                module.cut_at_encoder_output(False)
+            self.flat.detach()
+            loss.backward()
+            self.flat_a.gather([p.grad for p in self.flat_a.params])
+            self._slot.cut = (outs, [c.grad for c in copies])
+            self._join_side_streams()           # a capture cannot end with forked work outstanding
+            return loss.detach()
+        return self._with_arena(body, True)
+
+    def _stage2(self):
+        def body():
+            outs, grads = self._slot.cut
+            self._slot.cut = None
+            torch.autograd.backward(outs, grads)
+            self.flat_b.gather([p.grad for p in self.flat_b.params])
+        return self._with_arena(body, False)
+
+    def _exchange_whole(self):
+        if self.flat_opt:
+            self.flat.all_reduce_sum(self.group, force=self.force_collective)
+        else:
+            self.flat.all_reduce_mean(self.group)
 
     def _update(self):
         if self.flat_opt:
+            div = float(self.world)
             if self.clip_norm:
-                self.optimizer.clip_(self.clip_norm)
-            self.optimizer.step()
+                self.optimizer.clip_(self.clip_norm, grad_div=div)
+            else:
+                self.optimizer.grad_scale.fill_(1.0 / div)
+            self.optimizer.step(packed=True)
             return
         self.flat.attach()
         if self.clip_norm:
             torch.nn.utils.clip_grad_norm_(self.flat.views, self.clip_norm, foreach=True)
         self.optimizer.step()
 
+    def _one_eager_step(self):
+        if self.split:
+            loss = self._stage1()
+            work = self.flat_a.all_reduce_sum(self.group, force=self.force_collective, async_op=True)
+            self._stage2()
+            self.flat_b.all_reduce_sum(self.group, force=self.force_collective)
+            if work is not None:
+                work.wait()
+        else:
+            loss = self._fwd_bwd()
+            self._exchange_whole()
+        self._update()
+        return loss
+
     def _copy_in(self, inputs, targets, tok):
+        s = self._slot
         for k, v in inputs.items():
             if torch.is_tensor(v):
-                self.s_inputs[k].copy_(v, non_blocking=True)
+                s.inputs[k].copy_(v, non_blocking=True)
         for k, v in targets.items():
-            self.s_targets[k].copy_(v, non_blocking=True)
-        for k in self.s_tok.keys():
-            self.s_tok[k].copy_(tok[k], non_blocking=True)
+            s.targets[k].copy_(v, non_blocking=True)
+        for k in s.tok.keys():
+            s.tok[k].copy_(tok[k], non_blocking=True)
+
+    # -- warm-up steps must not train
+    def _snapshot(self):
+        snap = {"buffers": [b.clone() for b in self.model.buffers()]}
+        if self.flat_opt:
+            o = self.optimizer
+            snap["flat"] = [t.clone() for t in (o.flat_p, o.flat_m, o.flat_v, o.step_count)]
+        else:
+            import copy
+            snap["params"] = [p.detach().clone() for p in self.flat.params]
+            snap["opt"] = copy.deepcopy(self.optimizer.state_dict())
+        return snap
+
+    def _restore(self, snap):
+        with torch.no_grad():
+            for b, v in zip(self.model.buffers(), snap["buffers"]):
+                b.copy_(v)
+            if self.flat_opt:
+                o = self.optimizer
+                for t, v in zip((o.flat_p, o.flat_m, o.flat_v, o.step_count), snap["flat"]):
+                    t.copy_(v)
+            else:
+                for p, v in zip(self.flat.params, snap["params"]):
+                    p.copy_(v)
+                self.optimizer.load_state_dict(snap["opt"])
 
     def _capture(self, inputs, targets, tok):
         from transformers import BatchEncoding
-        self.s_inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
-        self.s_targets = {k: v.clone() for k, v in targets.items()}
-        self.s_tok = BatchEncoding({k: v.clone() for k, v in tok.items()})
+        s = self._slot = _Slot()
+        s.cut = None
+        s.announced = None
+        s.inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
+        s.targets = {k: v.clone() for k, v in targets.items()}
+        s.tok = BatchEncoding({k: v.clone() for k, v in tok.items()})
         if self.prefetch_sampling:
             pc = inputs["point_clouds"]
-            self.s_next_pc = pc[..., :3].clone()
+            s.next_pc = pc[..., :3].clone()
             levels = [getattr(self._backbone(), f"sa{l}").npoint for l in (1, 2, 3, 4)]
             b = pc.shape[0]
-            self.s_inds_next = torch.empty(b * sum(levels), dtype=torch.int32, device=pc.device)
-            self.s_inds_cur = torch.empty_like(self.s_inds_next)
+            s.inds_next = torch.empty(b * sum(levels), dtype=torch.int32, device=pc.device)
+            s.inds_cur = torch.empty_like(s.inds_next)
             views, o = [], 0
             for n in levels:
-                views.append(self.s_inds_cur[o:o + b * n].view(b, n))
+                views.append(s.inds_cur[o:o + b * n].view(b, n))
                 o += b * n
-            self.s_inputs["backbone_sample_inds"] = views
-            self._sample_stream = torch.cuda.Stream()
+            s.inputs["backbone_sample_inds"] = views
+            s.sample_stream = torch.cuda.Stream()
             self._sample_into_next()                          # prime with THIS batch
             torch.cuda.synchronize()
         if self.prefetch_text:
-            self.s_tok_next = BatchEncoding({k: v.clone() for k, v in tok.items()})
-            self.s_text_next = self._module().encode_text(self.s_tok_next).clone()   # prime with THIS batch
-            self.s_text_cur = torch.empty_like(self.s_text_next)
-            self.s_inputs["text_encoder_output"] = self.s_text_cur
-            self._text_stream = torch.cuda.Stream()
+            s.tok_next = BatchEncoding({k: v.clone() for k, v in tok.items()})
+            s.text_next = self._module().encode_text(s.tok_next).clone()   # prime with THIS batch
+            s.text_cur = torch.empty_like(s.text_next)
+            s.inputs["text_encoder_output"] = s.text_cur
+            s.text_stream = torch.cuda.Stream()
             torch.cuda.synchronize()
+        snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.warmup):
-                self._fwd_bwd()
-                self.flat.all_reduce_mean(self.group)
-                self._update()
+                self._one_eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.g_fwd_bwd = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd_bwd):
-            self.s_loss = self._fwd_bwd()
-        self.g_update = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_update, pool=self.g_fwd_bwd.pool()):
+        self._restore(snap)
+        torch.cuda.synchronize()
+        if self.split:
+            s.g_stage1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(s.g_stage1):
+                s.loss = self._stage1()
+            s.g_stage2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(s.g_stage2, pool=s.g_stage1.pool()):
+                self._stage2()
+            pool = s.g_stage1.pool()
+        else:
+            s.g_fwd_bwd = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(s.g_fwd_bwd):
+                s.loss = self._fwd_bwd()
+            pool = s.g_fwd_bwd.pool()
+        s.g_update = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(s.g_update, pool=pool):
             self._update()
+        # the captures above ran the optimizer once more under capture semantics only (nothing executed)
+
+    def _pad_tokens(self, tok):
+        """Pad (input_ids with the pad id 1, attention_mask with 0) to the bucketed / rank-agreed length."""
+        length = int(tok["input_ids"].shape[1])
+        want = length
+        if self.token_bucket:
+            want = (length + self.token_bucket - 1) // self.token_bucket * self.token_bucket
+        if self.world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([want], dtype=torch.int64, device=tok["input_ids"].device)
+            if dist.get_backend(self.group) == "gloo":
+                t = t.cpu()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            want = int(t.item())
+        if want == length:
+            return tok
+        from transformers import BatchEncoding
+        out = {}
+        for k, v in tok.items():
+            fill = 1 if k == "input_ids" else 0
+            out[k] = torch.nn.functional.pad(v, (0, want - length), value=fill)
+        return BatchEncoding(out)
+
+    def _tokenize(self, inputs):
+        return self._pad_tokens(self.model.tokenize(inputs))
 
     def __call__(self, inputs, targets, next_inputs=None):
         # host work stays in the step; a batch announced by the previous call was tokenised then
-        if self._tok_cache is not None and self._tok_cache[0] is inputs:
-            tok = self._tok_cache[1]
-        else:
-            tok = self.model.tokenize(inputs)
+        cache = getattr(self, "_tok_cache", None)
+        tok = cache[1] if (cache is not None and cache[0] is inputs) else self._tokenize(inputs)
         self._tok_cache = None
         if hasattr(self.criterion, "prepare"):                 # collectives of the criterion: outside the graph
             targets = self.criterion.prepare(targets)
         sig = (tuple(inputs["point_clouds"].shape), tuple(tok["input_ids"].shape))
         if sig != self._sig:
-            self._capture(inputs, targets, tok)
+            if sig in self._slots:
+                self._slot = self._slots[sig]
+                self._slot.announced = None
+            else:
+                self._capture(inputs, targets, tok)
+                self._slots[sig] = self._slot
+                self._slot.announced = inputs
             self._sig = sig
-            self._announced = inputs
+        s = self._slot
         self._copy_in(inputs, targets, tok)
-        announced = self._announced is inputs
+        announced = s.announced is inputs
         nxt = next_inputs if next_inputs is not None else inputs
         if self.prefetch_sampling:
             if not announced:                                  # not prefetched: sample it now
-                self.s_next_pc.copy_(inputs["point_clouds"][..., :3])
+                s.next_pc.copy_(inputs["point_clouds"][..., :3])
                 self._sample_into_next()
-            self.s_next_pc.copy_(nxt["point_clouds"][..., :3], non_blocking=True)
+            s.next_pc.copy_(nxt["point_clouds"][..., :3], non_blocking=True)
         text_ok = True
         if self.prefetch_text:
             if not announced:                                  # not prefetched: encode it now
-                for k in self.s_tok_next.keys():
-                    self.s_tok_next[k].copy_(tok[k])
+                for k in s.tok_next.keys():
+                    s.tok_next[k].copy_(tok[k])
                 self._encode_text_into_next()
-            tok_next = tok if nxt is inputs else self.model.tokenize(nxt)
-            text_ok = tuple(tok_next["input_ids"].shape) == tuple(self.s_tok_next["input_ids"].shape)
+            tok_next = tok if nxt is inputs else self._tokenize(nxt)
+            text_ok = tuple(tok_next["input_ids"].shape) == tuple(s.tok_next["input_ids"].shape)
             if text_ok:
-                for k in self.s_tok_next.keys():
-                    self.s_tok_next[k].copy_(tok_next[k], non_blocking=True)
-                if nxt is not inputs:
-                    self._tok_cache = (nxt, tok_next)
-        # a next batch of another token length re-captures anyway: treat it as unannounced
-        self._announced = nxt if (next_inputs is not None and text_ok) else None
-        self.g_fwd_bwd.replay()
-        self.flat.all_reduce_mean(self.group)
-        self.g_update.replay()
-        return self.s_loss
+                for k in s.tok_next.keys():
+                    s.tok_next[k].copy_(tok_next[k], non_blocking=True)
+            if nxt is not inputs:
+                self._tok_cache = (nxt, tok_next)
+        # a next batch of another token length runs in another slot: treat it as unannounced there
+        s.announced = nxt if (next_inputs is not None and text_ok) else None
+        if self.flat_opt:
+            self.optimizer.sync_hyper()                        # a scheduler may have moved the learning rates
+        if self.split:
+            s.g_stage1.replay()
+            work = self.flat_a.all_reduce_sum(self.group, force=self.force_collective, async_op=True)
+            s.g_stage2.replay()                                # encoder + backbone backward under the exchange
+            self.flat_b.all_reduce_sum(self.group, force=self.force_collective)
+            if work is not None:
+                work.wait()
+        else:
+            s.g_fwd_bwd.replay()
+            self._exchange_whole()
+        s.g_update.replay()
+        return s.loss

@@ -18,10 +18,13 @@ typedef void *butd_stream_t;
 /* AdamW (decoupled weight decay, torch semantics) on p[begin:end) of the packed buffers:
  *   g' = g * *grad_scale (device scalar: the clip coefficient, NULL = 1)
  *   p *= 1 - lr*wd;  m = b1*m + (1-b1)*g';  v = b2*v + (1-b2)*g'^2;
- *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = *step (device scalar, float, >= 1). */
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),   t = *step (device scalar, float, >= 1).
+ * hyper: NULL, or a device pointer to {lr, weight_decay} that REPLACE the by-value arguments -- the reference
+ * steps an LR scheduler every iteration (main_utils.py:438); a launch captured in a hipGraph bakes by-value
+ * arguments in, a device-resident pair is re-read by every replay. */
 int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, long end, float lr,
                     float beta1, float beta2, float eps, float weight_decay, const float *step,
-                    const float *grad_scale, butd_stream_t stream);
+                    const float *grad_scale, const float *hyper, butd_stream_t stream);
 
 /* Gradient packing: dst[dst_off[i] : dst_off[i] + numel[i]) = src[i][0 : numel[i]) for n segments in ONE
  * launch (the step gathers ~330 freshly produced parameter gradients into the flat all-reduce / AdamW

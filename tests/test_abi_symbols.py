@@ -97,5 +97,40 @@ def test_dropin_registers_reference_module_names(libpath, monkeypatch):
             "matcher", "losses", "eos_coef", "temperature"]                    # losses.py:341
         assert list(inspect.signature(compute_hungarian_loss).parameters)[:4] == [
             "end_points", "num_decoder_layers", "set_criterion", "query_points_obj_topk"]   # losses.py:546-547
+        # src/grounding_evaluator.py:11
+        from models.losses import _iou3d_par, box_cxcyczwhd_to_xyzxyz
+        import torch
+        a = torch.tensor([[0., 0., 0., 2., 2., 2.]])
+        b = torch.tensor([[1., 1., 1., 3., 3., 3.], [5., 5., 5., 6., 6., 6.]])
+        iou, union = _iou3d_par(a, b)
+        assert torch.allclose(iou, torch.tensor([[1. / 15., 0.]])) and torch.allclose(union, torch.tensor([[15., 9.]]))
+    finally:
+        attention_blocks.set_backend(prev)
+
+
+def test_dropin_falls_through_to_the_reference_for_what_it_does_not_provide(libpath, monkeypatch, tmp_path):
+    """train_dist_mod.py:24 `from models import APCalculator, parse_predictions, parse_groundtruths`: not
+    re-implemented here, so the stand-in package must hand them to the reference's models/ap_helper.py."""
+    import sys
+    for k in [k for k in sys.modules if k == "models" or k.startswith(("models.", "pointnet2"))]:
+        monkeypatch.delitem(sys.modules, k)
+    ref = tmp_path / "ref"
+    (ref / "models").mkdir(parents=True)
+    (ref / "models" / "ap_helper.py").write_text(      # a stand-in for the reference file (data for the test)
+        "class APCalculator: pass\ndef parse_predictions(*a): return 'pred'\ndef parse_groundtruths(*a): return 'gt'\n")
+    from butd_detr_amd import attention_blocks, dropin
+    prev = attention_blocks.get_backend()
+    try:
+        dropin.install(attention_backend="torch", reference_root=str(ref))
+        from models import BeaUTyDETR, APCalculator, parse_predictions, parse_groundtruths
+        assert BeaUTyDETR.__module__.startswith("butd_detr_amd")
+        assert APCalculator.__module__ == "models.ap_helper" and parse_predictions() == "pred"
+        assert parse_groundtruths() == "gt"
+        for k in [k for k in sys.modules if k == "models" or k.startswith("models.")]:
+            monkeypatch.delitem(sys.modules, k)
+        dropin.install(attention_backend="torch", reference_root=str(tmp_path / "nowhere"))
+        import models
+        with pytest.raises(ImportError):
+            models.APCalculator
     finally:
         attention_blocks.set_backend(prev)

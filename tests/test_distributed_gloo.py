@@ -73,3 +73,51 @@ def test_ddp_and_flat_allreduce_agree_world2():
     assert r0["worst"] < 1e-5 and r1["worst"] < 1e-5           # flat exchange == DDP
     assert torch.allclose(r0["grad0"], r1["grad0"])            # ranks hold the same averaged grads
     assert r0["loss"] != r1["loss"]                            # ... computed from different scenes
+
+
+def test_two_stage_backward_equals_one_backward():
+    """The overlapped gradient exchange splits backward at the encoder outputs (BeaUTyDETR.cut_at_encoder_output):
+    stage 1 must complete exactly the decoder-side parameters (the first bucket), stage 2 exactly the rest, and
+    together they must equal one ordinary backward."""
+    import warnings
+    from butd_detr_amd import pointnet2_utils
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from butd_detr_amd.train_step import surrogate_loss, synthetic_batch
+    from oracle import ext_adapter
+    from tests.golden import text_stub, weights
+    prev = pointnet2_utils._ext
+    pointnet2_utils._ext = ext_adapter          # test-only stand-in (see module docstring)
+    try:
+        torch.set_num_threads(4)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = BeaUTyDETR(num_queries=16, num_decoder_layers=2, text_encoder_factory=text_stub.factory,
+                               class_embeddings_path=None)
+        weights.fill_(model, seed=4, skip_prefixes=("text_encoder.",))
+        model.eval()
+        inputs, targets = synthetic_batch(2, torch.device("cpu"), n_points=2304, tokens=10)
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        surrogate_loss(model(inputs), targets).backward()
+        want = {n: p.grad.clone() for n, p in named}
+        for _, p in named:
+            p.grad = None
+        late = lambda n: n.startswith(model.pre_boundary_prefixes)
+        model.cut_at_encoder_output(True)
+        loss = surrogate_loss(model(inputs), targets)
+        (outs, copies), = model._boundary
+        model.cut_at_encoder_output(False)
+        assert len(outs) == 3                                   # visual, text and box features
+        loss.backward()
+        stage1 = {n for n, p in named if p.grad is not None}
+        assert stage1 == {n for n, _ in named if not late(n)}, sorted(stage1 ^ {n for n, _ in named if not late(n)})
+        first = {n: p.grad.clone() for n, p in named if p.grad is not None}
+        torch.autograd.backward(outs, [c.grad for c in copies])
+        for n, p in named:
+            assert p.grad is not None, n
+            if n in first:                                      # untouched by stage 2
+                assert torch.equal(p.grad, first[n]), n
+            torch.testing.assert_close(p.grad, want[n], rtol=1e-5, atol=1e-7, msg=n)
+        # without the cut the model is unchanged
+        assert model._boundary is None
+    finally:
+        pointnet2_utils._ext = prev

@@ -68,3 +68,25 @@ def test_gather_segments_equals_multi_tensor_copy():
         fg.gather(grads)
         want = torch.cat([g.reshape(-1) for g in grads])
         assert torch.equal(fg.flat, want), rep
+
+
+def test_eager_use_collects_gradients_and_refuses_missing_ones():
+    """Advisor finding of round 1: ``loss.backward(); opt.step()`` without a FlatGradients packing step used to
+    update from an all-zero gradient buffer."""
+    from butd_detr_amd.train_step import FlatAdamW
+    torch.manual_seed(1)
+    ref = torch.nn.Sequential(torch.nn.Linear(9, 5), torch.nn.Linear(5, 3)).cuda()
+    mine = copy.deepcopy(ref)
+    opt_ref = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=5e-4)
+    opt = FlatAdamW(mine, lr=1e-3, weight_decay=5e-4)
+    x = torch.randn(16, 9, device="cuda")
+    for m, o in ((ref, opt_ref), (mine, opt)):
+        o.zero_grad()
+        m(x).pow(2).sum().backward()
+        o.step()
+    for a, b in zip(ref.parameters(), mine.parameters()):
+        np.testing.assert_allclose(b.detach().cpu().numpy(), a.detach().cpu().numpy(), rtol=0, atol=1e-7)
+    opt.zero_grad()
+    mine[0](x).sum().backward()                 # the second layer gets no gradient
+    with pytest.raises(RuntimeError, match="no gradient"):
+        opt.step()

@@ -57,7 +57,7 @@ def test_prefetched_sampling_trains_like_inline_sampling():
             assert abs(a - b) <= 1e-4 * max(abs(b), 1.0), (pre_losses, ref_losses)
         # and the sampled indices the prefetching step consumed for the last batch are that batch's
         want = torch.cat([i.reshape(-1) for i in pre_model.backbone_net.sample(batches[-1][0]["point_clouds"])])
-        assert torch.equal(pre.s_inds_cur, want)
+        assert torch.equal(pre._slot.inds_cur, want)
     finally:
         attention_blocks.set_backend("torch")
 
@@ -104,4 +104,97 @@ def test_training_on_a_fixed_batch_reduces_the_hungarian_loss():
         assert all(l == l for l in losses), losses
         assert min(losses[-5:]) < 0.85 * losses[0], losses
     finally:
+        attention_blocks.set_backend("torch")
+
+
+def test_warmup_does_not_train_signatures_are_cached_and_the_scheduler_is_followed():
+    """Advisor findings of round 1: (1) the warm-up steps of a capture must not move parameters, optimizer
+    state or BatchNorm buffers; (2) a signature seen before must not be captured again; (3) a learning rate
+    written into param_groups (the reference steps a scheduler every iteration, main_utils.py:438) must reach
+    the captured update."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, synthetic_batch
+    try:
+        dev = torch.device("cuda", 0)
+        a = synthetic_batch(2, dev, seed=5, n_points=4096, tokens=24)
+        b = synthetic_batch(2, dev, seed=6, n_points=4096, tokens=16)        # another token length
+        model = _model()
+        opt = FlatAdamW(model, lr=1e-4, lr_backbone=1e-3)
+        p0 = opt.flat_p.clone()
+        bn0 = model.backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean.clone()
+        step = GraphedTrainStep(model, opt, warmup=3)
+        captures = []
+        orig = step._capture
+        step._capture = lambda *args: (captures.append(1), orig(*args))[1]
+        step(*a)
+        assert float(opt.step_count) == 1.0                                   # 3 warm-up steps left no trace
+        assert int(model.backbone_net.sa1.mlp_module.layer0.bn.bn.num_batches_tracked) == 1
+        moved = (opt.flat_p - p0).abs().max()
+        assert 0 < float(moved) <= 1.1e-3, float(moved)                       # ONE AdamW step: |dp| <= lr (+ decay)
+        assert not torch.equal(model.backbone_net.sa1.mlp_module.layer0.bn.bn.running_mean, bn0)
+        step(*b)
+        step(*a)
+        step(*b)
+        assert len(captures) == 2 and float(opt.step_count) == 4.0
+        # scheduler: lr -> 0 for every group: the next replay must leave the parameters where they are
+        for g in opt.param_groups:
+            g["lr"] = 0.0
+        before = opt.flat_p.clone()
+        step(*a)
+        assert torch.equal(opt.flat_p, before)
+        for g, lr in zip(opt.param_groups, (1e-4, 1e-3)):
+            g["lr"] = lr
+        step(*a)
+        assert not torch.equal(opt.flat_p, before)
+        # checkpoint round trip (main_utils.py:131-152)
+        sd = opt.state_dict()
+        m2 = _model()
+        opt2 = FlatAdamW(m2, lr=5e-5, lr_backbone=5e-5)
+        opt2.load_state_dict(sd)
+        assert torch.equal(opt2.flat_m, opt.flat_m) and float(opt2.step_count) == float(opt.step_count)
+        assert [g["lr"] for g in opt2.param_groups] == [g["lr"] for g in opt.param_groups]
+    finally:
+        attention_blocks.set_backend("torch")
+
+
+def test_overlapped_exchange_equals_the_single_graph_step(tmp_path):
+    """The two-piece capture (backward cut at the encoder outputs, the decoder-side bucket all-reduced while the
+    encoder / backbone backward replays) must train exactly like the single-graph step.  World size 1 over
+    gloo with the collectives forced (BUTD_FORCE_COLLECTIVE)."""
+    import os
+    import torch.distributed as dist
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, HungarianCriterion, synthetic_batch
+    os.environ["BUTD_FORCE_COLLECTIVE"] = "1"
+    dist.init_process_group("gloo", init_method=f"file://{tmp_path}/init", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        batches = [synthetic_batch(2, dev, seed=40 + i, n_points=4096, tokens=24) for i in range(3)]
+        one, two = _model(), None
+        two = copy.deepcopy(one)
+        crit = lambda: HungarianCriterion(num_decoder_layers=2)
+        # learning rate 0: identical parameters in every step, so the packed gradients must agree to the
+        # rounding of the atomics (split-K weight gradients)
+        zero = dict(lr=0.0, lr_backbone=0.0, weight_decay=0.0)
+        s1 = GraphedTrainStep(one, FlatAdamW(one, **zero), warmup=1, criterion=crit(), overlap_exchange=False)
+        s2 = GraphedTrainStep(two, FlatAdamW(two, **zero), warmup=1, criterion=crit(), overlap_exchange=True)
+        assert s2.split and not s1.split and 0 < s2.optimizer.boundary_offset < s2.optimizer.flat_g.numel()
+        for inp, tgt in batches:
+            l1, l2 = float(s1(inp, tgt)), float(s2(inp, tgt))
+            assert abs(l1 - l2) <= 1e-5 * max(abs(l1), 1.0), (l1, l2)
+            g1, g2 = s1.optimizer.flat_g, s2.optimizer.flat_g
+            assert float((g1 - g2).abs().max() / g1.abs().max()) <= 1e-4
+            assert float(g1.abs().max()) > 0
+        # and with the reference's learning rates the two keep training alike (Adam's m / sqrt(v) turns last-bit
+        # gradient differences into a fraction of lr where |g| ~ 0: compare the losses and the bulk)
+        for g in s1.optimizer.param_groups + s2.optimizer.param_groups:
+            g["lr"], g["weight_decay"] = 1e-4, 5e-4
+        for inp, tgt in batches:
+            l1, l2 = float(s1(inp, tgt)), float(s2(inp, tgt))
+            assert abs(l1 - l2) <= 1e-3 * max(abs(l1), 1.0), (l1, l2)
+        d = (s1.optimizer.flat_p - s2.optimizer.flat_p).abs()
+        assert float((d < 1e-5).float().mean()) > 0.98 and float(d.max()) < 1e-3, (float(d.max()),)
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("BUTD_FORCE_COLLECTIVE", None)
         attention_blocks.set_backend("torch")

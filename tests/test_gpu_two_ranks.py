@@ -78,3 +78,20 @@ def test_bench_runs_its_multi_rank_path():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["steps"] == 2 and rec["config"]["global_batch"] == 4
     assert rec["value"] > 0 and rec["scaling"] == "weak" and "cpu_baseline" not in rec
+
+
+def test_bench_brings_rccl_up_next_to_the_graph_replays():
+    """What one GPU can check of the N > 1 launch: ``backend="nccl"`` (RCCL) initialised at world size 1, the
+    step's collectives issued anyway (BUTD_BENCH_FORCE_DIST=1 -> two-piece capture, asynchronous all-reduce of
+    the decoder-side bucket under the replay of the encoder / backbone backward), HSA_ENABLE_IPC_MODE_LEGACY=0."""
+    import json
+    import subprocess
+    env = dict(os.environ, BUTD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1",
+                          "--batch", "2", "--points", "8192", "--no-cpu-baseline"], env=env, cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["final_loss"] == rec["config"]["final_loss"]
