@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
 FP32_MATRIX_PEAK_TF = 157.3
+BF16_MATRIX_PEAK_TF = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def parse():
@@ -47,6 +48,12 @@ def parse():
     ap.add_argument("--encoder-layers", type=int, default=3,
                     help="BiEncoder depth: 3 = the reference (models/bdetr.py:104); 6 = the extra row BASELINE "
                          "configs[2] words as '6-layer BiEncoder'")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the grouped products (projections, FFN, 1x1-conv chains, their gradients): "
+                         "f32 = the reference's precision (the headline); bf16 = operands rounded to bf16 on the "
+                         "matrix cores, fp32 accumulation (BASELINE configs[3]).  The default run reports the bf16 "
+                         "mode as an extra field next to the fp32 headline")
+    ap.add_argument("--no-bf16-row", action="store_true")
     ap.add_argument("--max-targets", type=int, default=16,
                     help="target boxes per scene of the synthetic ground truth: 1..16 (grounding splits) or, "
                          "e.g., 132 = 66..132 per scene (the detection split fills the 132 slots)")
@@ -303,6 +310,41 @@ def cpu_baseline(args, scenes):
                       + (", reference criterion with scipy's linear_sum_assignment" if criterion is not None else "")}
 
 
+def bf16_row(args, model, opt, criterion, inputs, targets):
+    """BASELINE configs[3]'s arithmetic as an EXTRA operating point (the headline stays the reference's fp32):
+    the same step re-captured with the grouped products on the bf16 matrix cores, timed the same way."""
+    from butd_detr_amd import fused_attention
+    from butd_detr_amd.train_step import GraphedTrainStep
+    fused_attention.set_compute_dtype("bf16")
+    try:
+        graphed = GraphedTrainStep(model, opt, criterion=criterion)
+        for _ in range(max(args.warmup, 1)):
+            graphed(inputs, targets, next_inputs=inputs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = graphed(inputs, targets, next_inputs=inputs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        from butd_detr_amd.train_step import make_optimizer, train_step as eager_step
+        local_targets = criterion.prepare(targets) if criterion is not None else targets
+        gemm = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, local_targets,
+                                                criterion=criterion))
+        gemm["peak"] = BF16_MATRIX_PEAK_TF
+        gemm["frac"] = round(gemm["achieved"] / BF16_MATRIX_PEAK_TF, 4)
+        gemm["traffic"] = None
+        gemm["kernel"] = gemm["kernel"].replace("fp32 MFMA", "bf16 MFMA (v_mfma_f32_16x16x32_bf16)")
+        gemm["note"] = ("at the bf16 matrix rate these products are bound by staging their fp32 operands "
+                        "(HBM / L2 -> LDS), not by the matrix pipe")
+        return {"value": round(args.batch * args.steps / dt, 3), "unit": "scenes/s",
+                "ms_per_step": round(dt / args.steps * 1e3, 3),
+                "dtype": "bf16 operands / f32 accumulate in every grouped product; attention core, statistics, "
+                         "index ops and all tensors in memory f32",
+                "final_loss": round(float(loss), 4), "roofline": gemm}
+    finally:
+        fused_attention.set_compute_dtype("f32")
+
+
 def make_criterion(args):
     if args.criterion == "surrogate":
         return None
@@ -337,6 +379,9 @@ def main():
     from butd_detr_amd.train_step import (GraphedTrainStep, make_optimizer, synthetic_batch,
                                           train_step as eager_step, wrap_data_parallel)
     model, backend = build_model(args, device)
+    if backend == "hip":
+        from butd_detr_amd import fused_attention
+        fused_attention.set_compute_dtype(args.dtype)
     inputs, targets = synthetic_batch(args.batch, device, n_points=args.points, tokens=args.tokens,
                                       rank=rank, max_targets=args.max_targets)
     criterion = make_criterion(args)
@@ -382,7 +427,9 @@ def main():
             "value": round(scenes / elapsed, 3), "unit": "scenes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.dtype == "f32" else "bf16 operands / f32 accumulate (grouped products); f32 elsewhere",
+            "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]/[3]: {args.batch} scenes/GPU x {args.points} "
                                    f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "
                                    f"{args.encoder_layers} encoder + 6 decoder layers, 1..{args.max_targets} "
@@ -401,6 +448,8 @@ def main():
             out["matcher_detection_split"] = matcher_at_detection_size(args.batch)
         else:
             out["roofline"] = ball_query_roofline(inputs)
+        if backend == "hip" and world == 1 and args.dtype == "f32" and not args.eager and not args.no_bf16_row:
+            out["bf16_operating_point"] = bf16_row(args, model, opt, criterion, inputs, targets)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
         print(json.dumps(out), flush=True)

@@ -39,8 +39,11 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kThreads = 256;
+constexpr int kLdH = 40;   // bf16 image: 32 k + 8 pad per row (80 B)
 constexpr int kBK = 32, kLd = kBK + 4;  // slab depth; LDS row stride 36 floats = 9 x 16 B
 constexpr int kMaxProblems = 8;
 constexpr int kAffK = 320;  // contraction range whose A-operand affine is staged in LDS (fast path)
@@ -197,7 +200,11 @@ struct Ragged { static constexpr bool ragged = true; };
 // multiplied (nothing waits for a load of its own iteration; barrier without the vmcnt drain);
 // 0 = one slab ahead, commit after the MFMAs (what the 10^5..10^6-slab weight-gradient launches of the
 // set-abstraction backward prefer, measured: 15-20 % there)
-template <int TM, int TN, bool FAST, int PIPE>
+// BF (FAST only): operands rounded to bf16 (RNE) on their way into LDS, v_mfma_f32_16x16x32_bf16 (one
+// instruction per 16 x 16 tile and slab), fp32 accumulators and epilogue -- BASELINE configs[3]'s "bf16
+// attention / FFN" operating point; tensors stay fp32 in HBM.  Both operand kinds use the [row][k] image (a
+// row-contiguous operand is transposed by four 2-byte writes): a fragment is 8 consecutive k = one ds_read_b128.
+template <int TM, int TN, bool FAST, int PIPE, bool BF = false>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
                                                         const uint64_t *__restrict__ rng_counter) {
   constexpr int kMI = TM / 32, kNJ = TN / 32;   // 16 x 16 MFMA tiles per wave: rows, columns
@@ -288,7 +295,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
         a_ok[u] = m0 + row < P.M;
         const long r = a_ok[u] ? m0 + row : 0;
         pa[u] = a_kc ? P.a + r * P.lda_m + kbeg + k : P.a + (long)(kbeg + k) * P.lda_k + r;
-        a_lds[u] = a_kc ? row * kLd + k : k * kLdTA + row;
+        a_lds[u] = BF ? row * kLdH + k : (a_kc ? row * kLd + k : k * kLdTA + row);
       }
 #pragma unroll
       for (int u = 0; u < kSubB; ++u) {
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
         b_ok[u] = n0 + row < P.N;
         const long r = b_ok[u] ? n0 + row : 0;
         pb[u] = b_kc ? P.b + r * P.ldb_n + kbeg + k : P.b + (long)(kbeg + k) * P.ldb_k + r;
-        b_lds[u] = b_kc ? row * kLd + k : k * kLdTB + row;
+        b_lds[u] = BF ? row * kLdH + k : (b_kc ? row * kLd + k : k * kLdTB + row);
         // virtual ones-row of B (row index N): which of this float4's elements is it, if any
         ones_e[u] = !f_ones ? -1 : (b_kc ? (n0 + row == P.N ? 4 : -1)
                                          : ((n0 + row <= P.N && P.N < n0 + row + 4) ? P.N - (n0 + row) : -1));
@@ -359,6 +366,19 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
           if constexpr (decltype(set)::value == 0) rb0[u] = v; else rb1[u] = v;
         }
       };
+      // one staged float4 -> LDS (fp32 image: as it is; bf16 image: rounded, transposed if row-contiguous)
+      auto put = [&](float *tile, int off, float4 v, auto kc) {
+        if constexpr (!BF) {
+          *reinterpret_cast<float4 *>(tile + off) = v;
+        } else {
+          __bf16 *h = reinterpret_cast<__bf16 *>(tile) + off;
+          if constexpr (decltype(kc)::value) {
+            *reinterpret_cast<bf16x4 *>(h) = (bf16x4){(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+          } else {
+            h[0] = (__bf16)v.x; h[kLdH] = (__bf16)v.y; h[2 * kLdH] = (__bf16)v.z; h[3 * kLdH] = (__bf16)v.w;
+          }
+        }
+      };
       auto commit_fast = [&](auto set, int slab, int buf, auto kind) {
         const int kslab0 = slab * kBK;   // k offset (relative to kbeg) of the slab held in rg
         float *at = As(buf), *bt = Bs(buf);
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
             if (f_adrop && live)
               va = drop4(va, a_key, (uint32_t)((pa[u] - P.a) + slab * sa), P.a_drop_p, a_inv);
           }
-          *reinterpret_cast<float4 *>(at + a_lds[u]) = va;
+          put(at, a_lds[u], va, a_kc_t);
         }
 #pragma unroll
         for (int u = 0; u < kSubB; ++u) {
@@ -410,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
               else if (ones_e[u] == 3) vb.w = 1.f;
             }
           }
-          *reinterpret_cast<float4 *>(bt + b_lds[u]) = vb;
+          put(bt, b_lds[u], vb, b_kc_t);
         }
       };
       // operand fragments of this wave: row index inside the tile, 16-wide sub-slab u16
@@ -427,6 +447,22 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
       auto mfma_fast = [&](int buf) {
         if (GEMM_ABL & 1) return;
         const float *at = As(buf), *bt = Bs(buf);
+        if constexpr (BF) {
+          const __bf16 *ah = reinterpret_cast<const __bf16 *>(at), *bh = reinterpret_cast<const __bf16 *>(bt);
+          bf16x8 af[kMI], bf[kNJ];
+#pragma unroll
+          for (int i = 0; i < kMI; ++i)
+            af[i] = *reinterpret_cast<const bf16x8 *>(ah + (wr * kWM + i * 16 + fr) * kLdH + fg * 8);
+#pragma unroll
+          for (int j = 0; j < kNJ; ++j)
+            bf[j] = *reinterpret_cast<const bf16x8 *>(bh + (wc * kWN + j * 16 + fr) * kLdH + fg * 8);
+#pragma unroll
+          for (int i = 0; i < kMI; ++i)
+#pragma unroll
+            for (int j = 0; j < kNJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          return;
+        }
 #pragma unroll
         for (int u = 0; u < kBK / 16; ++u) {
           f32x4 af[kMI], bf[kNJ];
@@ -820,14 +856,18 @@ void choose(const butd_gemm_problem *problems, const int *index, int count, bool
 }
 
 template <int TM, int TN>
-void launch_cfg(const GemmBatch &batch, long total, bool fast, int pipe, const uint64_t *rng_counter,
+void launch_cfg(const GemmBatch &batch, long total, bool fast, int pipe, bool bf16, const uint64_t *rng_counter,
                 hipStream_t stream) {
-  const dim3 grid((unsigned)total);
-  if (fast && pipe == 2)
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, 2>), grid, dim3(kThreads), 0, stream, batch, rng_counter);
+  const dim3 grid((unsigned)total), blk(kThreads);
+  if (fast && bf16 && pipe == 2)
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, 2, true>), grid, blk, 0, stream, batch, rng_counter);
+  else if (fast && bf16)
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, 0, true>), grid, blk, 0, stream, batch, rng_counter);
+  else if (fast && pipe == 2)
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, 2>), grid, blk, 0, stream, batch, rng_counter);
   else if (fast)
-    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, 0>), grid, dim3(kThreads), 0, stream, batch, rng_counter);
-  else hipLaunchKernelGGL((gemm_kernel<TM, TN, false, 0>), grid, dim3(kThreads), 0, stream, batch, rng_counter);
+    hipLaunchKernelGGL((gemm_kernel<TM, TN, true, 0>), grid, blk, 0, stream, batch, rng_counter);
+  else hipLaunchKernelGGL((gemm_kernel<TM, TN, false, 0>), grid, blk, 0, stream, batch, rng_counter);
 }
 
 int g_forced_pipe = -1;
@@ -841,18 +881,20 @@ int launch_group(const butd_gemm_problem *problems, const int *index, int count,
     best = g_forced_cfg;
     pipe = g_forced_pipe >= 0 ? g_forced_pipe : 2;
   }
+  bool bf16 = fast;
+  for (int i = 0; i < count; ++i) bf16 = bf16 && problems[index[i]].compute_bf16 != 0;
   GemmBatch batch;
   const long total = fill_batch(batch, problems, index, count, kMenu[best].tm, kMenu[best].tn);
   if (total < 0) return (int)hipErrorInvalidValue;
   if (total == 0) return 0;
   switch (best) {
-    case 0: launch_cfg<32, 32>(batch, total, fast, pipe, rng_counter, stream); break;
-    case 1: launch_cfg<64, 64>(batch, total, fast, pipe, rng_counter, stream); break;
-    case 2: launch_cfg<32, 96>(batch, total, fast, pipe, rng_counter, stream); break;
-    case 3: launch_cfg<64, 96>(batch, total, fast, pipe, rng_counter, stream); break;
-    case 4: launch_cfg<96, 32>(batch, total, fast, pipe, rng_counter, stream); break;
-    case 5: launch_cfg<128, 64>(batch, total, fast, pipe, rng_counter, stream); break;
-    default: launch_cfg<128, 96>(batch, total, fast, pipe, rng_counter, stream); break;
+    case 0: launch_cfg<32, 32>(batch, total, fast, pipe, bf16, rng_counter, stream); break;
+    case 1: launch_cfg<64, 64>(batch, total, fast, pipe, bf16, rng_counter, stream); break;
+    case 2: launch_cfg<32, 96>(batch, total, fast, pipe, bf16, rng_counter, stream); break;
+    case 3: launch_cfg<64, 96>(batch, total, fast, pipe, bf16, rng_counter, stream); break;
+    case 4: launch_cfg<96, 32>(batch, total, fast, pipe, bf16, rng_counter, stream); break;
+    case 5: launch_cfg<128, 64>(batch, total, fast, pipe, bf16, rng_counter, stream); break;
+    default: launch_cfg<128, 96>(batch, total, fast, pipe, bf16, rng_counter, stream); break;
   }
   return (int)hipGetLastError();
 }

@@ -113,6 +113,25 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_compute_bf16 = [False]
+
+
+def set_compute_dtype(name):
+    """'f32' (the reference's precision: exact fp32 MFMA) or 'bf16' (BASELINE configs[3]: operands of every
+    grouped product -- projections, FFN, 1x1-conv chains and their gradient products -- rounded to bf16 on
+    the matrix cores, fp32 accumulation; LayerNorm / softmax / BatchNorm statistics, the attention core and
+    all tensors in memory stay fp32).  Returns the previous setting."""
+    if name not in ("f32", "bf16"):
+        raise ValueError(name)
+    prev = "bf16" if _compute_bf16[0] else "f32"
+    _compute_bf16[0] = name == "bf16"
+    return prev
+
+
+def get_compute_dtype():
+    return "bf16" if _compute_bf16[0] else "f32"
+
+
 def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.0, bias=None,
              bias_grad=None, scale=1.0, relu=False, accumulate=False, ones_col=False, split_k=1,
              dropout_p=0.0, site=0, a_affine=None, b_affine=None, a_drop=(0.0, 0), b_drop=(0.0, 0),
@@ -126,7 +145,7 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                        float(a_drop[0]), int(a_drop[1]), float(b_drop[0]), int(b_drop[1]),
                        _ptr(col_stats[0]) if col_stats is not None else None,
                        _ptr(col_stats[1]) if col_stats is not None else None,
-                       int(c_add), _ptr(c2), int(col_slots[0]), int(col_slots[1]))
+                       int(c_add), _ptr(c2), int(col_slots[0]), int(col_slots[1]), int(_compute_bf16[0]))
 
 
 def _gemm(problems, ref):

@@ -72,6 +72,11 @@ typedef struct {
    * the slots (butd_sa_bn_finalize). */
   int col_slots;
   long col_slot_stride;
+  /* != 0: round the operands to bf16 (nearest even) while they are staged and multiply on the bf16 matrix
+   * cores (v_mfma_f32_16x16x32_bf16), fp32 accumulation and epilogue; every tensor stays fp32 in memory.  The
+   * "bf16 attention / FFN" operating point of BASELINE configs[3]; honoured when every float4-aligned
+   * problem of a launch asks for it, ignored (fp32) for the element-wise staged ones (a2, unaligned). */
+  int compute_bf16;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).

@@ -38,9 +38,37 @@ def test_set_tile_rejects_unknown():
     assert lib.butd_gemm_set_tile(0, 0) == 0
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_random_group(seed, tile):
+@pytest.fixture(params=["f32", "bf16"])
+def dtype(request):
+    """'bf16': operands rounded to bf16 on the matrix cores (compute_bf16), fp32 accumulation -- checked against
+    float64 products of the bf16-ROUNDED operands, i.e. the rounding is the only difference allowed."""
     from butd_detr_amd import fused_attention as fa
+    prev = fa.set_compute_dtype(request.param)
+    yield request.param
+    fa.set_compute_dtype(prev)
+
+
+def _close_any(a, refs, tol, what=""):
+    """bf16 mode: a problem the float4-streaming kernel cannot take (odd sizes) is multiplied in fp32, the
+    others on bf16-rounded operands -- accept whichever reference applies."""
+    errs = []
+    for b in refs:
+        x, y = a.double().cpu().numpy(), b.double().cpu().numpy()
+        errs.append(np.abs(x - y).max() / max(np.abs(y).max(), 1e-6))
+    assert min(errs) <= tol, f"{what}: {min(errs):.3e}"
+
+
+def _op(t, dtype):
+    """An operand as the kernel multiplies it: fp32, or rounded to bf16 (nearest even)."""
+    return t.double() if dtype == "f32" else t.bfloat16().double()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_group(seed, tile, dtype):
+    from butd_detr_amd import fused_attention as fa
+    # bf16: a prologue affine is evaluated in fp32 and THEN rounded; an fma-vs-mul+add difference of one fp32
+    # ulp there can move the bf16 rounding of an operand element by one bf16 ulp (2^-8 relative)
+    tol_scale = 1.0 if dtype == "f32" else 20.0
     rng = np.random.default_rng(seed)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(seed)
@@ -67,27 +95,30 @@ def test_random_group(seed, tile):
             keep += [x, w, y, bias, aff, c2, stats]
             probs.append(fa._fwd(x, w, y, M, N, K, bias=bias, relu=relu, scale=scale, a_affine=aff, c_add=c_add,
                                  c2=c2, col_stats=None if stats is None else (stats[0], stats[1])))
-            xa = x.double() if aff is None else torch.relu(x.double() * aff[0].double() + aff[1].double())
-            ref = xa @ w.double().t()
-            if bias is not None:
-                ref = ref + bias.double()
-            ref = ref * scale
-            if relu:
-                ref = torch.relu(ref)
+            xa = x if aff is None else torch.relu(x * aff[0] + aff[1])
 
-            def check(y=y, ref=ref, c_add=c_add, y0=y0, c2=c2, c20=c20, stats=stats):
-                _close(y, ref + y0.double() if c_add else ref)
+            def finish(ref, bias=bias, scale=scale, relu=relu):
+                if bias is not None:
+                    ref = ref + bias.double()
+                ref = ref * scale
+                return torch.relu(ref) if relu else ref
+            ref = finish(_op(xa, dtype) @ _op(w, dtype).t())
+            ref32 = finish(xa.double() @ w.double().t())
+
+            def check(y=y, refs=(ref, ref32), c_add=c_add, y0=y0, c2=c2, c20=c20, stats=stats):
+                _close_any(y, [r + y0.double() if c_add else r for r in refs], 2e-4 * tol_scale)
                 if c2 is not None:
-                    _close(c2, c20.double() + ref)
+                    _close_any(c2, [c20.double() + r for r in refs], 2e-4 * tol_scale)
                 if stats is not None:
-                    _close(stats[0], ref.sum(0), 1e-3)
-                    _close(stats[1], (ref * ref).sum(0), 1e-3)
+                    _close_any(stats[0], [r.sum(0) for r in refs], 1e-3 * tol_scale)
+                    _close_any(stats[1], [(r * r).sum(0) for r in refs], 1e-3 * tol_scale)
             checks.append(check)
         elif kind == "dgrad":
             dy, w, dx = r(M, N), r(N, K), torch.full((M, K), float("nan"), device=dev)
             keep += [dy, w, dx]
             probs.append(fa._dgrad(dy, w, dx, M, N, K))
-            checks.append(lambda dx=dx, dy=dy, w=w: _close(dx, dy.double() @ w.double()))
+            checks.append(lambda dx=dx, dy=dy, w=w: _close_any(dx, [_op(dy, dtype) @ _op(w, dtype),
+                                                                     dy.double() @ w.double()], 2e-4))
         else:
             dy, x = r(M, N), r(M, K)
             dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
@@ -96,12 +127,12 @@ def test_random_group(seed, tile):
             baff = (torch.rand(K, device=dev, generator=g) + 0.5, r(K)) if rng.random() < 0.3 else None
             keep += [dy, x, dw, db, baff]
             probs.append(fa._wgrad(dy, x, dw, db if with_bias else None, M, N, K, b_affine=baff))
-            xd = x.double() if baff is None else torch.relu(x.double() * baff[0].double() + baff[1].double())
+            xe = x if baff is None else torch.relu(x * baff[0] + baff[1])
 
-            def check(dw=dw, db=db, dy=dy, x=xd, with_bias=with_bias):
-                _close(dw, dy.double().t() @ x, 5e-4)
+            def check(dw=dw, db=db, dy=dy, xe=xe, with_bias=with_bias):
+                _close_any(dw, [_op(dy, dtype).t() @ _op(xe, dtype), dy.double().t() @ xe.double()], 5e-4 * tol_scale)
                 if with_bias:
-                    _close(db, dy.double().sum(0), 5e-4)
+                    _close_any(db, [_op(dy, dtype).sum(0), dy.double().sum(0)], 5e-4)
             checks.append(check)
     fa._gemm(probs, torch.empty(1, device=dev))
     torch.cuda.synchronize()
