@@ -228,8 +228,12 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
     if ((b | 63) >= nb) return b;                       // ragged last window: identity
     return (b & ~63) | ((b & 7) << 3) | ((b >> 3) & 7);
   }();
+  // (blk_begin is monotone and padded with the grid size: eight independent scalar loads and compares
+  // instead of a chain of dependent ones in front of the first operand load)
   int pi = 0;
-  while (pi + 1 < batch.count && wg >= batch.blk_begin[pi + 1]) ++pi;
+#pragma unroll
+  for (int i = 1; i < kMaxProblems; ++i) pi += (wg >= batch.blk_begin[i]) ? 1 : 0;
+  pi = min(pi, batch.count - 1);
   const butd_gemm_problem &P = batch.p[pi];
   int rel = wg - batch.blk_begin[pi];
   const int tn = batch.tiles_n[pi], tm = batch.tiles_m[pi];

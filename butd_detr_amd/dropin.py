@@ -36,8 +36,17 @@ def _find_reference_models(reference_root):
     return None
 
 
-def install(scope="all", attention_backend="hip", reference_root=None):
-    from . import pointnet2_ext
+def install(scope="all", attention_backend="hip", reference_root=None, ops_binding="ctypes"):
+    """``ops_binding``: which module becomes ``pointnet2._ext`` -- "ctypes" (butd_detr_amd.pointnet2_ext, the
+    product path's binding) or "aten" (the compiled ATen / pybind11 front end of the same C ABI,
+    butd_detr_amd/binding/pointnet2_aten.cpp; built on first use)."""
+    if ops_binding == "aten":
+        from .binding import build as _aten_build
+        pointnet2_ext = _aten_build.load()
+    elif ops_binding == "ctypes":
+        from . import pointnet2_ext
+    else:
+        raise ValueError(ops_binding)
     pkg = sys.modules.get("pointnet2")
     if pkg is None:
         pkg = types.ModuleType("pointnet2")

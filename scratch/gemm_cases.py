@@ -76,7 +76,7 @@ CASES = [
     ("SA bwd w(256,128,64k)+d", lambda: [wgrad(1 << 16, 256, 128, bias=False, baff=True), dgrad(1 << 16, 256, 128)]),
 ]
 only = os.environ.get("CASES")
-print("%-40s %s" % ("case", " ".join("%9s" % ("auto" if t == (0, 0) else "%dx%d" % t) for t in TILES)))
+print("%-40s %s" % ("case", " ".join("%9s" % ("auto" if t == (0, 0) else "%dx%d%s" % (t[0], abs(t[1]), "/1" if t[1] < 0 else "")) for t in TILES)))
 for name, mk in CASES:
     if only and only not in name:
         continue

@@ -75,3 +75,13 @@ def test_same_results_as_the_ctypes_binding(ext):
     assert torch.equal(inds_b, ct.furthest_point_sampling(big, 2048))
     cb = torch.gather(big, 1, inds_b.long()[..., None].expand(-1, -1, 3)).contiguous()
     assert torch.equal(ext.ball_query(cb, big, 0.2, 64), ct.ball_query(cb, big, 0.2, 64))
+
+
+def test_dropin_can_register_it_as_the_reference_extension(ext, monkeypatch):
+    import sys
+    for k in [k for k in sys.modules if k.startswith("pointnet2")]:
+        monkeypatch.delitem(sys.modules, k)
+    from butd_detr_amd import dropin
+    dropin.install(scope="ops", ops_binding="aten")
+    import pointnet2._ext as _ext
+    assert _ext is ext and callable(_ext.ball_query)
