@@ -175,8 +175,8 @@ def attention_roofline(batch, reps=10):
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC profile (profiles/r01_pmc.json), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    """HBM bytes per launch from the committed PMC profile (profiles/r02_pmc.json), or None."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
     try:
         return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:

@@ -1,4 +1,4 @@
-"""gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}.json -> profiles/r01_pmc.json (HBM bytes per launch, corrected as
+"""gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}.json -> profiles/r02_pmc.json (HBM bytes per launch, corrected as
 MI355X_MICROARCH.md's HBM section prescribes for gfx950)."""
 import json, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
@@ -15,5 +15,5 @@ for k in f:
     fk, wk = f[k]["avg_FETCH_SIZE"], w[k]["avg_WRITE_SIZE"]
     out[k] = {"launches": f[k]["launches"], "avg_FETCH_SIZE_kb": round(fk, 1), "avg_WRITE_SIZE_kb": round(wk, 1),
               "hbm_bytes_per_launch": int((2 * fk + wk) * 1024)}
-json.dump(out, open("profiles/r01_pmc.json" if len(sys.argv) < 3 else sys.argv[2], "w"), indent=1)
+json.dump(out, open("profiles/r02_pmc.json" if len(sys.argv) < 3 else sys.argv[2], "w"), indent=1)
 print(json.dumps(out, indent=1))
