@@ -13,6 +13,8 @@ packed in-proj, q * sqrt(1/head_dim), additive -inf key-padding mask, softmax, d
 """
 from copy import deepcopy
 
+import os
+
 import torch
 from torch import nn
 
@@ -150,6 +152,21 @@ class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
                         key_padding_mask=src_key_padding_mask)
 
 
+_LANGUAGE_STREAMS = {}
+
+
+def _language_stream(device):
+    st = _LANGUAGE_STREAMS.get(device)
+    if st is None:
+        st = _LANGUAGE_STREAMS[device] = torch.cuda.Stream(device)
+    return st
+
+
+def _fork_language(t):
+    """Fused gfx950 path on a GPU only (BUTD_ENCODER_FORK=0 switches it off: debug hook)."""
+    return t.is_cuda and ab.get_backend() == "hip" and os.environ.get("BUTD_ENCODER_FORK", "1") != "0"
+
+
 class BiEncoderLayer(nn.Module):
     """visual self-attn -> language self-attn -> CrossAttentionLayer."""
 
@@ -166,6 +183,9 @@ class BiEncoderLayer(nn.Module):
 
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
                 end_points={}, detected_feats=None, detected_mask=None):
+        if _fork_language(vis_feats):
+            return self._forward_forked(vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
+                                        detected_feats, detected_mask)
         if self.self_attention_visual is not None:
             vis_feats = self.self_attention_visual(vis_feats, pos_feats,
                                                    src_key_padding_mask=padding_mask)
@@ -176,6 +196,38 @@ class BiEncoderLayer(nn.Module):
                                 text_feats=text_feats, text_key_padding_mask=text_padding_mask,
                                 pos_feats=pos_feats, detected_feats=detected_feats,
                                 detected_mask=detected_mask)
+
+    def _forward_forked(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
+                        detected_feats, detected_mask):
+        """The language side of the layer (self-attention over <= 80 tokens, language <- vision cross-attention,
+        its FFN: ~25 launches forward, ~60 backward, most of them 640-row kernels that leave the chip idle) on a
+        forked stream next to the vision side, which is several times longer.  The two sides only read each
+        other's self-attention outputs (encoder_decoder_layers.py:83,101-102), so there are two hand-over points;
+        fork / join are captured as parallel branches of the hipGraph, autograd runs each node's backward on the
+        stream of its forward."""
+        main = torch.cuda.current_stream(vis_feats.device)
+        side = _language_stream(vis_feats.device)
+        side.wait_stream(main)
+        text_feats.record_stream(side)
+        with torch.cuda.stream(side):
+            text_self = text_feats
+            if self.self_attention_lang is not None:
+                text_self = self.self_attention_lang(text_feats, src_key_padding_mask=text_padding_mask)
+        vis_self = vis_feats
+        if self.self_attention_visual is not None:
+            vis_self = self.self_attention_visual(vis_feats, pos_feats, src_key_padding_mask=padding_mask)
+        side.wait_stream(main)                  # language <- vision reads vis_self
+        main.wait_stream(side)                  # vision <- language reads text_self
+        vis_self.record_stream(side)
+        text_self.record_stream(main)
+        cross = self.cross_layer
+        with torch.cuda.stream(side):
+            text_out = cross.language_branch(text_self, vis_self, padding_mask)
+        vis_out = cross.vision_branch(vis_self, text_self, text_padding_mask, pos_feats, detected_feats,
+                                      detected_mask)
+        main.wait_stream(side)                  # join
+        text_out.record_stream(main)
+        return vis_out, text_out
 
 
 class BiEncoder(nn.Module):

@@ -496,6 +496,10 @@ class GraphedTrainStep:
         if self.split:
             self.flat_a = _OptimizerGradients(optimizer, 0, optimizer.n_first)
             self.flat_b = _OptimizerGradients(optimizer, optimizer.n_first, None)
+        # with a process group alive its watchdog thread polls events while this thread captures: under the default
+        # (global) capture mode that aborts the process (seen with RCCL at world size 1); only this thread's own
+        # calls have to be capture-safe
+        self._capture_mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
         self._slots, self._slot, self._sig = {}, None, None
 
     # -- pieces shared by the eager warm-up and the captured region
@@ -694,19 +698,19 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         if self.split:
             s.g_stage1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(s.g_stage1):
+            with torch.cuda.graph(s.g_stage1, capture_error_mode=self._capture_mode):
                 s.loss = self._stage1()
             s.g_stage2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(s.g_stage2, pool=s.g_stage1.pool()):
+            with torch.cuda.graph(s.g_stage2, pool=s.g_stage1.pool(), capture_error_mode=self._capture_mode):
                 self._stage2()
             pool = s.g_stage1.pool()
         else:
             s.g_fwd_bwd = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(s.g_fwd_bwd):
+            with torch.cuda.graph(s.g_fwd_bwd, capture_error_mode=self._capture_mode):
                 s.loss = self._fwd_bwd()
             pool = s.g_fwd_bwd.pool()
         s.g_update = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(s.g_update, pool=pool):
+        with torch.cuda.graph(s.g_update, pool=pool, capture_error_mode=self._capture_mode):
             self._update()
         # the captures above ran the optimizer once more under capture semantics only (nothing executed)
 
