@@ -131,7 +131,7 @@ def gemm_roofline(step_fn):
             "algorithmic_flops_per_step": flops}
 
 
-def attention_roofline(batch, reps=10):
+def attention_roofline(batch, reps=10, bf16=False):
     """The attention core on the encoder's visual self-attention shape (B x 8 heads, 1024 x 1024, head
     dim 36, dropout 0.1): forward and backward launches timed with HIP events on the launch stream;
     algorithmic FLOPs = 4*Lq*Lk*D per head forward, 2.5x that backward."""
@@ -146,12 +146,15 @@ def attention_roofline(batch, reps=10):
     ctr = fa.rng_counter(dev).data_ptr()
     stream = torch.cuda.current_stream()
 
+    fwd_fn = lib.butd_attention_fwd_bf16 if bf16 else lib.butd_attention_fwd
+    bwd_fn = lib.butd_attention_bwd_bf16 if bf16 else lib.butd_attention_bwd
+
     def fwd():
-        return lib.butd_attention_fwd(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
+        return fwd_fn(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
                                       lse.data_ptr(), 0.1, 7, ctr, stream.cuda_stream)
 
     def bwd():
-        return lib.butd_attention_bwd(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
+        return bwd_fn(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
                                       do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                       dv.data_ptr(), 0, 0, 1.0, 0.1, 7, ctr, stream.cuda_stream)
 
@@ -168,9 +171,11 @@ def attention_roofline(batch, reps=10):
     ms_f, ms_b = timed(fwd), timed(bwd)
     flops_f = 4.0 * L * L * D * H * B
     achieved = (flops_f * 3.5) / ((ms_f + ms_b) * 1e-3) / 1e12
-    return {"kernel": "attn_fwd / attn_bwd_dq / attn_bwd_dkv (B=%d, 8 heads, 1024x1024, head dim 36)" % B,
-            "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MATRIX_PEAK_TF, 4), "traffic": _pmc_traffic("attn_fwd_kernel"),
+    peak = BF16_MATRIX_PEAK_TF if bf16 else FP32_MATRIX_PEAK_TF
+    return {"kernel": "attn_fwd / attn_bwd_dq / attn_bwd_dkv%s (B=%d, 8 heads, 1024x1024, head dim 36)"
+                      % (" <bf16 matrix steps>" if bf16 else "", B),
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": _pmc_traffic("attn_fwd_kernel"),
             "fwd_ms": round(ms_f, 4), "bwd_ms": round(ms_b, 4)}
 
 
@@ -338,9 +343,10 @@ def bf16_row(args, model, opt, criterion, inputs, targets):
                         "(HBM / L2 -> LDS), not by the matrix pipe")
         return {"value": round(args.batch * args.steps / dt, 3), "unit": "scenes/s",
                 "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "dtype": "bf16 operands / f32 accumulate in every grouped product; attention core, statistics, "
-                         "index ops and all tensors in memory f32",
-                "final_loss": round(float(loss), 4), "roofline": gemm}
+                "dtype": "bf16 operands / f32 accumulate in every grouped product and in the attention core's matrix "
+                         "steps; statistics, index ops and all tensors in memory f32",
+                "final_loss": round(float(loss), 4), "roofline": gemm,
+                "roofline_attention": attention_roofline(args.batch, bf16=True)}
     finally:
         fused_attention.set_compute_dtype("f32")
 
@@ -428,7 +434,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16 operands / f32 accumulate (grouped products); f32 elsewhere",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 operands / f32 accumulate (grouped products, attention "
+                                                       "matrix steps); f32 elsewhere",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[2]/[3]: {args.batch} scenes/GPU x {args.points} "
                                    f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "

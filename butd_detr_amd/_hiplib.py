@@ -62,6 +62,9 @@ ATTENTION_SYMBOLS = {
     "butd_attention_fwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_attention_bwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
                            + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+    "butd_attention_fwd_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+    "butd_attention_bwd_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
+                                + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_fwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 3
                                        + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_bwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 10

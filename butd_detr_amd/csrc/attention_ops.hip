@@ -246,6 +246,58 @@ namespace {
 constexpr int kAttnThreads = 256;
 constexpr float kNegInf = -INFINITY;
 
+// ---- fp32 / bf16 matrix steps ---------------------------------------------------------------------------
+// BF = false: v_mfma_f32_16x16x4_f32 (exact fp32).  BF = true (BASELINE configs[3], "bf16 attention"): operands
+// rounded to bf16 (nearest even) in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulation; softmax statistics,
+// the exponentials and everything in memory stay fp32.  A contraction index may be permuted freely as long as
+// both operands use the same permutation, so the head-dimension fragment of a lane (NS consecutive d) is simply
+// cut into quartets (zero padded: 36 = 9 quartets of the four lane groups) -- the LDS images are the fp32 ones.
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int NS, bool BF>
+struct DFrag {                      // one lane's share of a head-dimension operand
+  float f[NS];
+};
+template <int NS>
+struct DFrag<NS, true> {
+  bf16x4 v[(NS + 3) / 4];
+};
+template <int NS, bool BF>
+__device__ inline DFrag<NS, BF> make_frag(const float (&f)[NS]) {
+  DFrag<NS, BF> r;
+  if constexpr (!BF) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) r.f[s] = f[s];
+  } else {
+#pragma unroll
+    for (int m = 0; m < (NS + 3) / 4; ++m) {
+      float e[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e[i] = (4 * m + i < NS) ? f[4 * m + i] : 0.f;
+      r.v[m] = (bf16x4){(__bf16)e[0], (__bf16)e[1], (__bf16)e[2], (__bf16)e[3]};
+    }
+  }
+  return r;
+}
+// acc += A . B over the head dimension
+template <int NS, bool BF>
+__device__ inline f32x4 mma_d(const DFrag<NS, BF> &a, const DFrag<NS, BF> &b, f32x4 acc) {
+  if constexpr (!BF) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.f[s], b.f[s], acc, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int m = 0; m < (NS + 3) / 4; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a.v[m], b.v[m], acc, 0, 0, 0);
+  }
+  return acc;
+}
+// acc += A . B over the 16 rows of a score tile (this lane: rows 4g .. 4g+3), bf16 only: one instruction
+__device__ inline f32x4 mma_k16(const float (&a)[4], const f32x4 &b, f32x4 acc) {
+  const bf16x4 pa = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+  const bf16x4 pb = {(__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(pa, pb, acc, 0, 0, 0);
+}
+
 // Grid (tiles, H, B) -> (tile, h, b) of this workgroup.  Hardware workgroup i runs on XCD i % 8 and every XCD
 // has its own L2: in launch order the 16 query tiles of one (b, h) would be sprayed over all eight XCDs and
 // each L2 would fetch the same K / V slices (counter traffic 63 MB per forward launch for 20-38 MB of
@@ -358,7 +410,7 @@ struct Img {
 // NG = 2 (small grids, e.g. the decoder's 256 queries: 256 workgroups = ONE wave per SIMD, nothing to
 // hide a stall behind): two wave groups of a 512-thread workgroup walk the even / odd key tiles of the
 // same 64 queries with their own LDS images and merge their (o, m, l) states through LDS at the end.
-template <int NS, int NT, int NG>
+template <int NS, int NT, int NG, bool BF = false>
 __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
@@ -389,6 +441,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
 
   float qf[NS];
   load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
+  const DFrag<NS, BF> qF = make_frag<NS, BF>(qf);
   int vcol[NT];
   bool vok[NT];
 #pragma unroll
@@ -429,10 +482,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
       for (int t = 0; t < 4; ++t) {
         float kf[NS];
         I::frag(kf, Kimg[cur], t * 16 + fr, fg);
-        st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-          st[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[s], st[t], 0, 0, 0);
+        st[t] = mma_d<NS, BF>(make_frag<NS, BF>(kf), qF, (f32x4){0.f, 0.f, 0.f, 0.f});
       }
       float tmax = kNegInf;
 #pragma unroll
@@ -464,6 +514,17 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
       // O^T[n][q] += V^T[n][key] P^T[key][q]
+      if constexpr (BF) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float a4[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a4[s] = vok[nt] ? Vimg[cur][t * 16 + fg * 4 + s][vcol[nt]] : 0.f;
+            o[nt] = mma_k16(a4, st[t], o[nt]);
+          }
+      } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -475,6 +536,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
             o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, st[t][s], o[nt], 0, 0, 0);
           }
         }
+      }
       m = m_new;
     }
     if (more) {
@@ -534,7 +596,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
 // dQ: same walk as the forward with K and V swapping roles.  Also produces
 // delta[b,h,q] = sum_n dO[q][n] * O[q][n]  (each query row belongs to exactly one wave here) for the
 // dK/dV kernel that is launched next -- it used to be a launch of its own.
-template <int NS, int NT, int NG>
+template <int NS, int NT, int NG, bool BF = false>
 __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
@@ -569,6 +631,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
   float qf[NS], gf[NS];
   load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
   load_row_frag<NS>(gf, gb, E, qi, Lq, fg, D);
+  const DFrag<NS, BF> qF = make_frag<NS, BF>(qf), gF = make_frag<NS, BF>(gf);
   // rows beyond Lq: lse = +inf makes every probability exp(s - inf) = 0
   const float my_lse = qi < Lq ? lse[((long)b * H + h) * Lq + qi] : INFINITY;
   float my_delta;
@@ -622,10 +685,15 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
         I::frag(kf, Kimg[cur], t * 16 + fr, fg);
         I::frag(vf, Vimg[cur], t * 16 + fr, fg);
         f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
+          st = mma_d<NS, BF>(make_frag<NS, BF>(kf), qF, st);   // S^T
+          dp = mma_d<NS, BF>(make_frag<NS, BF>(vf), gF, dp);   // dP^T
+        } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[s], qf[s], st, 0, 0, 0);  // S^T
           dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s], gf[s], dp, 0, 0, 0);  // dP^T
+        }
         }
         const float4 bb = *reinterpret_cast<const float4 *>(&Bias[cur][t * 16 + fg * 4]);
         const float bias4[4] = {bb.x, bb.y, bb.z, bb.w};
@@ -642,6 +710,17 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
         }
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+      if constexpr (BF) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float a4[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) a4[s] = kok[nt] ? Kimg[cur][t * 16 + fg * 4 + s][kcol[nt]] : 0.f;
+            acc[nt] = mma_k16(a4, ds[t], acc[nt]);
+          }
+      } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -653,6 +732,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ds[t][s], acc[nt], 0, 0, 0);
           }
         }
+      }
     }
     if (more) {
       I::commit(Kimg[cur ^ 1], kr, D, tid);
@@ -700,7 +780,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
 // dV^T[n][key] += dO^T[n][q] P[q][key]  and  dK^T[d][key] += Q^T[d][q] dS[q][key].
 // NG = 2 (few key tiles: cross-attention to 80 tokens / 132 boxes is 128-192 workgroups): two wave
 // groups walk the even / odd QUERY tiles and add their dK / dV shares through LDS at the end.
-template <int NS, int NT, int NG>
+template <int NS, int NT, int NG, bool BF = false>
 __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ dout,
@@ -739,6 +819,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
   float kf[NS], vf[NS];
   load_row_frag<NS>(kf, kb, E, ki, Lk, fg, D);
   load_row_frag<NS>(vf, vb, E, ki, Lk, fg, D);
+  const DFrag<NS, BF> kF = make_frag<NS, BF>(kf), vF = make_frag<NS, BF>(vf);
   int ncol[NT];
   bool nok[NT];
 #pragma unroll
@@ -790,10 +871,15 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
         I::frag(qf, Qimg[cur], t * 16 + fr, fg);
         I::frag(gf, Gimg[cur], t * 16 + fr, fg);
         f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF) {
+          st = mma_d<NS, BF>(make_frag<NS, BF>(qf), kF, st);   // S[q][key]
+          dp = mma_d<NS, BF>(make_frag<NS, BF>(gf), vF, dp);   // dP[q][key]
+        } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           st = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], kf[s], st, 0, 0, 0);  // S[q][key]
           dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[s], vf[s], dp, 0, 0, 0);  // dP[q][key]
+        }
         }
         const float4 l4 = *reinterpret_cast<const float4 *>(&Lse[cur][t * 16 + fg * 4]);
         const float4 d4 = *reinterpret_cast<const float4 *>(&Del[cur][t * 16 + fg * 4]);
@@ -811,6 +897,19 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
           pd[i] = p * keepf;
           ds[i] = p * (dp[i] * keepf - dq4[i]);
         }
+        if constexpr (BF) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float g4[4], q4[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              g4[s] = nok[nt] ? Gimg[cur][t * 16 + fg * 4 + s][ncol[nt]] : 0.f;
+              q4[s] = nok[nt] ? Qimg[cur][t * 16 + fg * 4 + s][ncol[nt]] : 0.f;
+            }
+            av[nt] = mma_k16(g4, pd, av[nt]);
+            ak[nt] = mma_k16(q4, ds, ak[nt]);
+          }
+        } else {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const float *grow = Gimg[cur][t * 16 + fg * 4 + s];
@@ -822,6 +921,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
             av[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, pd[s], av[nt], 0, 0, 0);
             ak[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, ds[s], ak[nt], 0, 0, 0);
           }
+        }
         }
       }
     }
@@ -879,22 +979,28 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
 
 extern "C" {
 
-// kernels with the key-group parameter: NG = 2 for grids that leave the SIMDs a single wave each
-#define ATTN_DISPATCH_G(KERNEL, split, grid, ...)                                                   \
+// kernels with the key-group parameter: NG = 2 for grids that leave the SIMDs a single wave each;
+// BF: the bf16 matrix steps
+#define ATTN_DISPATCH_GB(KERNEL, split, BFV, grid, ...)                                             \
   do {                                                                                              \
     if (split) {                                                                                    \
       const dim3 blk(kAttnThreads * 2);                                                             \
-      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 2>), grid, blk, 0, s, __VA_ARGS__);             \
-      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 2>), grid, blk, 0, s, __VA_ARGS__);        \
-      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 2>), grid, blk, 0, s, __VA_ARGS__);        \
-      else hipLaunchKernelGGL((KERNEL<12, 3, 2>), grid, blk, 0, s, __VA_ARGS__);                    \
+      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);        \
+      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
+      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
+      else hipLaunchKernelGGL((KERNEL<12, 3, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);               \
     } else {                                                                                        \
       const dim3 blk(kAttnThreads);                                                                 \
-      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 1>), grid, blk, 0, s, __VA_ARGS__);             \
-      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 1>), grid, blk, 0, s, __VA_ARGS__);        \
-      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 1>), grid, blk, 0, s, __VA_ARGS__);        \
-      else hipLaunchKernelGGL((KERNEL<12, 3, 1>), grid, blk, 0, s, __VA_ARGS__);                    \
+      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);        \
+      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
+      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
+      else hipLaunchKernelGGL((KERNEL<12, 3, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);               \
     }                                                                                               \
+  } while (0)
+#define ATTN_DISPATCH_G(KERNEL, split, grid, ...)                                                   \
+  do {                                                                                              \
+    if (bf16) ATTN_DISPATCH_GB(KERNEL, split, true, grid, __VA_ARGS__);                             \
+    else ATTN_DISPATCH_GB(KERNEL, split, false, grid, __VA_ARGS__);                                 \
   } while (0)
 static bool split_keys(const dim3 &g, int Lk) {
   static const int forced = getenv("BUTD_ATTN_SPLIT") ? atoi(getenv("BUTD_ATTN_SPLIT")) : -1;
@@ -903,10 +1009,10 @@ static bool split_keys(const dim3 &g, int Lk) {
   return (long)g.x * g.y * g.z <= limit && Lk >= 128;
 }
 
-int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
-                       const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
-                       float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
-                       butd_stream_t stream) {
+static int attention_fwd_impl(bool bf16, int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                              const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
+                              float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                              butd_stream_t stream) {
   if (B <= 0 || H <= 0 || Lq <= 0) return 0;
   if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
@@ -916,11 +1022,11 @@ int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
   return (int)hipGetLastError();
 }
 
-int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
-                       const float *v, const uint8_t *key_padding_mask, const float *out,
-                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
-                       float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
-                       uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream) {
+static int attention_bwd_impl(bool bf16, int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                              const float *v, const uint8_t *key_padding_mask, const float *out,
+                              const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                              float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                              uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream) {
   if (B <= 0 || H <= 0 || Lq <= 0) return 0;
   if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
   if (ld_dq == 0) ld_dq = (long)H * D;
@@ -933,6 +1039,40 @@ int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
   ATTN_DISPATCH_G(attn_bwd_dkv_kernel, split_keys(gk, Lq), gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
                 dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter);
   return (int)hipGetLastError();
+}
+
+int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                       const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
+                       float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                       butd_stream_t stream) {
+  return attention_fwd_impl(false, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p, dropout_site,
+                            rng_counter, stream);
+}
+
+int butd_attention_fwd_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                            const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
+                            float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                            butd_stream_t stream) {
+  return attention_fwd_impl(true, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p, dropout_site,
+                            rng_counter, stream);
+}
+
+int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                       const float *v, const uint8_t *key_padding_mask, const float *out,
+                       const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                       float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                       uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream) {
+  return attention_bwd_impl(false, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq, dk, dv, ld_dq,
+                            ld_dkv, dq_scale, dropout_p, dropout_site, rng_counter, stream);
+}
+
+int butd_attention_bwd_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                            const float *v, const uint8_t *key_padding_mask, const float *out,
+                            const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                            float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                            uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream) {
+  return attention_bwd_impl(true, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq, dk, dv, ld_dq,
+                            ld_dkv, dq_scale, dropout_p, dropout_site, rng_counter, stream);
 }
 
 }  // extern "C"

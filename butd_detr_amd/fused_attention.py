@@ -118,14 +118,22 @@ _compute_bf16 = [False]
 
 def set_compute_dtype(name):
     """'f32' (the reference's precision: exact fp32 MFMA) or 'bf16' (BASELINE configs[3]: operands of every
-    grouped product -- projections, FFN, 1x1-conv chains and their gradient products -- rounded to bf16 on
-    the matrix cores, fp32 accumulation; LayerNorm / softmax / BatchNorm statistics, the attention core and
-    all tensors in memory stay fp32).  Returns the previous setting."""
+    grouped product -- projections, FFN, 1x1-conv chains and their gradient products -- and of the attention
+    core's matrix steps rounded to bf16 on the matrix cores, fp32 accumulation; LayerNorm / softmax / BatchNorm
+    statistics and all tensors in memory stay fp32).  Returns the previous setting."""
     if name not in ("f32", "bf16"):
         raise ValueError(name)
     prev = "bf16" if _compute_bf16[0] else "f32"
     _compute_bf16[0] = name == "bf16"
     return prev
+
+
+def _attn_fwd():
+    return _lib.butd_attention_fwd_bf16 if _compute_bf16[0] else _lib.butd_attention_fwd
+
+
+def _attn_bwd():
+    return _lib.butd_attention_bwd_bf16 if _compute_bf16[0] else _lib.butd_attention_bwd
 
 
 def get_compute_dtype():
@@ -203,7 +211,7 @@ class _AttentionBlock(torch.autograd.Function):
         att = torch.empty((B, Lq, E), device=dev)
         lse = torch.empty((B, H, Lq), device=dev)
         with torch.cuda.device(dev):
-            err = _lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            err = _attn_fwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                           _ptr(mask), att.data_ptr(), lse.data_ptr(), p_attn, site_attn,
                                           rng_counter(dev).data_ptr(), _stream(xq))
         _hiplib.check(err, "butd_attention_fwd")
@@ -260,7 +268,7 @@ class _AttentionBlock(torch.autograd.Function):
         dv = torch.empty((B, Lk, E), device=dev)
         delta = torch.empty((B, H, Lq), device=dev)
         with torch.cuda.device(dev):
-            err = _lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            err = _attn_bwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                           _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
                                           delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                           0, 0, 1.0, p_attn, site_attn, rng_counter(dev).data_ptr(),
@@ -417,7 +425,7 @@ class _XpmBlock(torch.autograd.Function):
         att = torch.empty((B, Lq, E), device=dev)
         lse = torch.empty((B, H, Lq), device=dev)
         with torch.cuda.device(dev):
-            err = _lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            err = _attn_fwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                           _ptr(mask), att.data_ptr(), lse.data_ptr(), p_attn, site_attn,
                                           rng_counter(dev).data_ptr(), _stream(x))
         _hiplib.check(err, "butd_attention_fwd")
@@ -485,7 +493,7 @@ class _XpmBlock(torch.autograd.Function):
         delta = torch.empty((B, H, Lq), device=dev)
         scale = math.sqrt(1.0 / float(D))
         with torch.cuda.device(dev):
-            err = _lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            err = _attn_bwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                           _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
                                           delta.data_ptr(), dq_ptr, dk_ptr, dv_ptr, ld_dq, ldg, scale,
                                           p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))

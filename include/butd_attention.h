@@ -111,6 +111,19 @@ int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
                        float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
                        uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
 
+/* The same two entry points with the matrix steps on the bf16 matrix cores (BASELINE configs[3]: "bf16 attention"):
+ * operands rounded to bf16 (nearest even) in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulation; scores'
+ * statistics, exponentials, the (o, m, l) state, dropout masks and every tensor in memory are fp32 as above. */
+int butd_attention_fwd_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                            const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
+                            float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                            butd_stream_t stream);
+int butd_attention_bwd_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                            const float *v, const uint8_t *key_padding_mask, const float *out,
+                            const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                            float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                            uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
+
 /* y = LayerNorm(residual + dropout(x)) over the last dim (cols <= 1024), eps as nn.LayerNorm.
  * Saves mean/rstd (rows) for backward. */
 int butd_add_dropout_layernorm_fwd(int rows, int cols, const float *x, const float *residual,

@@ -221,3 +221,84 @@ def test_attention_dropout_keep_rate(mods):
     torch.cuda.synchronize()
     assert abs(o.mean().item() - 1.0) < 0.01
     assert 0.02 < o.std().item() < 0.06          # sqrt(p/(1-p)/Lk) = 0.029
+
+
+@pytest.mark.parametrize("pattern,B,Lq,Lk,masked", [("self_pos", 8, 1024, 1024, False), ("cross_pos", 8, 256, 1024, False),
+                                                    ("cross_pos", 4, 1024, 132, True), ("cross", 2, 80, 1024, False),
+                                                    ("self", 3, 100, 100, True)])
+def test_bf16_matrix_steps_track_fp32(mods, pattern, B, Lq, Lk, masked):
+    """BASELINE configs[3] ("bf16 attention"): butd_attention_fwd_bf16 / _bwd_bf16 (and the bf16 grouped products
+    around them) against the fp32 kernels on the same block: the operands of every matrix step are rounded to
+    bf16 (2^-8), accumulation and softmax statistics are fp32 -- outputs within 2e-2 of the tensor scale,
+    gradients within 5e-2, on the call-site shapes incl. the benchmarked 1024 x 1024."""
+    ab, fa, MHA, _ = mods
+    torch.manual_seed(Lq + 3 * Lk)
+    E, H = 288, 8
+    is_self = pattern.startswith("self")
+    attn = MHA(E, H, dropout=0.0).cuda().train()
+    norm = torch.nn.LayerNorm(E).cuda()
+    with torch.no_grad():
+        attn.in_proj_bias.uniform_(-0.1, 0.1)
+        norm.weight.uniform_(0.8, 1.2)
+    drop = torch.nn.Dropout(0.0)
+    x = torch.randn(B, Lq, E, device="cuda", requires_grad=True)
+    pos = torch.randn(B, Lq, E, device="cuda", requires_grad=True) if pattern.endswith("pos") else None
+    mem = None if is_self else torch.randn(B, Lk, E, device="cuda", requires_grad=True)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+        for b in range(B):
+            mask[b, Lk - 1 - 3 * b:] = True
+    probe = torch.randn(B, Lq, E, device="cuda")
+    leaves = [t for t in (x, pos, mem) if t is not None]
+    params = list(attn.parameters()) + list(norm.parameters())
+
+    def run(dtype):
+        fa.set_compute_dtype(dtype)
+        for t in leaves + params:
+            t.grad = None
+        y = ab.block(attn, drop, norm, x=x, pos=pos, memory=mem, key_padding_mask=mask)
+        (y * probe).sum().backward()
+        return y, [t.grad.clone() for t in leaves + params]
+
+    try:
+        ab.set_backend("hip")
+        y32, g32 = run("f32")
+        y16, g16 = run("bf16")
+    finally:
+        fa.set_compute_dtype("f32")
+        ab.set_backend("torch")
+    assert not torch.equal(y16, y32)
+    _close(y16, y32, 2e-2)
+    for a, b in zip(g16, g32):
+        _close(a, b, 5e-2)
+
+
+def test_bf16_attention_core_alone(mods):
+    """The core by itself (no projections): bf16 entry points vs the fp32 ones on random q, k, v -- forward within
+    1e-2 of the output scale, dq / dk / dv within 3e-2 (dropout 0.1 on: both draw the same counter-hash masks)."""
+    from butd_detr_amd import _hiplib
+    ab, fa, _, _ = mods
+    lib = _hiplib.load()
+    B, H, D, Lq, Lk = 4, 8, 36, 512, 320
+    E = H * D
+    g = torch.Generator(device="cuda").manual_seed(0)
+    q, k, v, do = (torch.randn(B, L, E, device="cuda", generator=g) * 0.5 for L in (Lq, Lk, Lk, Lq))
+    ctr = fa.rng_counter(q.device).data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    res = {}
+    for name, fwd, bwd in (("f32", lib.butd_attention_fwd, lib.butd_attention_bwd),
+                           ("bf16", lib.butd_attention_fwd_bf16, lib.butd_attention_bwd_bf16)):
+        out, dq = torch.empty_like(q), torch.empty_like(q)
+        dk, dv = torch.empty_like(k), torch.empty_like(v)
+        lse, delta = torch.empty(B, H, Lq, device="cuda"), torch.empty(B, H, Lq, device="cuda")
+        assert fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(), lse.data_ptr(),
+                   0.1, 5, ctr, st) == 0
+        assert bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(), do.data_ptr(),
+                   lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), 0, 0, 1.0, 0.1, 5,
+                   ctr, st) == 0
+        torch.cuda.synchronize()
+        res[name] = (out, dq, dk, dv)
+    _close(res["bf16"][0], res["f32"][0], 1e-2)
+    for i in (1, 2, 3):
+        _close(res["bf16"][i], res["f32"][i], 3e-2)
