@@ -204,10 +204,59 @@ def supported(module, xyz, features_pm):
     return 256 % module.nsample == 0 or module.nsample in (16, 32, 64)
 
 
+def fused_eval_supported(module):
+    """butd_sa_fused_eval: hidden widths <= 128, output <= 256, all multiples of 32, nsample 16 / 32 / 64."""
+    cs = [l.conv.out_channels for l in module.mlp_module]
+    return (module.nsample in (16, 32, 64) and all(c % 32 == 0 for c in cs) and cs[0] <= 128 and cs[1] <= 128
+            and cs[2] <= 256 and os.environ.get("BUTD_SA_FUSED_EVAL", "1") != "0")
+
+
+def sa_fused_eval(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0):
+    """Inference: the whole level in ONE kernel (include/butd_sa.h: butd_sa_fused_eval) -- neighbourhood tiles in
+    LDS, three BatchNorm-folded 1x1 convolutions LDS -> MFMA -> LDS, max-pool; nothing but the pooled
+    (B, npoint, C3) features is written (SA1 at 8 x 50 000 points: 8 MB instead of 34 + 268 + 268 + 537 MB of
+    grouped input and layer outputs).  No autograd graph: callers use it under ``torch.no_grad()`` / when nothing
+    upstream requires a gradient."""
+    import ctypes
+    layers = list(module.mlp_module)
+    B, N, _ = xyz.shape
+    np_, ns = idx.shape[1], idx.shape[2]
+    C = 0 if features_pm is None else features_pm.shape[-1] - feat_offset
+    dev = xyz.device
+    ws, scales, shifts = [], [], []
+    for l in layers:
+        bn = l.bn.bn
+        w = l.conv.weight.detach().reshape(l.conv.out_channels, -1).contiguous()
+        sc = (bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)).contiguous()
+        ws.append(w)
+        scales.append(sc)
+        shifts.append((bn.bias.detach() - bn.running_mean * sc).contiguous())
+    assert ws[0].shape[1] == 3 + C
+    c_out = (ctypes.c_int * 3)(*[w.shape[0] for w in ws])
+    ldw = (ctypes.c_long * 3)(*[w.shape[1] for w in ws])
+    arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    C3 = ws[2].shape[0]
+    out_pm = torch.empty((B, np_, C3), device=dev)
+    out_cm = torch.empty((B, C3, np_), device=dev)
+    xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+    fptr = None
+    stride = 0
+    if features_pm is not None:
+        features_pm = features_pm.contiguous()
+        fptr = features_pm.data_ptr() + 4 * feat_offset
+        stride = features_pm.shape[-1]
+    _call("butd_sa_fused_eval", xyz, B, N, np_, ns, C, xyz.data_ptr(), new_xyz.data_ptr(), fptr, stride,
+          idx.data_ptr(), float(module.radius), int(bool(module.normalize_xyz)), c_out, arr(ws), ldw, arr(scales),
+          arr(shifts), out_pm.data_ptr(), out_cm.data_ptr())
+    return out_cm, out_pm
+
+
 def sa_mlp_pool(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0):
     """-> (new_features (B,C,npoint), new_features_pm (B,npoint,C)).  ``features_pm``: point-major
     (B,N,offset+C) tensor whose last C columns are the per-point features (for SA1 the raw point cloud
     with offset 3)."""
+    if (not module.training and fused_eval_supported(module) and not torch.is_grad_enabled()):
+        return sa_fused_eval(module, xyz, new_xyz, idx, features_pm, feat_offset)
     layers = list(module.mlp_module)
     bns = [l.bn.bn for l in layers]
     training = module.training

@@ -97,6 +97,21 @@ int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, 
 int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, int ldx, const int *idx,
                          float *d_feats_pm, butd_stream_t stream);
 
+/* The whole set-abstraction level for INFERENCE in one kernel (csrc/sa_fused.hip): ball-query neighbourhoods
+ * gathered into LDS tiles, three 1x1 convolutions with folded BatchNorm + ReLU run LDS -> MFMA -> LDS, max-pool
+ * over nsample; only the pooled features are written.  Replaces QueryAndGroup + SharedMLP + F.max_pool2d
+ * (pointnet2_utils.py:317-376, pytorch_utils.py:11-36, pointnet2_modules.py:243-257) in eval mode.
+ *   xyz (B,N,3), new_xyz (B,np,3), feats point-major with row stride feat_stride (NULL when C = 0),
+ *   idx (B,np,ns) int32, ns in {16, 32, 64};  layer l: w[l] (c_out[l] x k_l, row stride ldw[l]; k_0 = 3+C,
+ *   k_l = c_out[l-1]), y = relu(scale[l] * (x . w^T) + shift[l])  (scale = gamma / sqrt(var + eps),
+ *   shift = beta - mean * scale);  c_out[0], c_out[1] in {32, 64, 96, 128}, c_out[2] a multiple of 32 <= 256;
+ *   out_pm (B,np,c_out[2]) and / or out_cm (B,c_out[2],np) (either may be NULL). */
+int butd_sa_fused_eval(int B, int N, int np, int ns, int C, const float *xyz, const float *new_xyz,
+                       const float *feats, long feat_stride, const int *idx, float radius, int normalize,
+                       const int *c_out, const float *const *w, const long *ldw,
+                       const float *const *scale, const float *const *shift, float *out_pm, float *out_cm,
+                       butd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -70,3 +70,52 @@ def test_sa_module_fused_matches_torch(cfg, train):
                 assert int(b1) == int(b2) == 1
             else:
                 _close(b2, b1, 1e-4)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(N=4096, C=3, npoint=512, radius=0.4, nsample=64, mlp=[3, 64, 64, 128], B=2),          # SA1-like
+    dict(N=50000, C=3, npoint=2048, radius=0.2, nsample=64, mlp=[3, 64, 64, 128], B=8),       # SA1 at the bench size
+    dict(N=2048, C=128, npoint=1024, radius=0.4, nsample=32, mlp=[128, 128, 128, 256], B=2),  # SA2
+    dict(N=1024, C=256, npoint=512, radius=0.8, nsample=16, mlp=[256, 128, 128, 256], B=2),   # SA3
+    dict(N=512, C=256, npoint=256, radius=1.2, nsample=16, mlp=[256, 128, 128, 256], B=3),    # SA4
+    dict(N=2048, C=5, npoint=256, radius=0.5, nsample=32, mlp=[5, 32, 64, 128], B=2),         # other widths
+])
+def test_sa_level_as_one_kernel_in_eval_mode(cfg):
+    """butd_sa_fused_eval (csrc/sa_fused.hip): neighbourhood tiles in LDS, three BatchNorm-folded 1x1 convolutions
+    LDS -> MFMA -> LDS, max-pool, only the pooled features written -- vs the stock-torch module in eval mode
+    (QueryAndGroup + SharedMLP + max_pool2d, pointnet2_modules.py:243-257) and vs the multi-launch pipeline."""
+    from butd_detr_amd import attention_blocks, fused_sa
+    from butd_detr_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(cfg["N"])
+    B = cfg["B"]
+    ref = PointnetSAModuleVotes(npoint=cfg["npoint"], radius=cfg["radius"], nsample=cfg["nsample"],
+                                mlp=list(cfg["mlp"]), use_xyz=True, normalize_xyz=True).cuda().eval()
+    with torch.no_grad():
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(-1.5, 1.5)                  # negative scales too
+                m.bias.uniform_(-0.2, 0.2)
+                m.running_mean.uniform_(-0.1, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    xyz = torch.rand(B, cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(B, cfg["C"], cfg["N"], device="cuda")
+    calls = []
+    orig = fused_sa.sa_fused_eval
+    fused_sa.sa_fused_eval = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        with torch.no_grad():
+            attention_blocks.set_backend("torch")
+            x1, y1, i1 = ref(xyz, feats)
+            attention_blocks.set_backend("hip")
+            x2, y2, i2 = ref(xyz, feats)                      # no grad + eval: the one-kernel level
+            pm = ref.last_features_pm
+        assert calls == [1], "the fused eval kernel was not taken"
+        y3 = ref(xyz, feats.clone().requires_grad_(True))[1]  # grad enabled: the multi-launch pipeline
+        assert calls == [1]
+    finally:
+        fused_sa.sa_fused_eval = orig
+        attention_blocks.set_backend("torch")
+    assert torch.equal(i1, i2) and torch.equal(x1, x2)
+    _close(y2, y1, 1e-4)
+    _close(pm.transpose(1, 2), y1, 1e-4)
+    _close(y2, y3, 1e-4)
