@@ -54,6 +54,9 @@ def parse():
                          "matrix cores, fp32 accumulation (BASELINE configs[3]).  The default run reports the bf16 "
                          "mode as an extra field next to the fp32 headline")
     ap.add_argument("--no-bf16-row", action="store_true")
+    ap.add_argument("--distinct-batches", type=int, default=4,
+                    help="the timed steps rotate over this many different synthetic batches (scene geometry decides "
+                         "how much the pruned FPS and the ball query do; one batch replayed is its best case)")
     ap.add_argument("--max-targets", type=int, default=16,
                     help="target boxes per scene of the synthetic ground truth: 1..16 (grounding splits) or, "
                          "e.g., 132 = 66..132 per scene (the detection split fills the 132 slots)")
@@ -315,7 +318,7 @@ def cpu_baseline(args, scenes):
                       + (", reference criterion with scipy's linear_sum_assignment" if criterion is not None else "")}
 
 
-def bf16_row(args, model, opt, criterion, inputs, targets):
+def bf16_row(args, model, opt, criterion, batches):
     """BASELINE configs[3]'s arithmetic as an EXTRA operating point (the headline stays the reference's fp32):
     the same step re-captured with the grouped products on the bf16 matrix cores, timed the same way."""
     from butd_detr_amd import fused_attention
@@ -323,12 +326,14 @@ def bf16_row(args, model, opt, criterion, inputs, targets):
     fused_attention.set_compute_dtype("bf16")
     try:
         graphed = GraphedTrainStep(model, opt, criterion=criterion)
-        for _ in range(max(args.warmup, 1)):
-            graphed(inputs, targets, next_inputs=inputs)
+        inputs, targets = batches[0]
+        n = len(batches)
+        for k in range(max(args.warmup, 1)):
+            graphed(*batches[k % n], next_inputs=batches[(k + 1) % n][0])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss = graphed(inputs, targets, next_inputs=inputs)
+        for k in range(max(args.warmup, 1), max(args.warmup, 1) + args.steps):
+            loss = graphed(*batches[k % n], next_inputs=batches[(k + 1) % n][0])
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         from butd_detr_amd.train_step import make_optimizer, train_step as eager_step
@@ -388,8 +393,11 @@ def main():
     if backend == "hip":
         from butd_detr_amd import fused_attention
         fused_attention.set_compute_dtype(args.dtype)
-    inputs, targets = synthetic_batch(args.batch, device, n_points=args.points, tokens=args.tokens,
-                                      rank=rank, max_targets=args.max_targets)
+    # the timed steps rotate over several batches: every step sees other scenes than the one before it
+    batches = [synthetic_batch(args.batch, device, seed=1184 + 37 * k, n_points=args.points, tokens=args.tokens,
+                               rank=rank, max_targets=args.max_targets)
+               for k in range(max(1, args.distinct_batches))]
+    inputs, targets = batches[0]
     criterion = make_criterion(args)
     # a copy of the targets that already carries the rank-averaged box count, for the rank-0-only eager step of
     # the roofline section (criterion.prepare is a collective: every rank calls it here)
@@ -398,7 +406,8 @@ def main():
         ddp = wrap_data_parallel(model, device)
         opt = make_optimizer(model)
 
-        def train_step(_m, _o, i, t):
+        def train_step(k):
+            i, t = batches[k % len(batches)]
             return eager_step(ddp, opt, i, t, criterion=criterion)
     else:
         from butd_detr_amd.train_step import FlatAdamW
@@ -406,17 +415,18 @@ def main():
         graphed = GraphedTrainStep(model, opt, criterion=criterion)
         ddp = model
 
-        def train_step(_m, _o, i, t):
-            return graphed(i, t, next_inputs=i)
+        def train_step(k):       # batch k now; batch k+1 announced (its FPS chain / text run under this step)
+            i, t = batches[k % len(batches)]
+            return graphed(i, t, next_inputs=batches[(k + 1) % len(batches)][0])
 
-    for _ in range(args.warmup):
-        train_step(ddp, opt, inputs, targets)
+    for k in range(args.warmup):
+        train_step(k)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = train_step(ddp, opt, inputs, targets)
+    for k in range(args.warmup, args.warmup + args.steps):
+        loss = train_step(k)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -436,7 +446,7 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 operands / f32 accumulate (grouped products, attention "
                                                        "matrix steps); f32 elsewhere",
-            "data": "synthetic",
+            "data": f"synthetic ({len(batches)} different batches per rank, rotated)",
             "config": {"workload": f"BASELINE configs[2]/[3]: {args.batch} scenes/GPU x {args.points} "
                                    f"points, {args.queries} queries, {args.tokens} tokens, 132 box slots, "
                                    f"{args.encoder_layers} encoder + 6 decoder layers, 1..{args.max_targets} "
@@ -456,7 +466,7 @@ def main():
         else:
             out["roofline"] = ball_query_roofline(inputs)
         if backend == "hip" and world == 1 and args.dtype == "f32" and not args.eager and not args.no_bf16_row:
-            out["bf16_operating_point"] = bf16_row(args, model, opt, criterion, inputs, targets)
+            out["bf16_operating_point"] = bf16_row(args, model, opt, criterion, batches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
         print(json.dumps(out), flush=True)

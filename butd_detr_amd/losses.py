@@ -565,6 +565,12 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     else:
         generation = zero
     loss = 8 * generation + 1.0 / (num_decoder_layers + 1) * (loss_ce + 5 * loss_bbox + loss_giou + loss_align)
+    status = getattr(set_criterion.matcher, "last_status", None)
+    if status is not None:
+        # where scipy's linear_sum_assignment would have raised (NaN / -inf costs: matcher.py:105) the device solver
+        # sets a status word instead; inside a graph replay nothing can raise, so the failure is made visible the
+        # way the caller does look: the loss of that step is NaN (no host sync)
+        loss = torch.where(status.ne(0).any(), torch.full_like(loss, float("nan")), loss)
     end_points["loss_ce"] = loss_ce
     end_points["loss_bbox"] = loss_bbox
     end_points["loss_giou"] = loss_giou
@@ -572,5 +578,5 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     end_points["loss_constrastive_align"] = loss_align
     end_points["loss"] = loss
     end_points["hungarian_match"] = match
-    end_points["hungarian_status"] = getattr(set_criterion.matcher, "last_status", None)
+    end_points["hungarian_status"] = status
     return loss, end_points

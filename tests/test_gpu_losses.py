@@ -101,6 +101,22 @@ def test_criterion_on_gpu_reproduces_the_reference(path):
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6 + 1e-3 * np.abs(want).max(), err_msg=name)
 
 
+def test_a_failed_assignment_makes_the_loss_nan():
+    """Where scipy would raise (matcher.py:105: NaN costs) the device solver sets its status word; the criterion
+    turns that into a NaN loss so that a graph replay cannot train on a silently wrong match."""
+    from butd_detr_amd import losses as L
+    z, ep, leaves, crit = load_case(GOLD[0], device="cuda", grad=False)
+    layers = int(z["meta_layers"])
+    loss, out = L.compute_hungarian_loss(dict(ep), layers, crit, int(z["meta_topk"]))
+    assert torch.isfinite(loss) and not out["hungarian_status"].any()
+    bad = dict(ep)
+    key = "last_center" if "last_center" in bad else [k for k in bad if k.endswith("center")][0]
+    bad[key] = bad[key].clone()
+    bad[key][0, 0, 0] = float("nan")
+    loss, out = L.compute_hungarian_loss(bad, layers, crit, int(z["meta_topk"]))
+    assert out["hungarian_status"].any() and torch.isnan(loss)
+
+
 def test_reference_style_api_returns_scipy_indices():
     """HungarianMatcher.forward / SetCriterion.forward with the reference's list-of-dict targets."""
     from scipy.optimize import linear_sum_assignment
