@@ -318,24 +318,49 @@ def cpu_baseline(args, scenes):
                       + (", reference criterion with scipy's linear_sum_assignment" if criterion is not None else "")}
 
 
+def _time_recaptured(args, model, opt, criterion, batches, warm=None):
+    """The timed loop of main() on a freshly captured step (for the extra operating points) -> (seconds, loss)."""
+    from butd_detr_amd.train_step import GraphedTrainStep
+    graphed = GraphedTrainStep(model, opt, criterion=criterion)
+    n, warm = len(batches), max(args.warmup, 1) if warm is None else warm
+    for k in range(warm):
+        graphed(*batches[k % n], next_inputs=batches[(k + 1) % n][0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(warm, warm + args.steps):
+        loss = graphed(*batches[k % n], next_inputs=batches[(k + 1) % n][0])
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, loss
+
+
+def text_cache_row(args, model, opt, criterion, batches):
+    """SURVEY section 8(f)-3 as an EXTRA operating point: the frozen language model's hidden states per utterance
+    kept in HBM (text_stream.UtteranceCache, opt-in while training because it removes the frozen tower's dropout
+    noise) -- after the first pass over the batches RoBERTa no longer runs.  Not the headline: the reference
+    encodes every batch."""
+    from butd_detr_amd import text_stream
+    model.text_cache = text_stream.UtteranceCache(next(model.parameters()).device, cache_in_training=True)
+    try:
+        dt, loss = _time_recaptured(args, model, opt, criterion, batches, warm=max(args.warmup, len(batches) + 1))
+        c = model.text_cache
+        return {"value": round(args.batch * args.steps / dt, 3), "unit": "scenes/s",
+                "ms_per_step": round(dt / args.steps * 1e3, 3), "utterances": len(c), "store_bytes": c.bytes(),
+                "batches_served_from_hbm": c.hits, "batches_encoded": c.misses, "final_loss": round(float(loss), 4),
+                "note": "frozen RoBERTa replaced by one row gather per batch once its utterances are resident; "
+                        "the text tower then behaves as in eval() (no dropout inside it)"}
+    finally:
+        model.text_cache = None
+
+
 def bf16_row(args, model, opt, criterion, batches):
     """BASELINE configs[3]'s arithmetic as an EXTRA operating point (the headline stays the reference's fp32):
     the same step re-captured with the grouped products on the bf16 matrix cores, timed the same way."""
     from butd_detr_amd import fused_attention
-    from butd_detr_amd.train_step import GraphedTrainStep
     fused_attention.set_compute_dtype("bf16")
+    model.text_precision = "bf16"
     try:
-        graphed = GraphedTrainStep(model, opt, criterion=criterion)
         inputs, targets = batches[0]
-        n = len(batches)
-        for k in range(max(args.warmup, 1)):
-            graphed(*batches[k % n], next_inputs=batches[(k + 1) % n][0])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(max(args.warmup, 1), max(args.warmup, 1) + args.steps):
-            loss = graphed(*batches[k % n], next_inputs=batches[(k + 1) % n][0])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt, loss = _time_recaptured(args, model, opt, criterion, batches)
         from butd_detr_amd.train_step import make_optimizer, train_step as eager_step
         local_targets = criterion.prepare(targets) if criterion is not None else targets
         gemm = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, local_targets,
@@ -348,12 +373,14 @@ def bf16_row(args, model, opt, criterion, batches):
                         "(HBM / L2 -> LDS), not by the matrix pipe")
         return {"value": round(args.batch * args.steps / dt, 3), "unit": "scenes/s",
                 "ms_per_step": round(dt / args.steps * 1e3, 3),
-                "dtype": "bf16 operands / f32 accumulate in every grouped product and in the attention core's matrix "
-                         "steps; statistics, index ops and all tensors in memory f32",
+                "dtype": "bf16 operands / f32 accumulate in every grouped product, in the attention core's matrix "
+                         "steps and in the frozen language model's linear layers; statistics, index ops and all "
+                         "tensors in memory f32",
                 "final_loss": round(float(loss), 4), "roofline": gemm,
                 "roofline_attention": attention_roofline(args.batch, bf16=True)}
     finally:
         fused_attention.set_compute_dtype("f32")
+        model.text_precision = "f32"
 
 
 def make_criterion(args):
@@ -467,6 +494,7 @@ def main():
             out["roofline"] = ball_query_roofline(inputs)
         if backend == "hip" and world == 1 and args.dtype == "f32" and not args.eager and not args.no_bf16_row:
             out["bf16_operating_point"] = bf16_row(args, model, opt, criterion, batches)
+            out["text_cache_operating_point"] = text_cache_row(args, model, opt, criterion, batches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
         print(json.dumps(out), flush=True)

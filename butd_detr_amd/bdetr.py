@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import attention_blocks
+from . import attention_blocks, text_stream
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer
 from .modules import (ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule,
@@ -135,6 +135,9 @@ class BeaUTyDETR(nn.Module):
             self.contrastive_align_projection_text = _align_mlp(d_model)
 
         self.overlap_text_tower = os.environ.get("BUTD_TEXT_OVERLAP", "1") != "0"   # env: debug hook
+        # text stream options (text_stream.py): an UtteranceCache in HBM, "f32" | "bf16" language-model arithmetic
+        self.text_cache = None
+        self.text_precision = "f32"
         self._side_stream = None
         # gradient boundary between the encoder and the decoder (see cut_at_encoder_output)
         self._boundary = None
@@ -149,18 +152,25 @@ class BeaUTyDETR(nn.Module):
         ).to(inputs["point_clouds"].device)
 
     @torch.no_grad()
-    def encode_text(self, tokenized):
+    def encode_text(self, tokenized, texts=None):
         """The FROZEN language model on its own (bdetr.py:80-83 freezes every RoBERTa parameter): its
         output depends on the tokens only, so a training loop may run it for the next batch while the
-        current one trains and hand the result in as ``inputs["text_encoder_output"]``."""
-        return self.text_encoder(**tokenized).last_hidden_state
+        current one trains and hand the result in as ``inputs["text_encoder_output"]``.  With ``texts`` (the
+        utterances behind ``tokenized``) and ``self.text_cache`` set, cached utterances skip the language model
+        (text_stream.py); ``self.text_precision`` "bf16" runs its linear layers on the bf16 matrix cores."""
+        return text_stream.encode(self.text_encoder, tokenized, texts, self.text_cache, self.text_precision,
+                                  training=self.text_encoder.training,
+                                  pad_id=getattr(self.text_encoder.config, "pad_token_id", 1) or 1)
 
     def text_encoder_is_frozen(self):
         return not any(p.requires_grad for p in self.text_encoder.parameters())
 
-    def _run_text_tower(self, tokenized, end_points, hidden=None):
+    def _run_text_tower(self, tokenized, end_points, hidden=None, texts=None):
         if hidden is None:
-            hidden = self.text_encoder(**tokenized).last_hidden_state
+            if self.text_encoder_is_frozen():
+                hidden = self.encode_text(tokenized, texts)
+            else:
+                hidden = self.text_encoder(**tokenized).last_hidden_state
         end_points["text_feats"] = self.text_projector(hidden)
         # HF masks are 1 = token; torch attention wants True = padding (bdetr.py:171)
         end_points["text_attention_mask"] = tokenized.attention_mask.ne(1).bool()
@@ -185,14 +195,14 @@ class BeaUTyDETR(nn.Module):
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._run_text_tower(tokenized, text_out)
+                self._run_text_tower(tokenized, text_out, texts=inputs.get("text"))
             end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
             main.wait_stream(side)
             for v in (text_out["text_feats"], text_out["text_attention_mask"]):
                 v.record_stream(main)
         else:
             end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
-            self._run_text_tower(tokenized, text_out)
+            self._run_text_tower(tokenized, text_out, texts=inputs.get("text"))
         end_points["seed_inds"] = end_points["fp2_inds"]
         end_points["seed_xyz"] = end_points["fp2_xyz"]
         end_points["seed_features"] = end_points["fp2_features"]

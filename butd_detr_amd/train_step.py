@@ -475,6 +475,10 @@ class GraphedTrainStep:
         self.prefetch_sampling = prefetch_sampling
         self.prefetch_text = bool(prefetch_text and hasattr(self._module(), "text_encoder_is_frozen")
                                   and self._module().text_encoder_is_frozen())
+        # an UtteranceCache that may serve training batches (text_stream.py): hit or miss is host control flow, so
+        # the language model then runs OUTSIDE the graphs, on the text stream, under the previous step's replay
+        cache = getattr(self._module(), "text_cache", None)
+        self.text_outside = bool(self.prefetch_text and cache is not None and cache.cache_in_training)
         self.token_bucket = token_bucket
         self.arena = None
         from . import attention_blocks
@@ -537,7 +541,7 @@ class GraphedTrainStep:
             s.sample_stream.wait_stream(main)                # fork: next batch's chain on 8 CUs
             with torch.cuda.stream(s.sample_stream):
                 self._sample_into_next()
-        if self.prefetch_text:
+        if self.prefetch_text and not self.text_outside:
             main = torch.cuda.current_stream()
             s.text_cur.copy_(s.text_next)                    # this batch's language features
             s.text_stream.wait_stream(main)
@@ -550,7 +554,7 @@ class GraphedTrainStep:
         s = self._slot
         if self.prefetch_sampling:
             torch.cuda.current_stream().wait_stream(s.sample_stream)   # join
-        if self.prefetch_text:
+        if self.prefetch_text and not self.text_outside:
             torch.cuda.current_stream().wait_stream(s.text_stream)
 
     def _fwd_bwd_body(self):
@@ -681,8 +685,8 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
         if self.prefetch_text:
             s.tok_next = BatchEncoding({k: v.clone() for k, v in tok.items()})
-            s.text_next = self._module().encode_text(s.tok_next).clone()   # prime with THIS batch
-            s.text_cur = torch.empty_like(s.text_next)
+            s.text_next = self._module().encode_text(s.tok_next, inputs.get("text")).clone()   # THIS batch
+            s.text_cur = s.text_next.clone()
             s.inputs["text_encoder_output"] = s.text_cur
             s.text_stream = torch.cuda.Stream()
             torch.cuda.synchronize()
@@ -766,7 +770,22 @@ class GraphedTrainStep:
                 self._sample_into_next()
             s.next_pc.copy_(nxt["point_clouds"][..., :3], non_blocking=True)
         text_ok = True
-        if self.prefetch_text:
+        if self.prefetch_text and self.text_outside:
+            main, module = torch.cuda.current_stream(), self._module()
+            if announced:
+                main.wait_stream(s.text_stream)                # encoded (or gathered) under the previous replay
+            else:
+                s.text_next.copy_(module.encode_text(tok, inputs.get("text")))
+            s.text_cur.copy_(s.text_next)
+            tok_next = tok if nxt is inputs else self._tokenize(nxt)
+            text_ok = tuple(tok_next["input_ids"].shape) == tuple(s.tok_next["input_ids"].shape)
+            if text_ok:
+                s.text_stream.wait_stream(main)
+                with torch.cuda.stream(s.text_stream):         # cached utterances: one row gather, no RoBERTa
+                    s.text_next.copy_(module.encode_text(tok_next, nxt.get("text")))
+            if nxt is not inputs:
+                self._tok_cache = (nxt, tok_next)
+        elif self.prefetch_text:
             if not announced:                                  # not prefetched: encode it now
                 for k in s.tok_next.keys():
                     s.tok_next[k].copy_(tok[k])
