@@ -407,21 +407,103 @@ struct Img {
   }
 };
 
+// ---- transposed LDS image of a 64-row head slice: row = head-dim element n, column = key ---------------------
+// The P.V product  O^T[n][q] += V^T[n][key] P^T[key][q]  takes, per lane, V at FOUR CONSECUTIVE KEYS of one n: in the
+// transposed image that is one ds_read_b128 (the row-major image needed four scalar reads and, because rows >= D do
+// not exist there, a select per value).  Rows D .. 16*NT-1 are zeroed once and never written again.  LD = 68: rows
+// 4 banks apart, so the 16 rows x 4 key groups of a wave's read cover all banks evenly.
+template <int NT>
+struct TImg {
+  static constexpr int ROWS = NT * 16;
+  static constexpr int LD = 64 + 4;
+};
+
+// One thread's share of staging 64-row tiles of (L x D) head slices: which float4s it moves and where they land in the
+// fragment image (Img<NS>) resp. the transposed image (TImg).  Everything here depends on the thread id only and is
+// computed once, outside the key loop (the per-tile cost used to be an integer division per element).
+template <int NS, int NT>
+struct Stage {
+  using I = Img<NS>;
+  static constexpr int kVec = I::kVecPerThread;
+  int goff[kVec];       // element offset of the float4 inside the tile: row * E + 4 * c4
+  int row[kVec];        // its row (for the ragged last tile); 64 = this thread has no j-th float4
+  int koff[kVec][4];    // float offsets inside Img (row * LD + col(d))
+  int toff[kVec];       // float offset of element 0 inside TImg (d * LD + row); elements 1..3 are + LD each
+  __device__ inline void init(int tid, int D, long E) {
+    const int vpr = D >> 2;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      const int f = tid + j * kAttnThreads;
+      const int r = f / vpr, c4 = f - r * vpr;
+      const bool ok = r < 64;
+      row[j] = ok ? r : 64;
+      goff[j] = ok ? (int)(r * E) + c4 * 4 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) koff[j][i] = ok ? r * I::LD + I::col(c4 * 4 + i) : 0;
+      toff[j] = ok ? (c4 * 4) * TImg<NT>::LD + r : 0;
+    }
+  }
+  // rows [0, nrows) of the tile at `tile` exist (nrows >= 64: the common, unchecked case)
+  __device__ inline void fetch(float4 (&v)[kVec], const float *__restrict__ tile, int nrows) const {
+    if (nrows >= 64) {
+#pragma unroll
+      for (int j = 0; j < kVec; ++j)
+        if (row[j] < 64) v[j] = *reinterpret_cast<const float4 *>(tile + goff[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kVec; ++j)
+        v[j] = row[j] < nrows ? *reinterpret_cast<const float4 *>(tile + goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ inline void commit_frag(float *img, const float4 (&v)[kVec]) const {
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+      if (row[j] < 64) {
+        img[koff[j][0]] = v[j].x; img[koff[j][1]] = v[j].y; img[koff[j][2]] = v[j].z; img[koff[j][3]] = v[j].w;
+      }
+  }
+  __device__ inline void commit_t(float *timg, const float4 (&v)[kVec]) const {
+    constexpr int LD = TImg<NT>::LD;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+      if (row[j] < 64) {
+        float *p = timg + toff[j];
+        p[0] = v[j].x; p[LD] = v[j].y; p[2 * LD] = v[j].z; p[3 * LD] = v[j].w;
+      }
+  }
+};
+
+// ---- dropout of attention probabilities ----------------------------------------------------------------------
+// One 32-bit hash decides TWO neighbouring keys of a query (16 bits each: drop when the field is below
+// round(p * 65536)), so the kernels that hold four consecutive keys per lane (forward, dQ) hash twice per quartet
+// instead of four times.  Element (row, key): pair index row * ceil(Lk / 2) + key / 2, field key & 1.
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ inline uint32_t drop_threshold(float p) { return (uint32_t)(p * 65536.f + 0.5f); }
+__device__ inline uint32_t pair_hash(uint32_t key, uint32_t pair) { return rng::mix32(pair ^ key); }
+
 // NG = 2 (small grids, e.g. the decoder's 256 queries: 256 workgroups = ONE wave per SIMD, nothing to
 // hide a stall behind): two wave groups of a 512-thread workgroup walk the even / odd key tiles of the
 // same 64 queries with their own LDS images and merge their (o, m, l) states through LDS at the end.
+//
+// On this part the fp32 matrix instructions and ordinary VALU instructions do not overlap, not even between waves of
+// one SIMD (scratch/ubench/mfma_valu.hip: one MFMA wave + one VALU wave per SIMD take 0.88 x the SUM of their times),
+// so the time of a key tile is its 84 matrix instructions PLUS every VALU instruction around them.  The loop is
+// therefore written for instruction count: exp2 with the log2(e) factor folded into one fma, bias / all-keys-masked
+// handling only in tiles that have masked keys, dropout hashed per key pair and its 1/(1-p) applied once at the end,
+// V operands as ds_read_b128 from the transposed image (no per-value select), staging offsets precomputed.
 template <int NS, int NT, int NG, bool BF = false>
 __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
     float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
+  using T = TImg<NT>;
   __shared__ __attribute__((aligned(16))) float KimgG[NG][2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float VimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float VtG[NG][2][T::ROWS][T::LD];
   __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
   const int grp = threadIdx.x / kAttnThreads;
   float(*Kimg)[64][I::LD] = KimgG[grp];
-  float(*Vimg)[64][I::LD] = VimgG[grp];
+  float(*Vt)[T::ROWS][T::LD] = VtG[grp];
   float(*Bias)[64] = BiasG[grp];
   const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -435,46 +517,52 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
   const float *vb = v + (long)b * Lk * E + h * D;
   const uint8_t *mb = mask ? mask + (long)b * Lk : nullptr;
   const bool drop = p_drop > 0.f;
-  const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
-  const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
   const int qi = q0 + fr;  // this lane's query (column of every transposed tile)
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+  const uint32_t pair_row = (uint32_t)(((long)b * H + h) * Lq + qi) * LkP + (uint32_t)fg * 2u;
 
   float qf[NS];
   load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
   const DFrag<NS, BF> qF = make_frag<NS, BF>(qf);
-  int vcol[NT];
-  bool vok[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + fr;
-    vok[nt] = n < D;
-    vcol[nt] = I::col(vok[nt] ? n : 0);
-  }
   float m = kNegInf, l = 0.f;
   f32x4 o[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  Stage<NS, NT> sg;
+  sg.init(tid, D, E);
+  // rows D .. ROWS-1 of the transposed images: zero, once
+  for (int e = tid; e < 2 * (T::ROWS - D) * 64; e += kAttnThreads) {
+    const int buf = e / ((T::ROWS - D) * 64), r = e % ((T::ROWS - D) * 64);
+    Vt[buf][D + r / 64][r % 64] = 0.f;
+  }
+
   // key tiles of this wave group: grp, grp + NG, ... (a tile past Lk stages zeros with -inf bias and
   // contributes nothing, so both groups run the same number of iterations and barriers)
   const int iters = ((Lk + 63) / 64 + NG - 1) / NG;
-  typename I::Regs kr, vr;
+  float4 kr[Stage<NS, NT>::kVec], vr[Stage<NS, NT>::kVec];
   float br = 0.f;
-  I::fetch(kr, kb, E, D, grp * 64, Lk, tid);
-  I::fetch(vr, vb, E, D, grp * 64, Lk, tid);
-  if (tid < 64) br = key_bias(mb, grp * 64 + tid, Lk);
-  I::commit(Kimg[0], kr, D, tid);
-  I::commit(Vimg[0], vr, D, tid);
-  if (tid < 64) Bias[0][tid] = br;
+  {
+    const int key0 = grp * 64;
+    sg.fetch(kr, kb + (long)key0 * E, Lk - key0);
+    sg.fetch(vr, vb + (long)key0 * E, Lk - key0);
+    if (tid < 64) br = key_bias(mb, key0 + tid, Lk);
+    sg.commit_frag(&Kimg[0][0][0], kr);
+    sg.commit_t(&Vt[0][0][0], vr);
+    if (tid < 64) Bias[0][tid] = br;
+  }
   __syncthreads();
   int cur = 0;
   for (int it = 0; it < iters; ++it) {
     const int key0 = (it * NG + grp) * 64;
     const bool more = it + 1 < iters;
     if (more) {
-      I::fetch(kr, kb, E, D, key0 + NG * 64, Lk, tid);
-      I::fetch(vr, vb, E, D, key0 + NG * 64, Lk, tid);
-      if (tid < 64) br = key_bias(mb, key0 + NG * 64 + tid, Lk);
+      const int nk = key0 + NG * 64;
+      sg.fetch(kr, kb + (long)nk * E, Lk - nk);
+      sg.fetch(vr, vb + (long)nk * E, Lk - nk);
+      if (tid < 64) br = key_bias(mb, nk + tid, Lk);
     }
     if (live) {
       f32x4 st[4];
@@ -484,64 +572,87 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
         I::frag(kf, Kimg[cur], t * 16 + fr, fg);
         st[t] = mma_d<NS, BF>(make_frag<NS, BF>(kf), qF, (f32x4){0.f, 0.f, 0.f, 0.f});
       }
-      float tmax = kNegInf;
+      // the first V operands travel while the softmax runs
+      f32x4 va[NT];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float4 bb = *reinterpret_cast<const float4 *>(&Bias[cur][t * 16 + fg * 4]);
-        st[t][0] += bb.x; st[t][1] += bb.y; st[t][2] += bb.z; st[t][3] += bb.w;
-        tmax = fmaxf(fmaxf(fmaxf(tmax, st[t][0]), fmaxf(st[t][1], st[t][2])), st[t][3]);
+      for (int nt = 0; nt < NT; ++nt) va[nt] = *reinterpret_cast<const f32x4 *>(&Vt[cur][nt * 16 + fr][fg * 4]);
+
+      const bool masked_tile = mb != nullptr || key0 + 64 > Lk;   // uniform: bias and dead-row handling needed
+      float m_new, alpha, m2;
+      if (masked_tile) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 bb = *reinterpret_cast<const float4 *>(&Bias[cur][t * 16 + fg * 4]);
+          st[t][0] += bb.x; st[t][1] += bb.y; st[t][2] += bb.z; st[t][3] += bb.w;
+        }
       }
+      float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+      for (int t = 1; t < 4; ++t) tmax = fmaxf(tmax, fmaxf(fmaxf(st[t][0], st[t][1]), fmaxf(st[t][2], st[t][3])));
       tmax = quad_max(tmax);
-      const float m_new = fmaxf(m, tmax);
-      const bool dead = m_new == kNegInf;  // nothing but masked keys so far
-      const float alpha = dead ? 1.f : __expf(m - m_new);
+      m_new = fmaxf(m, tmax);
+      m2 = m_new * kLog2e;
+      alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m, kLog2e, -m2));
+      if (masked_tile) {
+        const bool dead = m_new == kNegInf;  // nothing but masked keys so far: exp2(-inf - 0) = 0 everywhere
+        m2 = dead ? 0.f : m2;
+        alpha = dead ? 1.f : alpha;
+      }
       float psum = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float p = dead ? 0.f : __expf(st[t][i] - m_new);
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][i], kLog2e, -m2));
           psum += p;
-          float pd = p;
-          if (drop) {
-            const int kk = key0 + t * 16 + fg * 4 + i;
-            const uint32_t idx = (uint32_t)((((long)b * H + h) * Lq + qi) * Lk + kk);
-            pd = rng::keep(ctr, site, idx, p_drop) ? p * inv_keep : 0.f;
-          }
-          st[t][i] = pd;
+          st[t][i] = p;
         }
+      if (drop) {
+        const uint32_t pair0 = pair_row + (uint32_t)(key0 >> 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t h0 = pair_hash(hkey, pair0 + t * 8), h1 = pair_hash(hkey, pair0 + t * 8 + 1);
+          st[t][0] = (h0 & 0xffffu) >= thr ? st[t][0] : 0.f;
+          st[t][1] = (h0 >> 16) >= thr ? st[t][1] : 0.f;
+          st[t][2] = (h1 & 0xffffu) >= thr ? st[t][2] : 0.f;
+          st[t][3] = (h1 >> 16) >= thr ? st[t][3] : 0.f;
+        }
+      }
       l = l * alpha + psum;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
       // O^T[n][q] += V^T[n][key] P^T[key][q]
-      if constexpr (BF) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        f32x4 vn[NT];
+        if (t < 3) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            vn[nt] = *reinterpret_cast<const f32x4 *>(&Vt[cur][nt * 16 + fr][(t + 1) * 16 + fg * 4]);
+        }
+        if constexpr (BF) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            float a4[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a4[s] = vok[nt] ? Vimg[cur][t * 16 + fg * 4 + s][vcol[nt]] : 0.f;
+            const float a4[4] = {va[nt][0], va[nt][1], va[nt][2], va[nt][3]};
             o[nt] = mma_k16(a4, st[t], o[nt]);
           }
-      } else {
+        } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+          for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float *vrow = Vimg[cur][t * 16 + fg * 4 + s];
+            for (int nt = 0; nt < NT; ++nt)
+              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], st[t][s], o[nt], 0, 0, 0);
+        }
+        if (t < 3) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float a = vok[nt] ? vrow[vcol[nt]] : 0.f;
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, st[t][s], o[nt], 0, 0, 0);
-          }
+          for (int nt = 0; nt < NT; ++nt) va[nt] = vn[nt];
         }
       }
       m = m_new;
     }
     if (more) {
-      I::commit(Kimg[cur ^ 1], kr, D, tid);
-      I::commit(Vimg[cur ^ 1], vr, D, tid);
+      sg.commit_frag(&Kimg[cur ^ 1][0][0], kr);
+      sg.commit_t(&Vt[cur ^ 1][0][0], vr);
       if (tid < 64) Bias[cur ^ 1][tid] = br;
     }
     __syncthreads();
@@ -579,7 +690,8 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
   if (live) {
     l = quad_sum(l);
     if (qi < Lq) {
-      const float inv_l = 1.f / l;  // l == 0 (every key masked) -> inf * 0 = NaN like torch's softmax
+      // l == 0 (every key masked) -> inf * 0 = NaN like torch's softmax; the dropout scale 1/(1-p) is applied here
+      const float inv_l = (drop ? 1.f / (1.f - p_drop) : 1.f) / l;
       float *ob = out + ((long)b * Lq + qi) * E + h * D;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -604,12 +716,15 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
     float *__restrict__ dq, long ldo, float dq_scale,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
+  using T = TImg<NT>;
   __shared__ __attribute__((aligned(16))) float KimgG[NG][2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float VimgG[NG][2][64][I::LD];
+  __shared__ __attribute__((aligned(16))) float KtG[NG][2][T::ROWS][T::LD];   // K transposed: the dQ product's operand
   __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
   const int grp = threadIdx.x / kAttnThreads;   // key-tile group, see attn_fwd_kernel
   float(*Kimg)[64][I::LD] = KimgG[grp];
   float(*Vimg)[64][I::LD] = VimgG[grp];
+  float(*Kt)[T::ROWS][T::LD] = KtG[grp];
   float(*Bias)[64] = BiasG[grp];
   const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -625,8 +740,11 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
   const uint8_t *mb = mask ? mask + (long)b * Lk : nullptr;
   const bool drop = p_drop > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
-  const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
   const int qi = q0 + fr;
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+  const uint32_t pair_row = (uint32_t)(((long)b * H + h) * Lq + qi) * LkP + (uint32_t)fg * 2u;
 
   float qf[NS], gf[NS];
   load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
@@ -634,6 +752,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
   const DFrag<NS, BF> qF = make_frag<NS, BF>(qf), gF = make_frag<NS, BF>(gf);
   // rows beyond Lq: lse = +inf makes every probability exp(s - inf) = 0
   const float my_lse = qi < Lq ? lse[((long)b * H + h) * Lq + qi] : INFINITY;
+  const float lse2 = my_lse * kLog2e;          // p = exp2(s * log2(e) - lse2): one fma + v_exp_f32 per score
   float my_delta;
   {
     float of[NS];
@@ -644,40 +763,45 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
     my_delta = quad_sum(part);   // the four lanes of a query hold disjoint d-groups
     if (grp == 0 && fg == 0 && qi < Lq) delta[((long)b * H + h) * Lq + qi] = my_delta;
   }
-  int kcol[NT];
-  bool kok[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int d = nt * 16 + fr;
-    kok[nt] = d < D;
-    kcol[nt] = I::col(kok[nt] ? d : 0);
-  }
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  Stage<NS, NT> sg;
+  sg.init(tid, D, E);
+  for (int e = tid; e < 2 * (T::ROWS - D) * 64; e += kAttnThreads) {   // rows D.. of the transposed images: zero, once
+    const int buf = e / ((T::ROWS - D) * 64), r = e % ((T::ROWS - D) * 64);
+    Kt[buf][D + r / 64][r % 64] = 0.f;
+  }
+
   // key tiles of this wave group: grp, grp + NG, ... (a tile past Lk stages zeros with -inf bias and
   // contributes nothing, so both groups run the same number of iterations and barriers)
   const int iters = ((Lk + 63) / 64 + NG - 1) / NG;
-  typename I::Regs kr, vr;
+  float4 kr[Stage<NS, NT>::kVec], vr[Stage<NS, NT>::kVec];
   float br = 0.f;
-  I::fetch(kr, kb, E, D, grp * 64, Lk, tid);
-  I::fetch(vr, vb, E, D, grp * 64, Lk, tid);
-  if (tid < 64) br = key_bias(mb, grp * 64 + tid, Lk);
-  I::commit(Kimg[0], kr, D, tid);
-  I::commit(Vimg[0], vr, D, tid);
-  if (tid < 64) Bias[0][tid] = br;
+  {
+    const int key0 = grp * 64;
+    sg.fetch(kr, kb + (long)key0 * E, Lk - key0);
+    sg.fetch(vr, vb + (long)key0 * E, Lk - key0);
+    if (tid < 64) br = key_bias(mb, key0 + tid, Lk);
+    sg.commit_frag(&Kimg[0][0][0], kr);
+    sg.commit_t(&Kt[0][0][0], kr);
+    sg.commit_frag(&Vimg[0][0][0], vr);
+    if (tid < 64) Bias[0][tid] = br;
+  }
   __syncthreads();
   int cur = 0;
   for (int it = 0; it < iters; ++it) {
     const int key0 = (it * NG + grp) * 64;
     const bool more = it + 1 < iters;
     if (more) {
-      I::fetch(kr, kb, E, D, key0 + NG * 64, Lk, tid);
-      I::fetch(vr, vb, E, D, key0 + NG * 64, Lk, tid);
-      if (tid < 64) br = key_bias(mb, key0 + NG * 64 + tid, Lk);
+      const int nk = key0 + NG * 64;
+      sg.fetch(kr, kb + (long)nk * E, Lk - nk);
+      sg.fetch(vr, vb + (long)nk * E, Lk - nk);
+      if (tid < 64) br = key_bias(mb, nk + tid, Lk);
     }
     if (live) {
+      const bool masked_tile = mb != nullptr || key0 + 64 > Lk;   // uniform
       f32x4 ds[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -695,48 +819,59 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
           dp = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[s], gf[s], dp, 0, 0, 0);  // dP^T
         }
         }
-        const float4 bb = *reinterpret_cast<const float4 *>(&Bias[cur][t * 16 + fg * 4]);
-        const float bias4[4] = {bb.x, bb.y, bb.z, bb.w};
+        if (masked_tile) {
+          const float4 bb = *reinterpret_cast<const float4 *>(&Bias[cur][t * 16 + fg * 4]);
+          st[0] += bb.x; st[1] += bb.y; st[2] += bb.z; st[3] += bb.w;
+        }
+        if (drop) {   // the forward's mask: one hash per key pair (pair_hash)
+          const uint32_t pair0 = pair_row + (uint32_t)(key0 >> 1) + t * 8;
+          const uint32_t h0 = pair_hash(hkey, pair0), h1 = pair_hash(hkey, pair0 + 1);
+          dp[0] = (h0 & 0xffffu) >= thr ? dp[0] * inv_keep : 0.f;
+          dp[1] = (h0 >> 16) >= thr ? dp[1] * inv_keep : 0.f;
+          dp[2] = (h1 & 0xffffu) >= thr ? dp[2] * inv_keep : 0.f;
+          dp[3] = (h1 >> 16) >= thr ? dp[3] * inv_keep : 0.f;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float p = __expf(st[i] + bias4[i] - my_lse);
-          float dpe = dp[i];
-          if (drop) {
-            const int kk = key0 + t * 16 + fg * 4 + i;
-            const uint32_t idx = (uint32_t)((((long)b * H + h) * Lq + qi) * Lk + kk);
-            dpe = rng::keep(ctr, site, idx, p_drop) ? dpe * inv_keep : 0.f;
-          }
-          ds[t][i] = p * (dpe - my_delta);
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lse2));
+          ds[t][i] = p * (dp[i] - my_delta);
         }
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-      if constexpr (BF) {
+      f32x4 ka[NT];
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+      for (int nt = 0; nt < NT; ++nt) ka[nt] = *reinterpret_cast<const f32x4 *>(&Kt[cur][nt * 16 + fr][fg * 4]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f32x4 kn[NT];
+        if (t < 3) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            kn[nt] = *reinterpret_cast<const f32x4 *>(&Kt[cur][nt * 16 + fr][(t + 1) * 16 + fg * 4]);
+        }
+        if constexpr (BF) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            float a4[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) a4[s] = kok[nt] ? Kimg[cur][t * 16 + fg * 4 + s][kcol[nt]] : 0.f;
+            const float a4[4] = {ka[nt][0], ka[nt][1], ka[nt][2], ka[nt][3]};
             acc[nt] = mma_k16(a4, ds[t], acc[nt]);
           }
-      } else {
+        } else {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+          for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float *krow = Kimg[cur][t * 16 + fg * 4 + s];
+            for (int nt = 0; nt < NT; ++nt)
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][s], ds[t][s], acc[nt], 0, 0, 0);
+        }
+        if (t < 3) {
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const float a = kok[nt] ? krow[kcol[nt]] : 0.f;
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, ds[t][s], acc[nt], 0, 0, 0);
-          }
+          for (int nt = 0; nt < NT; ++nt) ka[nt] = kn[nt];
         }
       }
     }
     if (more) {
-      I::commit(Kimg[cur ^ 1], kr, D, tid);
-      I::commit(Vimg[cur ^ 1], vr, D, tid);
+      sg.commit_frag(&Kimg[cur ^ 1][0][0], kr);
+      sg.commit_t(&Kt[cur ^ 1][0][0], kr);
+      sg.commit_frag(&Vimg[cur ^ 1][0][0], vr);
       if (tid < 64) Bias[cur ^ 1][tid] = br;
     }
     __syncthreads();
@@ -812,7 +947,9 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
   const float *db = delta + ((long)b * H + h) * Lq;
   const bool drop = p_drop > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
-  const uint64_t ctr = (drop && rng_counter) ? *rng_counter : 0ull;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
   const int ki = k0 + fr;  // this lane's key (column)
   const float my_bias = key_bias(mask ? mask + (long)b * Lk : nullptr, ki, Lk);
 
@@ -889,10 +1026,10 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
         for (int i = 0; i < 4; ++i) {
           const float p = __expf(st[i] + my_bias - lq[i]);
           float keepf = 1.f;
-          if (drop) {
+          if (drop) {   // the forward's mask (pair_hash): this lane's key selects the field, its queries the pairs
             const int qq = qs + t * 16 + fg * 4 + i;
-            const uint32_t idx = (uint32_t)((((long)b * H + h) * Lq + qq) * Lk + ki);
-            keepf = rng::keep(ctr, site, idx, p_drop) ? inv_keep : 0.f;
+            const uint32_t hh = pair_hash(hkey, (uint32_t)(((long)b * H + h) * Lq + qq) * LkP + (uint32_t)(ki >> 1));
+            keepf = ((hh >> ((ki & 1) * 16)) & 0xffffu) >= thr ? inv_keep : 0.f;
           }
           pd[i] = p * keepf;
           ds[i] = p * (dp[i] * keepf - dq4[i]);
