@@ -749,7 +749,6 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
   float qf[NS], gf[NS];
   load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
   load_row_frag<NS>(gf, gb, E, qi, Lq, fg, D);
-  const DFrag<NS, BF> qF = make_frag<NS, BF>(qf), gF = make_frag<NS, BF>(gf);
   // rows beyond Lq: lse = +inf makes every probability exp(s - inf) = 0
   const float my_lse = qi < Lq ? lse[((long)b * H + h) * Lq + qi] : INFINITY;
   const float lse2 = my_lse * kLog2e;          // p = exp2(s * log2(e) - lse2): one fma + v_exp_f32 per score
@@ -763,6 +762,10 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
     my_delta = quad_sum(part);   // the four lanes of a query hold disjoint d-groups
     if (grp == 0 && fg == 0 && qi < Lq) delta[((long)b * H + h) * Lq + qi] = my_delta;
   }
+  // dP is only ever used as dropout(dP) = keep * dP / (1 - p): the scale rides on this lane's dO fragment
+#pragma unroll
+  for (int s = 0; s < NS; ++s) gf[s] *= inv_keep;
+  const DFrag<NS, BF> qF = make_frag<NS, BF>(qf), gF = make_frag<NS, BF>(gf);
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -826,10 +829,10 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
         if (drop) {   // the forward's mask: one hash per key pair (pair_hash)
           const uint32_t pair0 = pair_row + (uint32_t)(key0 >> 1) + t * 8;
           const uint32_t h0 = pair_hash(hkey, pair0), h1 = pair_hash(hkey, pair0 + 1);
-          dp[0] = (h0 & 0xffffu) >= thr ? dp[0] * inv_keep : 0.f;
-          dp[1] = (h0 >> 16) >= thr ? dp[1] * inv_keep : 0.f;
-          dp[2] = (h1 & 0xffffu) >= thr ? dp[2] * inv_keep : 0.f;
-          dp[3] = (h1 >> 16) >= thr ? dp[3] * inv_keep : 0.f;
+          dp[0] = (h0 & 0xffffu) >= thr ? dp[0] : 0.f;
+          dp[1] = (h0 >> 16) >= thr ? dp[1] : 0.f;
+          dp[2] = (h1 & 0xffffu) >= thr ? dp[2] : 0.f;
+          dp[3] = (h1 >> 16) >= thr ? dp[3] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
   using I = Img<NS>;
   __shared__ __attribute__((aligned(16))) float QimgG[NG][2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float GimgG[NG][2][64][I::LD];
-  __shared__ __attribute__((aligned(16))) float LseG[NG][2][64];
+  __shared__ __attribute__((aligned(16))) float LseG[NG][2][64];   // lse * log2(e)
   __shared__ __attribute__((aligned(16))) float DelG[NG][2][64];
   const int grp = threadIdx.x / kAttnThreads;
   float(*Qimg)[64][I::LD] = QimgG[grp];
@@ -952,18 +955,26 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
   const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
   const int ki = k0 + fr;  // this lane's key (column)
   const float my_bias = key_bias(mask ? mask + (long)b * Lk : nullptr, ki, Lk);
+  const bool wave_masked = __any(my_bias != 0.f);    // uniform: only then the bias is added at all
+  // the forward's dropout mask (pair_hash): this lane's key selects the pair column and the 16-bit field
+  const uint32_t pair_col = (uint32_t)(((long)b * H + h) * Lq) * LkP + (uint32_t)(ki >> 1);
+  const uint32_t field_shift = (uint32_t)(ki & 1) * 16u;
 
   float kf[NS], vf[NS];
   load_row_frag<NS>(kf, kb, E, ki, Lk, fg, D);
   load_row_frag<NS>(vf, vb, E, ki, Lk, fg, D);
+  // dP is only ever used as dropout(dP) = keep * dP / (1 - p): the scale rides on this lane's V fragment
+#pragma unroll
+  for (int s = 0; s < NS; ++s) vf[s] *= inv_keep;
   const DFrag<NS, BF> kF = make_frag<NS, BF>(kf), vF = make_frag<NS, BF>(vf);
+  // operands of the two transposed products: element n of rows q .. q+3.  n >= D reads a slot of the row padding that
+  // is zeroed once below and never written by a commit (no select per value)
+  constexpr int kZeroSlot = 4 * I::NSP;
   int ncol[NT];
-  bool nok[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = nt * 16 + fr;
-    nok[nt] = n < D;
-    ncol[nt] = I::col(nok[nt] ? n : 0);
+    ncol[nt] = n < D ? I::col(n) : kZeroSlot;
   }
   f32x4 ak[NT], av[NT];
 #pragma unroll
@@ -971,11 +982,17 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
     ak[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     av[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  for (int e = tid; e < 2 * 64; e += kAttnThreads) {
+    Qimg[e >> 6][e & 63][kZeroSlot] = 0.f;
+    Gimg[e >> 6][e & 63][kZeroSlot] = 0.f;
+  }
 
-  typename I::Regs qr, gr;
-  float sr = 0.f;  // threads 0..63: lse of row tid ; threads 64..127: delta of row tid-64
+  Stage<NS, NT> sg;
+  sg.init(tid, D, E);
+  float4 qr[Stage<NS, NT>::kVec], gr[Stage<NS, NT>::kVec];
+  float sr = 0.f;  // threads 0..63: lse * log2(e) of row tid ; threads 64..127: delta of row tid-64
   auto fetch_stats = [&](int qs) {
-    if (tid < 64) sr = (qs + tid < Lq) ? lb[qs + tid] : INFINITY;       // +inf -> probability 0
+    if (tid < 64) sr = (qs + tid < Lq) ? lb[qs + tid] * kLog2e : INFINITY;       // +inf -> probability 0
     else if (tid < 128) sr = (qs + tid - 64 < Lq) ? db[qs + tid - 64] : 0.f;
   };
   auto commit_stats = [&](int buf) {
@@ -985,23 +1002,28 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
   // query tiles of this wave group: grp, grp + NG, ... (a tile past Lq stages zeros with lse = +inf:
   // every probability is 0, so both groups run the same number of iterations and barriers)
   const int iters = ((Lq + 63) / 64 + NG - 1) / NG;
-  I::fetch(qr, qb, E, D, grp * 64, Lq, tid);
-  I::fetch(gr, gb, E, D, grp * 64, Lq, tid);
-  fetch_stats(grp * 64);
-  I::commit(Qimg[0], qr, D, tid);
-  I::commit(Gimg[0], gr, D, tid);
-  commit_stats(0);
+  {
+    const int qs = grp * 64;
+    sg.fetch(qr, qb + (long)qs * E, Lq - qs);
+    sg.fetch(gr, gb + (long)qs * E, Lq - qs);
+    fetch_stats(qs);
+    sg.commit_frag(&Qimg[0][0][0], qr);
+    sg.commit_frag(&Gimg[0][0][0], gr);
+    commit_stats(0);
+  }
   __syncthreads();
   int cur = 0;
   for (int it = 0; it < iters; ++it) {
     const int qs = (it * NG + grp) * 64;
     const bool more = it + 1 < iters;
     if (more) {
-      I::fetch(qr, qb, E, D, qs + NG * 64, Lq, tid);
-      I::fetch(gr, gb, E, D, qs + NG * 64, Lq, tid);
-      fetch_stats(qs + NG * 64);
+      const int nq = qs + NG * 64;
+      sg.fetch(qr, qb + (long)nq * E, Lq - nq);
+      sg.fetch(gr, gb + (long)nq * E, Lq - nq);
+      fetch_stats(nq);
     }
     if (live) {
+      const uint32_t pair_tile = pair_col + (uint32_t)(qs + fg * 4) * LkP;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         float qf[NS], gf[NS];
@@ -1010,66 +1032,76 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
         f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         if constexpr (BF) {
           st = mma_d<NS, BF>(make_frag<NS, BF>(qf), kF, st);   // S[q][key]
-          dp = mma_d<NS, BF>(make_frag<NS, BF>(gf), vF, dp);   // dP[q][key]
+          dp = mma_d<NS, BF>(make_frag<NS, BF>(gf), vF, dp);   // dP[q][key] / (1 - p)
         } else {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
           st = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], kf[s], st, 0, 0, 0);  // S[q][key]
-          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[s], vf[s], dp, 0, 0, 0);  // dP[q][key]
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[s], vf[s], dp, 0, 0, 0);  // dP[q][key] / (1 - p)
         }
         }
-        const float4 l4 = *reinterpret_cast<const float4 *>(&Lse[cur][t * 16 + fg * 4]);
-        const float4 d4 = *reinterpret_cast<const float4 *>(&Del[cur][t * 16 + fg * 4]);
-        const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
-        f32x4 pd, ds;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float p = __expf(st[i] + my_bias - lq[i]);
-          float keepf = 1.f;
-          if (drop) {   // the forward's mask (pair_hash): this lane's key selects the field, its queries the pairs
-            const int qq = qs + t * 16 + fg * 4 + i;
-            const uint32_t hh = pair_hash(hkey, (uint32_t)(((long)b * H + h) * Lq + qq) * LkP + (uint32_t)(ki >> 1));
-            keepf = ((hh >> ((ki & 1) * 16)) & 0xffffu) >= thr ? inv_keep : 0.f;
-          }
-          pd[i] = p * keepf;
-          ds[i] = p * (dp[i] * keepf - dq4[i]);
-        }
-        if constexpr (BF) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            float g4[4], q4[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              g4[s] = nok[nt] ? Gimg[cur][t * 16 + fg * 4 + s][ncol[nt]] : 0.f;
-              q4[s] = nok[nt] ? Qimg[cur][t * 16 + fg * 4 + s][ncol[nt]] : 0.f;
-            }
-            av[nt] = mma_k16(g4, pd, av[nt]);
-            ak[nt] = mma_k16(q4, ds, ak[nt]);
-          }
-        } else {
+        // operands of the transposed products for these 16 queries: in flight under the softmax arithmetic
+        float ga[4][NT], qa[4][NT];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const float *grow = Gimg[cur][t * 16 + fg * 4 + s];
           const float *qrow = Qimg[cur][t * 16 + fg * 4 + s];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const float ag = nok[nt] ? grow[ncol[nt]] : 0.f;
-            const float aq = nok[nt] ? qrow[ncol[nt]] : 0.f;
-            av[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ag, pd[s], av[nt], 0, 0, 0);
-            ak[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, ds[s], ak[nt], 0, 0, 0);
+            ga[s][nt] = grow[ncol[nt]];
+            qa[s][nt] = qrow[ncol[nt]];
           }
         }
+        const float4 l4 = *reinterpret_cast<const float4 *>(&Lse[cur][t * 16 + fg * 4]);
+        const float4 d4 = *reinterpret_cast<const float4 *>(&Del[cur][t * 16 + fg * 4]);
+        const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+        if (wave_masked) {
+          st[0] += my_bias; st[1] += my_bias; st[2] += my_bias; st[3] += my_bias;
+        }
+        f32x4 pd, ds;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pd[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lq[i]));
+        if (drop) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t hh = pair_hash(hkey, pair_tile + (uint32_t)(t * 16 + i) * LkP);
+            const bool keep = ((hh >> field_shift) & 0xffffu) >= thr;
+            ds[i] = pd[i] * ((keep ? dp[i] : 0.f) - dq4[i]);
+            pd[i] = keep ? pd[i] : 0.f;                      // the 1/(1-p) of dV is applied once, at the end
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ds[i] = pd[i] * (dp[i] - dq4[i]);
+        }
+        if constexpr (BF) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float g4[4] = {ga[0][nt], ga[1][nt], ga[2][nt], ga[3][nt]};
+            const float q4[4] = {qa[0][nt], qa[1][nt], qa[2][nt], qa[3][nt]};
+            av[nt] = mma_k16(g4, pd, av[nt]);
+            ak[nt] = mma_k16(q4, ds, ak[nt]);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              av[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][nt], pd[s], av[nt], 0, 0, 0);
+              ak[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s][nt], ds[s], ak[nt], 0, 0, 0);
+            }
         }
       }
     }
     if (more) {
-      I::commit(Qimg[cur ^ 1], qr, D, tid);
-      I::commit(Gimg[cur ^ 1], gr, D, tid);
+      sg.commit_frag(&Qimg[cur ^ 1][0][0], qr);
+      sg.commit_frag(&Gimg[cur ^ 1][0][0], gr);
       commit_stats(cur ^ 1);
     }
     __syncthreads();
     cur ^= 1;
   }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) av[nt] *= inv_keep;
   if constexpr (NG == 2) {
     float *xch = &QimgG[0][0][0][0];
     static_assert(sizeof(float) * 256 * 8 * NT <= sizeof(QimgG[0]), "exchange area");
