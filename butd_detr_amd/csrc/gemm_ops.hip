@@ -650,6 +650,70 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
     const int c4 = (tid % kRQ) * 4, rphase = tid / kRQ;
     const bool active = rphase < kRowPhases;
     const int n = n0 + c4;
+    // Lean path (uniform per workgroup): a whole tile inside the matrix, 16-byte aligned rows, no output dropout, no
+    // second destination.  fp32 matrix and vector instructions share their issue slots on this part
+    // (scratch/ubench/mfma_valu.hip), so every instruction of this epilogue is paid in matrix time: per float4 it is
+    // one ds_read_b128, 4 fma (+4 max, +8 for the column statistics, +4 for an accumulating store) and one store.
+    if (m0 + TM <= pM && n0 + TN <= pN && !drop && P.c2 == nullptr && (ldc & 3) == 0 &&
+        (((uintptr_t)cptr | (uintptr_t)P.bias) & 15) == 0) {
+      double *const col_sum = P.col_sum, *const col_sumsq = P.col_sumsq;
+      const bool c_add = P.c_add != 0;
+      const bool streaming = !c_add && (long)pM * pN >= (16L << 20);   // >= 64 MB
+      f32x4 bs = {0.f, 0.f, 0.f, 0.f};
+      if (P.bias && slice == 0 && active) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(P.bias + n);   // n % 4 == 0; bias rows are 16-byte aligned
+        bs = b4 * scale;
+      }
+      f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+      auto rows = [&](auto relu_t, auto stats_t, auto add_t) {
+        if (!active) return;
+        float *dst = cptr + (long)(m0 + rphase) * ldc + n;
+        const long step = (long)kRowPhases * ldc;
+#pragma unroll 4
+        for (int row = rphase; row < TM; row += kRowPhases, dst += step) {
+          f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[row * kLdC + c4]) * scale + bs;
+          if constexpr (decltype(relu_t)::value) {
+            v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+          if constexpr (decltype(stats_t)::value) {
+            cs += v;
+            cq += v * v;
+          }
+          if constexpr (decltype(add_t)::value) v += *reinterpret_cast<const f32x4 *>(dst);
+          store_c4(dst, make_float4(v[0], v[1], v[2], v[3]), streaming);
+        }
+      };
+      typedef std::true_type T_;
+      typedef std::false_type F_;
+      switch ((relu ? 1 : 0) | (col_sum ? 2 : 0) | (c_add ? 4 : 0)) {
+        case 0: rows(F_(), F_(), F_()); break;
+        case 1: rows(T_(), F_(), F_()); break;
+        case 2: rows(F_(), T_(), F_()); break;
+        case 3: rows(T_(), T_(), F_()); break;
+        case 4: rows(F_(), F_(), T_()); break;
+        case 5: rows(T_(), F_(), T_()); break;
+        case 6: rows(F_(), T_(), T_()); break;
+        default: rows(T_(), T_(), T_()); break;
+      }
+      if (col_sum) {
+        float *red = lds;
+        __syncthreads();
+        if (active) {
+          *reinterpret_cast<f32x4 *>(&red[(0 * kRowPhases + rphase) * TN + c4]) = cs;
+          *reinterpret_cast<f32x4 *>(&red[(1 * kRowPhases + rphase) * TN + c4]) = cq;
+        }
+        __syncthreads();
+        if (tid < 2 * TN) {
+          const int which = tid / TN, col = tid % TN;
+          double s = 0.0;
+#pragma unroll
+          for (int r = 0; r < kRowPhases; ++r) s += (double)red[(which * kRowPhases + r) * TN + col];
+          const long slot_off = P.col_slots > 1 ? (long)(blockIdx.x & (P.col_slots - 1)) * P.col_slot_stride : 0;
+          atomicAdd((which ? col_sumsq : col_sum) + slot_off + n0 + col, s);
+        }
+      }
+      return;
+    }
     float bv[4] = {0.f, 0.f, 0.f, 0.f};
     if (P.bias && slice == 0 && active) {
 #pragma unroll
