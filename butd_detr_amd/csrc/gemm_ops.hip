@@ -56,6 +56,14 @@ __device__ inline f32x4 ldg4(const float *p) {
   return *reinterpret_cast<global_f4_ptr>(reinterpret_cast<uintptr_t>(p));
 }
 
+// uniform base (scalar registers) + 32-bit BYTE offset per lane: the "saddr + voffset" form of global_load -- no 64-bit
+// vector address arithmetic in front of the load
+typedef const __attribute__((address_space(1))) char *global_byte_ptr;
+__device__ inline f32x4 ldg4_at(const float *base, uint32_t byte_off) {
+  const global_byte_ptr g = reinterpret_cast<global_byte_ptr>(reinterpret_cast<uintptr_t>(base));
+  return *reinterpret_cast<global_f4_ptr>(g + byte_off);
+}
+
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it waits for the
 // global loads of the slabs still in flight
 __device__ inline void lds_barrier() {
@@ -287,18 +295,28 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
       // per-thread staging plan: float4 u of operand X sits at (row, k) of the slab; rows outside the
       // matrix read row 0 of the operand instead (every load stays an unconditional global_load) and are
       // zeroed at commit time
-      const float *pa[kSubA], *pb[kSubB];
+      // (addresses: ONE uniform base per operand and tile -- scalar registers -- plus a 32-bit element offset per
+      // float4: the loads take the "scalar base + vector offset" form and neither the plan nor the K loop does
+      // 64-bit vector arithmetic; tile rows x leading dimension stays far below 2^31 elements)
+      const float *const abase = a_kc ? P.a + (long)m0 * P.lda_m + kbeg : P.a + (long)kbeg * P.lda_k + m0;
+      // (a column tile that holds nothing but the virtual ones-row starts AT row N: its clamped loads must still
+      //  land inside the operand, so the base row is min(n0, N - 1); tiles with real rows have n0 < N)
+      const int n0c = min(n0, b_kc ? P.N - 1 : P.N - 4);   // (row-contiguous operands: a float4 spans four rows)
+      const float *const bbase = b_kc ? P.b + (long)n0c * P.ldb_n + kbeg : P.b + (long)kbeg * P.ldb_k + n0c;
+      const bool edge = m0 + TM > P.M || n0 + TN > P.N;   // uniform: only then rows are clamped / zeroed
+      uint32_t pa[kSubA], pb[kSubB];
       int a_lds[kSubA], b_lds[kSubB], a_k[kSubA], b_k[kSubB], ones_e[kSubB];
       bool a_ok[kSubA], b_ok[kSubB];
       float4 bsc[kSubB], bsh[kSubB];
+      const int lda_m = (int)P.lda_m, lda_k = (int)P.lda_k, ldb_n = (int)P.ldb_n, ldb_k = (int)P.ldb_k;
 #pragma unroll
       for (int u = 0; u < kSubA; ++u) {
         int row, k;
         slab_pos<TM>(a_kc, tid + u * kThreads, row, k);
         a_k[u] = k;
-        a_ok[u] = m0 + row < P.M;
-        const long r = a_ok[u] ? m0 + row : 0;
-        pa[u] = a_kc ? P.a + r * P.lda_m + kbeg + k : P.a + (long)(kbeg + k) * P.lda_k + r;
+        a_ok[u] = !edge || m0 + row < P.M;
+        const int r = a_ok[u] ? row : 0;   // rows outside the matrix read the tile's first row instead
+        pa[u] = 4u * (uint32_t)(a_kc ? r * lda_m + k : k * lda_k + r);   // bytes
         a_lds[u] = BF ? row * kLdH + k : (a_kc ? row * kLd + k : k * kLdTA + row);
       }
 #pragma unroll
@@ -306,9 +324,9 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
         int row, k;
         slab_pos<TN>(b_kc, tid + u * kThreads, row, k);
         b_k[u] = k;
-        b_ok[u] = n0 + row < P.N;
-        const long r = b_ok[u] ? n0 + row : 0;
-        pb[u] = b_kc ? P.b + r * P.ldb_n + kbeg + k : P.b + (long)(kbeg + k) * P.ldb_k + r;
+        b_ok[u] = !edge || n0 + row < P.N;
+        const int r = b_ok[u] ? row : 0;
+        pb[u] = 4u * (uint32_t)(b_kc ? r * ldb_n + k : k * ldb_k + r);
         b_lds[u] = BF ? row * kLdH + k : (b_kc ? row * kLd + k : k * kLdTB + row);
         // virtual ones-row of B (row index N): which of this float4's elements is it, if any
         ones_e[u] = !f_ones ? -1 : (b_kc ? (n0 + row == P.N ? 4 : -1)
@@ -358,15 +376,15 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
 #pragma unroll
         for (int u = 0; u < kSubA; ++u) {
           f32x4 v;
-          if constexpr (!decltype(kind)::ragged) v = ldg4(pa[u] + slab * sa);
-          else v = (slab * kBK + a_k[u] < krange) ? ldg4(pa[u] + slab * sa) : zero_v;
+          if constexpr (!decltype(kind)::ragged) v = ldg4_at(abase + slab * sa, pa[u]);
+          else v = (slab * kBK + a_k[u] < krange) ? ldg4_at(abase + slab * sa, pa[u]) : zero_v;
           if constexpr (decltype(set)::value == 0) ra0[u] = v; else ra1[u] = v;
         }
 #pragma unroll
         for (int u = 0; u < kSubB; ++u) {
           f32x4 v;
-          if constexpr (!decltype(kind)::ragged) v = ldg4(pb[u] + slab * sb);
-          else v = (slab * kBK + b_k[u] < krange) ? ldg4(pb[u] + slab * sb) : zero_v;
+          if constexpr (!decltype(kind)::ragged) v = ldg4_at(bbase + slab * sb, pb[u]);
+          else v = (slab * kBK + b_k[u] < krange) ? ldg4_at(bbase + slab * sb, pb[u]) : zero_v;
           if constexpr (decltype(set)::value == 0) rb0[u] = v; else rb1[u] = v;
         }
       };
@@ -392,7 +410,11 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
           if constexpr (decltype(kind)::ragged) in = kslab0 + a_k[u] < krange;
           const bool live = a_ok[u] && in;
           float4 va;
-          if constexpr (decltype(set)::value == 0) va = live ? f4(ra0[u]) : zero4; else va = live ? f4(ra1[u]) : zero4;
+          if constexpr (decltype(set)::value == 0) va = f4(ra0[u]); else va = f4(ra1[u]);
+          if (decltype(kind)::ragged || edge) {   // (uniform condition; element-wise: a select between two float4
+            va.x = live ? va.x : 0.f; va.y = live ? va.y : 0.f;   //  STRUCTS is a select between their addresses and
+            va.z = live ? va.z : 0.f; va.w = live ? va.w : 0.f;   //  sends both to scratch memory)
+          }
           if constexpr (FX) {
             if (a_aff && live) {
               float4 sc, sh;
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
               va.z = fmaxf(va.z * sc.z + sh.z, 0.f); va.w = fmaxf(va.w * sc.w + sh.w, 0.f);
             }
             if (f_adrop && live)
-              va = drop4(va, a_key, (uint32_t)((pa[u] - P.a) + slab * sa), P.a_drop_p, a_inv);
+              va = drop4(va, a_key, (uint32_t)((abase - P.a) + slab * sa) + (pa[u] >> 2), P.a_drop_p, a_inv);
           }
           put(at, a_lds[u], va, a_kc_t);
         }
@@ -418,14 +440,18 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
           if constexpr (decltype(kind)::ragged) in = kslab0 + b_k[u] < krange;
           const bool live = b_ok[u] && in;
           float4 vb;
-          if constexpr (decltype(set)::value == 0) vb = live ? f4(rb0[u]) : zero4; else vb = live ? f4(rb1[u]) : zero4;
+          if constexpr (decltype(set)::value == 0) vb = f4(rb0[u]); else vb = f4(rb1[u]);
+          if (decltype(kind)::ragged || edge) {
+            vb.x = live ? vb.x : 0.f; vb.y = live ? vb.y : 0.f;
+            vb.z = live ? vb.z : 0.f; vb.w = live ? vb.w : 0.f;
+          }
           if constexpr (FX) {
             if (b_aff && live) {
               vb.x = fmaxf(vb.x * bsc[u].x + bsh[u].x, 0.f); vb.y = fmaxf(vb.y * bsc[u].y + bsh[u].y, 0.f);
               vb.z = fmaxf(vb.z * bsc[u].z + bsh[u].z, 0.f); vb.w = fmaxf(vb.w * bsc[u].w + bsh[u].w, 0.f);
             }
             if (f_bdrop && live)
-              vb = drop4(vb, b_key, (uint32_t)((pb[u] - P.b) + slab * sb), P.b_drop_p, b_inv);
+              vb = drop4(vb, b_key, (uint32_t)((bbase - P.b) + slab * sb) + (pb[u] >> 2), P.b_drop_p, b_inv);
             if (in) {   // the ones-row is 1 for every k inside the slice
               if (ones_e[u] == 4) vb = make_float4(1.f, 1.f, 1.f, 1.f);
               else if (ones_e[u] == 0) vb.x = 1.f;
@@ -833,7 +859,7 @@ struct TileCfg {
 // the menu (every entry is instantiated for FAST / PIPE 2, FAST / PIPE 0 and generic)
 constexpr TileCfg kMenu[] = {{32, 32}, {64, 64}, {32, 96}, {64, 96}, {96, 32}, {128, 64}, {128, 96}};
 constexpr int kMenuSize = sizeof(kMenu) / sizeof(kMenu[0]);
-constexpr int kCfg32x32 = 0, kCfg64x64 = 1, kCfg32x96 = 2, kCfg64x96 = 3, kCfg96x32 = 4;
+constexpr int kCfg32x32 = 0, kCfg64x64 = 1, kCfg32x96 = 2, kCfg64x96 = 3, kCfg96x32 = 4, kCfg128x64 = 5;
 
 int g_forced_cfg = -1;   // butd_gemm_set_tile(): tuning hook
 
@@ -877,7 +903,8 @@ long fill_batch(GemmBatch &batch, const butd_gemm_problem *problems, const int *
 //    attention block's input+weight gradient pair: 43 us vs 50 us with round 1's 32 x 32); 32 x 32 when the
 //    launch is a decoder-sized one (<= 2048 rows); 64 x 64 for the set-abstraction ones, which contract
 //    10^5..10^6 rows per slice;
-//  * tall plain-store problems (set-abstraction forward, M >= 32768): 96 x 32, one slab ahead;
+//  * tall plain-store problems (set-abstraction forward, M >= 32768): 128 x 64, one slab ahead (with the lean
+//    epilogue the fixed cost per tile matters more than the number of workgroups: 294 vs 321 us on 1M x 128 x 64);
 //  * projections / FFN / input gradients of the attention stack (640..8192 rows, N and K <= 864): by the
 //    amount of work, counted in 32 x 32 tiles: small launches want many small workgroups (latency-bound: a
 //    2048 x 288 x 288 product is 10 us on 32 x 32, 13 us on 64 x 64), large ones want the 96-wide tiles that
@@ -908,7 +935,7 @@ void choose(const butd_gemm_problem *problems, const int *index, int count, bool
   }
   if (max_m_plain >= 32768) {
     pipe = 0;
-    cfg = kCfg96x32;
+    cfg = kCfg128x64;
     return;
   }
   if (tiles32 <= 1200 || (count > 1 && tiles32 <= 3000 && max_m_plain > 2048)) {
