@@ -434,7 +434,7 @@ struct Stage {
 #pragma unroll
     for (int j = 0; j < kVec; ++j) {
       const int f = tid + j * kAttnThreads;
-      const int r = f / vpr, c4 = f - r * vpr;
+      const int r = vpr == NS ? f / NS : f / vpr, c4 = f - r * vpr;   // (a constant divisor in the usual case)
       const bool ok = r < 64;
       row[j] = ok ? r : 64;
       goff[j] = ok ? (int)(r * E) + c4 * 4 : 0;
@@ -534,9 +534,9 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
   Stage<NS, NT> sg;
   sg.init(tid, D, E);
   // rows D .. ROWS-1 of the transposed images: zero, once
-  for (int e = tid; e < 2 * (T::ROWS - D) * 64; e += kAttnThreads) {
-    const int buf = e / ((T::ROWS - D) * 64), r = e % ((T::ROWS - D) * 64);
-    Vt[buf][D + r / 64][r % 64] = 0.f;
+  for (int r = D + (tid >> 6); r < T::ROWS; r += kAttnThreads / 64) {
+    Vt[0][r][tid & 63] = 0.f;
+    Vt[1][r][tid & 63] = 0.f;
   }
 
   // key tiles of this wave group: grp, grp + NG, ... (a tile past Lk stages zeros with -inf bias and
@@ -772,9 +772,9 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
 
   Stage<NS, NT> sg;
   sg.init(tid, D, E);
-  for (int e = tid; e < 2 * (T::ROWS - D) * 64; e += kAttnThreads) {   // rows D.. of the transposed images: zero, once
-    const int buf = e / ((T::ROWS - D) * 64), r = e % ((T::ROWS - D) * 64);
-    Kt[buf][D + r / 64][r % 64] = 0.f;
+  for (int r = D + (tid >> 6); r < T::ROWS; r += kAttnThreads / 64) {   // rows D.. of the transposed images: zero, once
+    Kt[0][r][tid & 63] = 0.f;
+    Kt[1][r][tid & 63] = 0.f;
   }
 
   // key tiles of this wave group: grp, grp + NG, ... (a tile past Lk stages zeros with -inf bias and
