@@ -90,6 +90,7 @@ SA_SYMBOLS = {
 OPTIM_SYMBOLS = {
     "butd_adamw_flat": (_c_int, [_P] * 4 + [_c_long, _c_long] + [_c_float] * 5 + [_P, _P, _P, _P]),
     "butd_gather_segments": (_c_int, [_c_int, _P, _P, _P, _c_long]),
+    "butd_sum_tensors": (_c_int, [_c_int, _P, _c_long, _P, _P]),
 }
 
 MLP_MAX_SEGMENTS = 8  # BUTD_MLP_MAX_SEGMENTS

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import attention_blocks, text_stream
+from .fan_out import fan_out
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer
 from .modules import (ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule,
@@ -275,6 +276,10 @@ class BeaUTyDETR(nn.Module):
                                           end_points=end_points, prefix="proposal_")
         base_xyz, base_size = center.detach().clone(), size.detach().clone()
 
+        # the encoder outputs feed all decoder layers: one gradient sum per stream (fan_out.py)
+        n_dec = len(self.decoder)
+        vis_l, text_l = fan_out(vis, n_dec), fan_out(text_feats, n_dec)
+        det_l = fan_out(detected_feats if self.butd else None, n_dec)
         for i, (layer, head) in enumerate(zip(self.decoder, self.prediction_heads)):
             prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
             if self.self_position_embedding == "none":
@@ -285,8 +290,8 @@ class BeaUTyDETR(nn.Module):
                 query_pos = torch.cat([base_xyz, base_size], -1)
             else:
                 raise NotImplementedError
-            query = layer(query, vis, text_feats, query_pos, None, text_padding_mask,
-                          detected_feats=detected_feats if self.butd else None,
+            query = layer(query, vis_l[i], text_l[i], query_pos, None, text_padding_mask,
+                          detected_feats=det_l[i],
                           detected_mask=detected_mask if self.butd else None)
             if self.contrastive_align_loss:
                 proj_inputs.append((prefix, query))

@@ -87,3 +87,41 @@ extern "C" int butd_adamw_flat(float *p, const float *g, float *m, float *v, lon
                      begin, end, lr, beta1, beta2, eps, weight_decay, step, grad_scale, hyper);
   return (int)hipGetLastError();
 }
+
+
+// out = s0 + s1 + ... (n <= 8 tensors of `numel` floats): the gradient fan-in of a tensor that feeds several blocks
+// (autograd sums the incoming gradients pairwise: one launch and one extra pass per addend).
+namespace {
+struct SumSrc { const float *p[8]; };
+__global__ __launch_bounds__(256) void sum_n_kernel(SumSrc src, int n, long n4, long numel, float *__restrict__ out) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4 *>(src.p[0])[i];
+    for (int k = 1; k < n; ++k) {
+      const float4 b = reinterpret_cast<const float4 *>(src.p[k])[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4 *>(out)[i] = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (numel & 3)) {   // tail
+    const long i = (numel & ~3L) + threadIdx.x;
+    float a = src.p[0][i];
+    for (int k = 1; k < n; ++k) a += src.p[k][i];
+    out[i] = a;
+  }
+}
+}  // namespace
+
+extern "C" int butd_sum_tensors(int n, const float *const *srcs, long numel, float *out, butd_stream_t stream) {
+  if (n < 1 || n > 8 || numel < 0) return (int)hipErrorInvalidValue;
+  if (numel == 0) return 0;
+  SumSrc s;
+  for (int k = 0; k < 8; ++k) s.p[k] = srcs[k < n ? k : 0];
+  for (int k = 0; k < n; ++k)
+    if (((uintptr_t)s.p[k] | (uintptr_t)out) & 15) return (int)hipErrorInvalidValue;   // float4 path: 16-byte aligned
+  const long n4 = numel >> 2;
+  long blocks = (n4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sum_n_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, n, n4, numel, out);
+  return (int)hipGetLastError();
+}

@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from . import attention_blocks as ab
+from .fan_out import fan_out
 
 
 def _get_clones(module, n):
@@ -238,10 +239,13 @@ class BiEncoder(nn.Module):
 
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
                 end_points={}, detected_feats=None, detected_mask=None):
+        # the position embedding and the box stream feed every layer: one gradient sum each (fan_out.py)
+        pos_l = fan_out(pos_feats, self.num_layers)
+        det_l = fan_out(detected_feats, self.num_layers)
         for i, layer in enumerate(self.layers):
-            vis_feats, text_feats = layer(vis_feats, pos_feats, padding_mask, text_feats,
+            vis_feats, text_feats = layer(vis_feats, pos_l[i], padding_mask, text_feats,
                                           text_padding_mask, end_points,
-                                          detected_feats=detected_feats,
+                                          detected_feats=det_l[i],
                                           detected_mask=detected_mask)
             if "lv_attention" in end_points:
                 end_points["lv_attention%d" % i] = end_points["lv_attention"]
@@ -289,14 +293,16 @@ class BiDecoderLayer(nn.Module):
         else:
             query_pos = None       # the reference adds zeros_like(query) (:364-365)
 
-        query = ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=query_pos,
+        # the four blocks' position gradients arrive together and are summed in one pass (fan_out.py)
+        pos_s, pos_l, pos_d, pos_v = fan_out(query_pos, 4)
+        query = ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s,
                          key_padding_mask=padding_mask)
-        query = ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=query_pos,
+        query = ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l,
                          memory=lang_feats, key_padding_mask=text_key_padding_mask)
         if detected_feats is not None:
-            query = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=query_pos,
+            query = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d,
                              memory=detected_feats, key_padding_mask=detected_mask)
-        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=query_pos,
+        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v,
                          memory=vis_feats, key_padding_mask=None)
         query = ab.ffn_block(self.ffn, self.norm2, query)
         return query.contiguous()

@@ -1,0 +1,57 @@
+"""Gradient fan-in of tensors that feed several blocks.
+
+The reference hands one tensor to many consumers: a decoder layer's ``query_pos`` to its four attention blocks
+(encoder_decoder_layers.py:356-404), the encoder's visual / text / box outputs to all six decoder layers
+(bdetr.py:277-299), the visual position embedding to every encoder layer.  Autograd sums the n incoming gradients
+pairwise -- n - 1 launches that each re-read the running sum.  ``fan_out(t, n)`` returns n aliases of ``t`` whose
+gradients arrive together and are summed by ONE kernel (``butd_sum_tensors``, include/butd_optim.h).
+Values and gradients are those of using ``t`` n times (the sum is evaluated left to right, as autograd's).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _hiplib
+
+
+def _sum(grads):
+    live = [g for g in grads if g is not None]
+    if not live:
+        return None
+    if len(live) == 1:
+        return live[0]
+    live = [g.contiguous() for g in live]
+    first = live[0]
+    if (not first.is_cuda or first.dtype != torch.float32 or len(live) > 8
+            or any(g.shape != first.shape or g.dtype != first.dtype or (g.data_ptr() & 15) for g in live)):
+        out = live[0] + live[1]
+        for g in live[2:]:
+            out = out + g
+        return out
+    out = torch.empty_like(first)
+    ptrs = (ctypes.c_void_p * len(live))(*[g.data_ptr() for g in live])
+    with torch.cuda.device(first.device):
+        err = _hiplib.load().butd_sum_tensors(len(live), ptrs, first.numel(), out.data_ptr(),
+                                              torch.cuda.current_stream(first.device).cuda_stream)
+    _hiplib.check(err, "butd_sum_tensors")
+    return out
+
+
+class _FanOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, n):
+        return tuple(t.view_as(t) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        return _sum(grads), None
+
+
+def fan_out(t, n):
+    """n aliases of ``t`` (n >= 1); plain repetition when there is nothing to gain (no gradient, CPU, n < 3, or
+    BUTD_FAN_OUT=0: debug hook)."""
+    if (t is None or n < 3 or not t.is_cuda or not t.requires_grad or not torch.is_grad_enabled()
+            or os.environ.get("BUTD_FAN_OUT", "1") == "0"):
+        return (t,) * n
+    return _FanOut.apply(t, n)

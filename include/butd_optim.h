@@ -33,6 +33,13 @@ int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, lo
  * (n + 1)], a workgroup copies BUTD_GATHER_CHUNK consecutive floats of one segment. */
 #define BUTD_GATHER_CHUNK 4096
 int butd_gather_segments(int n, const int64_t *table, float *dst, butd_stream_t stream, long total_blocks);
+/* out[0:numel) = srcs[0] + ... + srcs[n-1] (1 <= n <= 8 device pointers in a HOST array, 16-byte aligned): the summed
+ * gradient of a tensor that feeds several blocks -- what torch's autograd engine does with n-1 pairwise adds
+ * (torch/csrc/autograd/input_buffer.cpp) in one pass.  Used by butd_detr_amd/fan_out.py for the tensors the
+ * reference hands to several layers (query_pos: encoder_decoder_layers.py:356-404; the encoder outputs:
+ * bdetr.py:277-299). */
+int butd_sum_tensors(int n, const float *const *srcs, long numel, float *out, butd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
