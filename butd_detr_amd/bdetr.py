@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import attention_blocks, text_stream
-from .fan_out import fan_out
+from .fan_out import fan_out, unstack
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer
 from .modules import (ClsAgnosticPredictHead, GeneralSamplingModule, PointsObjClsModule,
@@ -293,13 +293,15 @@ class BeaUTyDETR(nn.Module):
             query = layer(query, vis_l[i], text_l[i], query_pos, None, text_padding_mask,
                           detected_feats=det_l[i],
                           detected_mask=detected_mask if self.butd else None)
+            # the layer output feeds the next layer, its head and the contrastive projection
+            query, q_head, q_proj = fan_out(query, 3)
             if self.contrastive_align_loss:
-                proj_inputs.append((prefix, query))
-            center, size = head(query.transpose(1, 2), base_xyz=cluster_xyz,
-                                end_points=end_points, prefix=prefix, features_pm=query)
+                proj_inputs.append((prefix, q_proj))
+            center, size = head(q_head.transpose(1, 2), base_xyz=cluster_xyz,
+                                end_points=end_points, prefix=prefix, features_pm=q_head)
             base_xyz, base_size = center.detach().clone(), size.detach().clone()
         if proj_inputs:
-            proj = self._normalized_proj(torch.stack([q for _, q in proj_inputs]))
+            proj = unstack(self._normalized_proj(torch.stack([q for _, q in proj_inputs])))
             for i, (prefix, _) in enumerate(proj_inputs):
                 end_points[f"{prefix}proj_queries"] = proj[i]
         return end_points

@@ -55,3 +55,28 @@ def fan_out(t, n):
             or os.environ.get("BUTD_FAN_OUT", "1") == "0"):
         return (t,) * n
     return _FanOut.apply(t, n)
+
+
+class _Unstack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        ctx.shape, ctx.dtype, ctx.device = t.shape, t.dtype, t.device
+        return tuple(t[i] for i in range(t.shape[0]))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if all(g is not None for g in grads):
+            return torch.stack(grads)                    # one pass instead of (zero-fill + copy + add) per slice
+        out = torch.zeros(ctx.shape, dtype=ctx.dtype, device=ctx.device)
+        for i, g in enumerate(grads):
+            if g is not None:
+                out[i].copy_(g)
+        return out
+
+
+def unstack(t):
+    """The slices ``t[0], t[1], ...`` whose gradients are put back together by one ``stack`` (autograd's
+    ``select_backward`` writes each slice's gradient into its own zero tensor of the full shape and adds them up)."""
+    if not t.requires_grad or not torch.is_grad_enabled() or os.environ.get("BUTD_FAN_OUT", "1") == "0":
+        return tuple(t[i] for i in range(t.shape[0]))
+    return _Unstack.apply(t)

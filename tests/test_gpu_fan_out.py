@@ -45,3 +45,20 @@ def test_sum_kernel_rejects_bad_arguments():
     assert lib.butd_sum_tensors(9, ptrs, 16, x.data_ptr(), s) != 0
     assert lib.butd_sum_tensors(1, (ctypes.c_void_p * 1)(x.data_ptr() + 4), 8, x.data_ptr(), s) != 0   # unaligned
     assert lib.butd_sum_tensors(1, ptrs, 0, x.data_ptr(), s) == 0
+
+
+def test_unstack_matches_indexing():
+    from butd_detr_amd.fan_out import unstack
+    torch.manual_seed(0)
+    x = torch.randn(7, 8, 256, 64, device="cuda", requires_grad=True)
+    y = x.detach().clone().requires_grad_(True)
+    w = torch.randn(7, 8, 256, 64, device="cuda")
+    parts = unstack(x * 1.0)
+    assert len(parts) == 7 and all(torch.equal(p, x[i]) for i, p in enumerate(parts))
+    torch.stack([parts[i] for i in (1, 6, 0, 2, 3, 4, 5)]).mul(w).sum().backward()      # re-stacked in another order
+    torch.stack([(y * 1.0)[i] for i in (1, 6, 0, 2, 3, 4, 5)]).mul(w).sum().backward()
+    torch.testing.assert_close(x.grad, y.grad, rtol=0, atol=0)
+    z = torch.randn(3, 5, device="cuda", requires_grad=True)
+    p = unstack(z * 1.0)
+    p[1].sum().backward()                                                              # unused slices: zero gradient
+    assert torch.equal(z.grad, torch.tensor([[0.0] * 5, [1.0] * 5, [0.0] * 5], device="cuda"))
