@@ -67,6 +67,8 @@ ATTENTION_SYMBOLS = {
                                 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_fwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 3
                                        + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+    "butd_add_dropout_layernorm_fwd_pos": (_c_int, [_c_int, _c_int] + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 3
+                                           + [_c_float, _c_u32, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_bwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 10
                                        + [_c_float, _c_u32, _c_void_p, _c_void_p]),
 }

@@ -87,18 +87,21 @@ def attention_block(attn, dropout, norm, *, residual, query, key, value, key_pad
     return norm(residual + dropout(out))
 
 
-def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None):
+def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None):
     """The block in the two shapes the model uses it (every call site of
     encoder_decoder_layers.py:87-122,149-155,179-185,356-404):
         memory is None:  self-attention,  query = key = x (+ pos), value = x
         otherwise:       cross-attention, query = x (+ pos), key = value = memory
-    with residual x.  Knowing the structure lets the fused backward return summed gradients."""
+    with residual x.  Knowing the structure lets the fused backward return summed gradients.
+    ``next_pos`` / ``xq_pre``: a chain of blocks that share a position embedding asks each block for
+    ``(y, y + next_pos)`` and hands the second to the next block as its ready-made query input."""
     if _BACKEND == "hip" and x.is_cuda:
         from . import fused_attention
-        return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask)
+        return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask, xq_pre, next_pos)
     q = x if pos is None else x + pos
     k, v = (q, x) if memory is None else (memory, memory)
-    return norm(x + dropout(_mha_torch(attn, q, k, v, key_padding_mask)))
+    y = norm(x + dropout(_mha_torch(attn, q, k, v, key_padding_mask)))
+    return y if next_pos is None else (y, None)     # (y + next_pos is the fused path's by-product only)
 
 
 def ffn_block(ffn, norm, x):

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd_kernel(
     int rows, int cols, const float *__restrict__ x, const float *__restrict__ residual,
     const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
     float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd, float dropout_p,
-    uint32_t site, const uint64_t *__restrict__ rng_counter) {
+    uint32_t site, const uint64_t *__restrict__ rng_counter, const float *__restrict__ pos,
+    float *__restrict__ y_pos) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kLnThreads / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -80,7 +81,12 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     const int c = lane + i * 64;
-    if (c < cols) y[(long)row * cols + c] = (s[i] - mu) * rs * gamma[c] + beta[c];
+    if (c < cols) {
+      const float out = (s[i] - mu) * rs * gamma[c] + beta[c];
+      y[(long)row * cols + c] = out;
+      // the next block's query input y + pos, written while y is in registers (it used to be a separate add)
+      if (y_pos) y_pos[(long)row * cols + c] = out + pos[(long)row * cols + c];
+    }
   }
   if (lane == 0) {
     mean[row] = mu;
@@ -196,7 +202,21 @@ int butd_add_dropout_layernorm_fwd(int rows, int cols, const float *x, const flo
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((rows + kLnThreads / 64 - 1) / (kLnThreads / 64));
   LN_DISPATCH(ln_fwd_kernel, rows, cols, x, residual, gamma, beta, eps, y, mean, rstd, dropout_p,
-              dropout_site, rng_counter);
+              dropout_site, rng_counter, (const float *)nullptr, (float *)nullptr);
+  return (int)hipGetLastError();
+}
+
+int butd_add_dropout_layernorm_fwd_pos(int rows, int cols, const float *x, const float *residual,
+                                       const float *gamma, const float *beta, float eps, float *y,
+                                       float *mean, float *rstd, float dropout_p, uint32_t dropout_site,
+                                       const uint64_t *rng_counter, const float *pos, float *y_pos,
+                                       butd_stream_t stream) {
+  if (rows <= 0) return 0;
+  if (cols <= 0 || cols > 64 * kLnMaxPerLane || (pos == nullptr) != (y_pos == nullptr)) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid((rows + kLnThreads / 64 - 1) / (kLnThreads / 64));
+  LN_DISPATCH(ln_fwd_kernel, rows, cols, x, residual, gamma, beta, eps, y, mean, rstd, dropout_p,
+              dropout_site, rng_counter, pos, y_pos);
   return (int)hipGetLastError();
 }
 

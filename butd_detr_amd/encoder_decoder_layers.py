@@ -295,14 +295,17 @@ class BiDecoderLayer(nn.Module):
 
         # the four blocks' position gradients arrive together and are summed in one pass (fan_out.py)
         pos_s, pos_l, pos_d, pos_v = fan_out(query_pos, 4)
-        query = ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s,
-                         key_padding_mask=padding_mask)
-        query = ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l,
-                         memory=lang_feats, key_padding_mask=text_key_padding_mask)
+        # ... and every block writes `its output + query_pos` for the next one while the output is in registers
+        nxt = query_pos if query_pos is not None else None
+        two = lambda r: r if isinstance(r, tuple) else (r, None)
+        query, qp = two(ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s,
+                                 key_padding_mask=padding_mask, next_pos=nxt))
+        query, qp = two(ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l, xq_pre=qp,
+                                 memory=lang_feats, key_padding_mask=text_key_padding_mask, next_pos=nxt))
         if detected_feats is not None:
-            query = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d,
-                             memory=detected_feats, key_padding_mask=detected_mask)
-        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v,
+            query, qp = two(ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d, xq_pre=qp,
+                                     memory=detected_feats, key_padding_mask=detected_mask, next_pos=nxt))
+        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v, xq_pre=qp,
                          memory=vis_feats, key_padding_mask=None)
         query = ab.ffn_block(self.ffn, self.norm2, query)
         return query.contiguous()

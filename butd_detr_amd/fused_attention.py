@@ -406,12 +406,14 @@ class _XpmBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, mem, mask, w_in, b_in, w_o, b_o, gamma, beta,
-                num_heads, eps, p_attn, p_out, site_attn, site_out):
+                num_heads, eps, p_attn, p_out, site_attn, site_out, xq_pre=None, next_pos=None):
         B, Lq, E = x.shape
         H, D = num_heads, E // num_heads
         dev = x.device
         self_attn = mem is None
-        xq = x if pos is None else x + pos
+        # xq_pre: x + pos as the PREVIOUS block's LayerNorm kernel already wrote it (data only: the gradients of x
+        # and pos are this block's as ever); next_pos: write y + next_pos for the next block the same way
+        xq = x if pos is None else (xq_pre if xq_pre is not None else x + pos)
         xk, xv = (xq, x) if self_attn else (mem, mem)
         Lk = xk.shape[1]
         Mq, Mk = B * Lq, B * Lk
@@ -434,19 +436,23 @@ class _XpmBlock(torch.autograd.Function):
         y = torch.empty((B, Lq, E), device=dev)
         mean = torch.empty((Mq,), device=dev)
         rstd = torch.empty((Mq,), device=dev)
+        y_pos = torch.empty((B, Lq, E), device=dev) if next_pos is not None else None
         with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_fwd(
+            err = _lib.butd_add_dropout_layernorm_fwd_pos(
                 Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
                 y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
-                rng_counter(dev).data_ptr(), _stream(x))
-        _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
+                rng_counter(dev).data_ptr(), _ptr(next_pos), _ptr(y_pos), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
         ctx.save_for_backward(x, xq if pos is not None else None, mem, mask, w_in, w_o, gamma, q, k, v,
                               att, lse, proj, mean, rstd)
         ctx.cfg = (H, p_attn, p_out, site_attn, site_out)
-        return y
+        if next_pos is None:
+            return y
+        ctx.mark_non_differentiable(y_pos)
+        return y, y_pos
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _d_y_pos=None):
         x, xq_saved, mem, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean, rstd = ctx.saved_tensors
         H, p_attn, p_out, site_attn, site_out = ctx.cfg
         has_pos = xq_saved is not None
@@ -522,19 +528,23 @@ class _XpmBlock(torch.autograd.Function):
                    _xwgrad(dq, E, xq, d_w_in[:E], d_b_in[:E], Mq, E, E),
                    _xwgrad(G, ldg, mem, d_w_in[E:], d_b_in[E:], Mk, 2 * E, E)], x)
         return (R, d_pos, d_mem, None, d_w_in, d_b_in, d_w_o, d_b_o, d_gamma, d_beta,
-                None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
-def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None):
-    """LayerNorm(x + Dropout(MHA(x + pos, k, v))), (k, v) = (x + pos, x) or (memory, memory)."""
+def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None):
+    """LayerNorm(x + Dropout(MHA(x + pos, k, v))), (k, v) = (x + pos, x) or (memory, memory).
+    ``next_pos``: also return ``y + next_pos`` (written by the LayerNorm kernel; no gradient flows through it) for the
+    next block, which takes it as ``xq_pre`` in place of computing ``x + pos`` itself: -> (y, y + next_pos)."""
     training = attn.training
     p_attn = float(attn.dropout) if training else 0.0
     p_out = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
     x = x.contiguous()
     pos = None if pos is None else pos.contiguous()
     memory = None if memory is None else memory.contiguous()
+    next_pos = None if next_pos is None else next_pos.detach().contiguous()
+    xq_pre = None if (xq_pre is None or pos is None) else xq_pre.detach()
     _check(x, pos, memory)
     return _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
                            attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
                            norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
-                           _next_site(), _next_site())
+                           _next_site(), _next_site(), xq_pre, next_pos)

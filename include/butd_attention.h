@@ -131,6 +131,15 @@ int butd_add_dropout_layernorm_fwd(int rows, int cols, const float *x, const flo
                                    float *mean, float *rstd, float dropout_p, uint32_t dropout_site,
                                    const uint64_t *rng_counter, butd_stream_t stream);
 
+/* The same, and additionally y_pos = y + pos (both rows x cols; pos == NULL <=> y_pos == NULL): the query input
+ * `tgt + query_pos` of the NEXT attention block (encoder_decoder_layers.py:356-404) leaves the kernel that produced
+ * `tgt` instead of being a separate elementwise pass. */
+int butd_add_dropout_layernorm_fwd_pos(int rows, int cols, const float *x, const float *residual,
+                                       const float *gamma, const float *beta, float eps, float *y,
+                                       float *mean, float *rstd, float dropout_p, uint32_t dropout_site,
+                                       const uint64_t *rng_counter, const float *pos, float *y_pos,
+                                       butd_stream_t stream);
+
 /* Backward: given dy and the saved statistics, produces d_residual (= d of the pre-norm sum) and
  * dx (= d_residual * dropout mask / (1-p)); accumulates dgamma/dbeta (cols) with atomics
  * (caller zero-fills them).  dx may alias d_residual when dropout_p == 0. */

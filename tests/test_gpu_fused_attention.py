@@ -302,3 +302,57 @@ def test_bf16_attention_core_alone(mods):
     _close(res["bf16"][0], res["f32"][0], 1e-2)
     for i in (1, 2, 3):
         _close(res["bf16"][i], res["f32"][i], 3e-2)
+
+
+def test_chain_of_blocks_with_the_position_sum_from_the_layernorm_kernel(mods):
+    """``next_pos`` / ``xq_pre`` (butd_add_dropout_layernorm_fwd_pos): a block writes `output + pos` for the next
+    block, which uses it in place of its own `x + pos` -- values and every gradient (x, pos, memory, parameters) equal
+    the chain that adds in each block, and the torch maths (the decoder layer's four blocks,
+    encoder_decoder_layers.py:356-404)."""
+    ab, fa, MHA, _ = mods
+    torch.manual_seed(5)
+    E, H, B, Lq, Lk = 288, 8, 3, 256, 80
+    blocks = []
+    for _ in range(3):
+        attn = MHA(E, H, dropout=0.0).cuda().eval()
+        norm = torch.nn.LayerNorm(E).cuda()
+        with torch.no_grad():
+            norm.weight.uniform_(0.8, 1.2)
+            norm.bias.uniform_(-0.1, 0.1)
+        blocks.append((attn, norm))
+    drop = torch.nn.Dropout(0.0).eval()
+    x = torch.randn(B, Lq, E, device="cuda", requires_grad=True)
+    pos = torch.randn(B, Lq, E, device="cuda", requires_grad=True)
+    mem = torch.randn(B, Lk, E, device="cuda", requires_grad=True)
+    probe = torch.randn(B, Lq, E, device="cuda")
+    leaves = [x, pos, mem] + [p for a, n in blocks for p in list(a.parameters()) + list(n.parameters())]
+
+    def run(backend, chained):
+        ab.set_backend(backend)
+        for t in leaves:
+            t.grad = None
+        q, qp = x, None
+        for i, (attn, norm) in enumerate(blocks):
+            memory = None if i == 0 else mem
+            last = i == len(blocks) - 1
+            if chained:
+                r = ab.block(attn, drop, norm, x=q, pos=pos, memory=memory, xq_pre=qp,
+                             next_pos=None if last else pos)
+                q, qp = r if isinstance(r, tuple) else (r, None)
+            else:
+                q = ab.block(attn, drop, norm, x=q, pos=pos, memory=memory)
+        (q * probe).sum().backward()
+        return q, [t.grad.clone() for t in leaves]
+
+    try:
+        y_ref, g_ref = run("torch", False)
+        y_add, g_add = run("hip", False)
+        y_ch, g_ch = run("hip", True)
+    finally:
+        ab.set_backend("torch")
+    assert torch.equal(y_ch, y_add)                  # same arithmetic: x + pos is one rounding either way
+    for a, b in zip(g_ch, g_add):                    # (split-K weight gradients add their slices in arrival order)
+        _close(a, b, 1e-5)
+    _close(y_ch, y_ref)
+    for a, b in zip(g_ch, g_ref):
+        _close(a, b, 2e-3)
