@@ -41,6 +41,7 @@ def _sum(grads):
 class _FanOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, n):
+        ctx.set_materialize_grads(False)             # an unused alias contributes None, not a tensor of zeros
         return tuple(t.view_as(t) for _ in range(n))
 
     @staticmethod
@@ -60,6 +61,7 @@ def fan_out(t, n):
 class _Unstack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t):
+        ctx.set_materialize_grads(False)
         ctx.shape, ctx.dtype, ctx.device = t.shape, t.dtype, t.device
         return tuple(t[i] for i in range(t.shape[0]))
 

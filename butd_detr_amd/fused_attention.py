@@ -449,10 +449,13 @@ class _XpmBlock(torch.autograd.Function):
         if next_pos is None:
             return y
         ctx.mark_non_differentiable(y_pos)
+        ctx.set_materialize_grads(False)             # no zero tensor for y_pos's (non-existent) gradient
         return y, y_pos
 
     @staticmethod
     def backward(ctx, dy, _d_y_pos=None):
+        if dy is None:                                 # (gradients are not materialised: the block's output unused)
+            return (None,) * 18
         x, xq_saved, mem, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean, rstd = ctx.saved_tensors
         H, p_attn, p_out, site_attn, site_out = ctx.cfg
         has_pos = xq_saved is not None
