@@ -17,11 +17,15 @@ with arena:
     loss = crit(model(inputs), targets); loss.backward()     # warm
 for p in model.parameters(): p.grad = None
 KEEP = ("add", "copy_", "clone", "_to_copy", "zeros", "fill_", "zero_", "mul", "div", "cat", "stack", "sum", "contiguous", "where", "index")
+ALL = os.environ.get("ALL_OPS") == "1"
+SKIP = ("view", "_unsafe_view", "t.", "transpose", "detach", "alias", "expand", "slice", "select", "unsqueeze", "squeeze",
+        "permute", "as_strided", "empty", "reshape", "unbind", "split", "_local_scalar", "is_", "size", "stride", "new_empty",
+        "lift", "sym_", "record_stream", "_reshape_alias")
 class Log(TorchDispatchMode):
     def __init__(self): super().__init__(); self.rows = collections.Counter(); self.phase = "fwd"
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func).replace("aten.", "")
-        if name.split(".")[0] in KEEP:
+        if ALL and not name.startswith(SKIP) or name.split(".")[0] in KEEP:
             shp = next((tuple(a.shape) for a in args if isinstance(a, torch.Tensor)), ())
             site = "autograd"
             for fr in reversed(traceback.extract_stack(limit=40)):
@@ -40,5 +44,10 @@ torch.cuda.synchronize()
 tot = collections.Counter()
 for (ph, name, shp, site), n in log.rows.items(): tot[(ph, name.split(".")[0])] += n
 print("totals:", dict(tot))
+bysite = collections.Counter()
+for (ph, name, shp, site), n in log.rows.items(): bysite[(ph, site)] += n
+if ALL:
+    print("by site:")
+    for (ph, site), n in sorted(bysite.items(), key=lambda kv: -kv[1])[:45]: print(f"{n:4d} {ph} {site}")
 for (ph, name, shp, site), n in sorted(log.rows.items(), key=lambda kv: -kv[1])[:70]:
     print(f"{n:4d} {ph} {name:22s} {str(shp):24s} {site}")
