@@ -31,8 +31,8 @@ BF16_MATRIX_PEAK_TF = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--queries", type=int, default=256)
