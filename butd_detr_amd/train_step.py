@@ -724,12 +724,20 @@ class GraphedTrainStep:
         want = length
         if self.token_bucket:
             want = (length + self.token_bucket - 1) // self.token_bucket * self.token_bucket
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:   # (forced at world size 1: the one-GPU rehearsal of this path)
             import torch.distributed as dist
-            t = torch.tensor([want], dtype=torch.int64, device=tok["input_ids"].device)
-            if dist.get_backend(self.group) == "gloo":
-                t = t.cpu()
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            dev = tok["input_ids"].device
+            if dist.get_backend(self.group) == "gloo" or dev.type != "cuda":
+                t = torch.tensor([want], dtype=torch.int64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            else:
+                # on the upload stream: the collective (and the .item() behind it) must not queue behind the
+                # previous step's graphs on the main stream -- the host would stall until that step has finished
+                # and the GPU would idle while the next graphs are being enqueued
+                with torch.cuda.stream(self._upload_stream(dev)):
+                    t = torch.tensor([want], dtype=torch.int64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                    t = t.cpu()                      # (the read-back is stream-ordered too: inside the context)
             want = int(t.item())
         if want == length:
             return tok
@@ -740,8 +748,41 @@ class GraphedTrainStep:
             out[k] = torch.nn.functional.pad(v, (0, want - length), value=fill)
         return BatchEncoding(out)
 
+    def _upload_stream(self, dev):
+        if getattr(self, "_up", None) is None:
+            self._up = torch.cuda.Stream(dev)
+            self._up_done = torch.cuda.Event()
+            self._up_pinned = {}
+        return self._up
+
     def _tokenize(self, inputs):
-        return self._pad_tokens(self.model.tokenize(inputs))
+        """Host tokenisation (bdetr.py:164-166) + upload.  ``BatchEncoding.to(device)`` from pageable memory is a
+        synchronous copy on the current stream: the host waited there until the previous step's graphs had finished
+        and only then enqueued the next ones (0.8 ms of idle GPU per step in the trace).  The ids go through pinned
+        staging buffers on an upload stream instead; the main stream waits for the upload's event."""
+        module = self._module()
+        dev = inputs["point_clouds"].device
+        if dev.type != "cuda" or not hasattr(module, "tokenizer"):
+            return self._pad_tokens(self.model.tokenize(inputs))
+        from transformers import BatchEncoding
+        host = module.tokenizer.batch_encode_plus(inputs["text"], padding="longest", return_tensors="pt")
+        up = self._upload_stream(dev)
+        self._up_done.synchronize()                  # the previous upload has left its staging buffers
+        out = {}
+        with torch.cuda.stream(up):
+            for k, v in host.items():
+                key = (k, tuple(v.shape), v.dtype)
+                pin = self._up_pinned.get(key)
+                if pin is None:
+                    pin = self._up_pinned[key] = torch.empty_like(v).pin_memory()
+                pin.copy_(v)
+                out[k] = pin.to(dev, non_blocking=True)
+            self._up_done.record(up)
+        main = torch.cuda.current_stream(dev)
+        main.wait_event(self._up_done)
+        for v in out.values():
+            v.record_stream(main)
+        return self._pad_tokens(BatchEncoding(out))
 
     def __call__(self, inputs, targets, next_inputs=None):
         # host work stays in the step; a batch announced by the previous call was tokenised then
