@@ -383,6 +383,15 @@ def bf16_row(args, model, opt, criterion, batches):
         model.text_precision = "f32"
 
 
+def _flush_c_stdio():
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def make_criterion(args):
     if args.criterion == "surrogate":
         return None
@@ -448,6 +457,8 @@ def main():
 
     for k in range(args.warmup):
         train_step(k)
+    _flush_c_stdio()            # RCCL's start-up banner sits in the C stdio buffer of every rank: out with it now, so
+                                # that the JSON line below is the LAST line on stdout
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -497,6 +508,7 @@ def main():
             out["text_cache_operating_point"] = text_cache_row(args, model, opt, criterion, batches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
+        _flush_c_stdio()
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.barrier()
