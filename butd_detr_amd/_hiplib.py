@@ -53,7 +53,7 @@ class GemmProblem(ctypes.Structure):
                 ("b_drop_p", _c_float), ("b_drop_site", _c_u32),
                 ("col_sum", _c_void_p), ("col_sumsq", _c_void_p),
                 ("c_add", _c_int), ("c2", _c_void_p), ("col_slots", _c_int), ("col_slot_stride", _c_long),
-                ("compute_bf16", _c_int)]
+                ("compute_bf16", _c_int), ("c_gate", _c_void_p), ("c_gate_scale", _c_float)]
 
 
 ATTENTION_SYMBOLS = {

@@ -681,7 +681,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
     // (scratch/ubench/mfma_valu.hip), so every instruction of this epilogue is paid in matrix time: per float4 it is
     // one ds_read_b128, 4 fma (+4 max, +8 for the column statistics, +4 for an accumulating store) and one store.
     if (m0 + TM <= pM && n0 + TN <= pN && !drop && P.c2 == nullptr && (ldc & 3) == 0 &&
-        (((uintptr_t)cptr | (uintptr_t)P.bias) & 15) == 0) {
+        (((uintptr_t)cptr | (uintptr_t)P.bias | (uintptr_t)P.c_gate) & 15) == 0) {
       double *const col_sum = P.col_sum, *const col_sumsq = P.col_sumsq;
       const bool c_add = P.c_add != 0;
       const bool streaming = !c_add && (long)pM * pN >= (16L << 20);   // >= 64 MB
@@ -691,6 +691,8 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
         bs = b4 * scale;
       }
       f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
+      const float *const gate = P.c_gate;
+      const float gate_scale = P.c_gate_scale;
       auto rows = [&](auto relu_t, auto stats_t, auto add_t) {
         if (!active) return;
         float *dst = cptr + (long)(m0 + rphase) * ldc + n;
@@ -700,6 +702,11 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
           f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[row * kLdC + c4]) * scale + bs;
           if constexpr (decltype(relu_t)::value) {
             v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+          }
+          if (gate) {   // (uniform) ReLU / dropout backward of the gradient this product creates
+            const f32x4 gt = *reinterpret_cast<const f32x4 *>(gate + (dst - cptr));
+            v[0] = gt[0] > 0.f ? v[0] * gate_scale : 0.f; v[1] = gt[1] > 0.f ? v[1] * gate_scale : 0.f;
+            v[2] = gt[2] > 0.f ? v[2] * gate_scale : 0.f; v[3] = gt[3] > 0.f ? v[3] * gate_scale : 0.f;
           }
           if constexpr (decltype(stats_t)::value) {
             cs += v;
@@ -766,6 +773,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
           if (relu) v[e] = fmaxf(v[e], 0.f);
           if (drop)
             v[e] = rng::keep(ctr, site, (uint32_t)((long)m * pN + n + e), p_drop) ? v[e] * inv_keep : 0.f;
+          if (P.c_gate && n + e < pN) v[e] = P.c_gate[(long)m * ldc + n + e] > 0.f ? v[e] * P.c_gate_scale : 0.f;
           if (n + e < pN) {
             cs[e] += v[e];
             cq[e] += v[e] * v[e];
@@ -1025,7 +1033,7 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
     const butd_gemm_problem &p = problems[i];
     if (p.M <= 0 || p.N <= 0) continue;
     if (p.split_k > 1 && !p.accumulate) return (int)hipErrorInvalidValue;
-    if ((p.col_sum != nullptr || p.c_add || p.c2 != nullptr) && (p.accumulate || p.ones_col || p.split_k > 1))
+    if ((p.col_sum != nullptr || p.c_add || p.c2 != nullptr || p.c_gate != nullptr) && (p.accumulate || p.ones_col || p.split_k > 1))
       return (int)hipErrorInvalidValue;
     if (p.col_slots > 1 && (p.col_slots & (p.col_slots - 1))) return (int)hipErrorInvalidValue;
     if (fast_eligible(p)) fast_idx[nf++] = i; else slow_idx[ns++] = i;

@@ -143,7 +143,7 @@ def get_compute_dtype():
 def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.0, bias=None,
              bias_grad=None, scale=1.0, relu=False, accumulate=False, ones_col=False, split_k=1,
              dropout_p=0.0, site=0, a_affine=None, b_affine=None, a_drop=(0.0, 0), b_drop=(0.0, 0),
-             col_stats=None, c_add=False, c2=None, col_slots=(0, 0)):
+             col_stats=None, c_add=False, c2=None, col_slots=(0, 0), gate=None, gate_scale=1.0):
     asc, ash = a_affine if a_affine is not None else (None, None)
     bsc, bsh = b_affine if b_affine is not None else (None, None)
     return GemmProblem(_ptr(a), _ptr(a2), _ptr(b), _ptr(bias), _ptr(c), _ptr(bias_grad), M, N, K,
@@ -153,7 +153,8 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                        float(a_drop[0]), int(a_drop[1]), float(b_drop[0]), int(b_drop[1]),
                        _ptr(col_stats[0]) if col_stats is not None else None,
                        _ptr(col_stats[1]) if col_stats is not None else None,
-                       int(c_add), _ptr(c2), int(col_slots[0]), int(col_slots[1]), int(_compute_bf16[0]))
+                       int(c_add), _ptr(c2), int(col_slots[0]), int(col_slots[1]), int(_compute_bf16[0]),
+                       _ptr(gate), float(gate_scale))
 
 
 def _gemm(problems, ref):
@@ -337,11 +338,13 @@ class _FfnBlock(torch.autograd.Function):
                 p2, site2, rng_counter(dev).data_ptr(), _stream(x))
         _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
         d_h = torch.empty((B, L, Fh), device=dev)
-        _gemm([_dgrad(d_o, w2, d_h, M, E, Fh),
-               _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)], x)
         gate = 1.0 / (1.0 - p1) if p1 > 0 else 1.0        # h = relu(z) * keep / (1-p): h > 0 <=> live
-        _gemm([_dgrad(d_h, w1, d_x, M, Fh, E, a2=h, a2_mode=1, a2_scale=gate, accumulate=True),
-               _wgrad(d_h, x, d_w1, d_b1, M, Fh, E, a2=h, a2_mode=1, a2_scale=gate)], x)
+        # the product that creates d_h applies the ReLU / dropout gate in its epilogue (c_gate): the two products that
+        # read d_h then stay on the float4 staging path (they carried h as a companion operand before)
+        _gemm([_dgrad(d_o, w2, d_h, M, E, Fh, gate=h, gate_scale=gate),
+               _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)], x)
+        _gemm([_dgrad(d_h, w1, d_x, M, Fh, E, c_add=True),
+               _wgrad(d_h, x, d_w1, d_b1, M, Fh, E)], x)
         return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None
 
 

@@ -77,6 +77,14 @@ typedef struct {
    * "bf16 attention / FFN" operating point of BASELINE configs[3]; honoured when every float4-aligned
    * problem of a launch asks for it, ignored (fp32) for the element-wise staged ones (a2, unaligned). */
   int compute_bf16;
+  /* Optional gate on the stored result (plain-store problems only: accumulate == 0, ones_col == 0):
+   *   C[m,n] <- c_gate[m*ldc + n] > 0 ? epilogue(v) * c_gate_scale : 0
+   * -- the backward of ReLU (+ dropout: the saved activation h = relu(z) * keep / (1-p) is > 0 exactly where the
+   * gradient passes, and c_gate_scale = 1 / (1-p)) applied by the product that CREATES the gradient d_h, so the
+   * products that read it need no companion operand (a2_mode 1 does the same on the reading side and keeps those
+   * products on the element-wise staging path).  c_gate has the layout of C (same ldc). */
+  const float *c_gate;
+  float c_gate_scale;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).

@@ -115,10 +115,18 @@ def test_random_group(seed, tile, dtype):
             checks.append(check)
         elif kind == "dgrad":
             dy, w, dx = r(M, N), r(N, K), torch.full((M, K), float("nan"), device=dev)
-            keep += [dy, w, dx]
-            probs.append(fa._dgrad(dy, w, dx, M, N, K))
-            checks.append(lambda dx=dx, dy=dy, w=w: _close_any(dx, [_op(dy, dtype) @ _op(w, dtype),
-                                                                     dy.double() @ w.double()], 2e-4))
+            # the ReLU / dropout gate of the gradient this product creates, applied in its epilogue (c_gate)
+            gate = torch.relu(r(M, K)) if rng.random() < 0.4 else None
+            gscale = float(rng.choice([1.0, 1.25]))
+            keep += [dy, w, dx, gate]
+            probs.append(fa._dgrad(dy, w, dx, M, N, K, gate=gate, gate_scale=gscale))
+
+            def check(dx=dx, dy=dy, w=w, gate=gate, gscale=gscale):
+                refs = [_op(dy, dtype) @ _op(w, dtype), dy.double() @ w.double()]
+                if gate is not None:
+                    refs = [torch.where(gate > 0, ref * gscale, torch.zeros_like(ref)) for ref in refs]
+                _close_any(dx, refs, 2e-4)
+            checks.append(check)
         else:
             dy, x = r(M, N), r(M, K)
             dw, db = torch.zeros(N, K, device=dev), torch.zeros(N, device=dev)
