@@ -221,7 +221,16 @@ class BeaUTyDETR(nn.Module):
         return end_points
 
     def _normalized_proj(self, x):
-        return F.normalize(self.contrastive_align_projection_image(x), p=2, dim=-1)
+        return F.normalize(self._proj_mlp(self.contrastive_align_projection_image, x), p=2, dim=-1)
+
+    @staticmethod
+    def _proj_mlp(seq, x):
+        """The Linear-ReLU-Linear-ReLU-Linear projections on the grouped GEMM (fused gate / bias / ReLU epilogues)
+        when the fused backend is active; the stock modules otherwise."""
+        if x.is_cuda and attention_blocks.get_backend() == "hip" and os.environ.get("BUTD_PROJ_CHAIN", "1") != "0":
+            from .fused_attention import linear_relu_chain
+            return linear_relu_chain(seq, x)
+        return seq(x)
 
     # ------------------------------------------------------------------ forward
     def forward(self, inputs):
@@ -261,7 +270,7 @@ class BeaUTyDETR(nn.Module):
         end_points["seed_features"] = points_features
         if self.contrastive_align_loss:
             end_points["proj_tokens"] = F.normalize(
-                self.contrastive_align_projection_text(text_feats), p=2, dim=-1)
+                self._proj_mlp(self.contrastive_align_projection_text, text_feats), p=2, dim=-1)
 
         end_points = self._generate_queries(points_xyz, points_features, end_points, features_pm=vis)
         cluster_feature = end_points["query_points_feature"]     # (B, d, Q)

@@ -348,6 +348,79 @@ class _FfnBlock(torch.autograd.Function):
         return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None
 
 
+class _LinearReluChain(torch.autograd.Function):
+    """y = W_n(relu(... relu(W_1 x + b_1) ...)) + b_n over the rows of x: the contrastive-alignment projections
+    (bdetr.py:104-121: Linear-ReLU-Linear-ReLU-Linear).  n products forward (ReLU in the epilogue); backward n
+    launches, each the input-gradient product of a layer -- with the previous layer's ReLU gate applied in its
+    epilogue -- together with that layer's weight / bias gradient."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        n = len(params) // 2
+        ws, bs = params[0::2], params[1::2]
+        lead, dev = x.shape[:-1], x.device
+        a = x.reshape(-1, x.shape[-1])
+        M = a.shape[0]
+        acts = [a]
+        for i, (w, b) in enumerate(zip(ws, bs)):
+            N, K = w.shape
+            out = torch.empty((M, N), device=dev)
+            _gemm([_fwd(acts[-1], w, out, M, N, K, bias=b, relu=i < n - 1)], x)
+            acts.append(out)
+        ctx.save_for_backward(*acts[:-1], *ws)
+        ctx.n, ctx.has_bias = n, [b is not None for b in bs]
+        return acts[-1].view(*lead, ws[-1].shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        n = ctx.n
+        acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dev = dy.device
+        g = dy.reshape(-1, dy.shape[-1]).contiguous()
+        M = g.shape[0]
+        sizes = [w.numel() + w.shape[0] for w in ws]
+        slab = zeros(sum(sizes), device=dev)
+        grads, off = [], 0
+        for w, s in zip(ws, sizes):
+            grads.append((slab[off:off + w.numel()].view_as(w), slab[off + w.numel():off + s]))
+            off += s
+        need_dx = ctx.needs_input_grad[0]
+        dx = None
+        for i in reversed(range(n)):
+            N, K = ws[i].shape
+            probs = [_wgrad(g, acts[i], grads[i][0], grads[i][1] if ctx.has_bias[i] else None, M, N, K)]
+            if i > 0:       # the gradient of relu(z_{i-1}): acts[i] = relu(z_{i-1}) > 0 exactly where it passes
+                d_in = torch.empty((M, K), device=dev)
+                probs.append(_dgrad(g, ws[i], d_in, M, N, K, gate=acts[i], gate_scale=1.0))
+            elif need_dx:
+                d_in = torch.empty((M, K), device=dev)
+                probs.append(_dgrad(g, ws[i], d_in, M, N, K))
+            _gemm(probs, dy)
+            if i > 0:
+                g = d_in
+            elif need_dx:
+                dx = d_in.view(*dy.shape[:-1], K)
+        out = [dx]
+        for (dw, db), hb in zip(grads, ctx.has_bias):
+            out += [dw, db if hb else None]
+        return tuple(out)
+
+
+def linear_relu_chain(seq, x):
+    """``seq`` = nn.Sequential(Linear, ReLU, Linear, ReLU, ..., Linear) applied to the last dimension of ``x``."""
+    lins = [m for m in seq if isinstance(m, torch.nn.Linear)]
+    ok = (len(seq) == 2 * len(lins) - 1 and all(isinstance(m, torch.nn.ReLU) for m in list(seq)[1::2])
+          and all(l.in_features % 4 == 0 and l.out_features % 4 == 0 for l in lins))
+    if not ok or not x.is_cuda or x.dtype != torch.float32:
+        return seq(x)
+    x = x.contiguous()
+    _check(x)
+    params = []
+    for l in lins:
+        params += [l.weight, l.bias]
+    return _LinearReluChain.apply(x, *params)
+
+
 def _as_mask(mask):
     if mask is None:
         return None

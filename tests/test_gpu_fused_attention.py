@@ -356,3 +356,33 @@ def test_chain_of_blocks_with_the_position_sum_from_the_layernorm_kernel(mods):
     _close(y_ch, y_ref)
     for a, b in zip(g_ch, g_ref):
         _close(a, b, 2e-3)
+
+
+@pytest.mark.parametrize("lead", [(7, 8, 256), (8, 80), (3, 5)])
+def test_linear_relu_chain_matches_the_stock_modules(mods, lead):
+    """fused_attention.linear_relu_chain: the contrastive-alignment projection MLPs (bdetr.py:104-121) on the grouped
+    GEMM -- ReLU in the forward epilogues, the ReLU gate in the epilogue of the product that creates each hidden
+    gradient (c_gate) -- values and all gradients vs nn.Sequential."""
+    ab, fa, _, _ = mods
+    torch.manual_seed(sum(lead))
+    seq = torch.nn.Sequential(torch.nn.Linear(288, 288), torch.nn.ReLU(), torch.nn.Linear(288, 288), torch.nn.ReLU(),
+                              torch.nn.Linear(288, 64)).cuda()
+    x = torch.randn(*lead, 288, device="cuda", requires_grad=True)
+    probe = torch.randn(*lead, 64, device="cuda")
+    leaves = [x] + list(seq.parameters())
+
+    def run(fn):
+        for t in leaves:
+            t.grad = None
+        y = fn(x)
+        (torch.nn.functional.normalize(y, p=2, dim=-1) * probe).sum().backward()
+        return y, [t.grad.clone() for t in leaves]
+
+    y_ref, g_ref = run(seq)
+    y_hip, g_hip = run(lambda t: fa.linear_relu_chain(seq, t))
+    _close(y_hip, y_ref)
+    for a, b in zip(g_hip, g_ref):
+        _close(a, b, 2e-3)
+    # anything else than Linear / ReLU alternation goes to the modules themselves
+    odd = torch.nn.Sequential(torch.nn.Linear(288, 288), torch.nn.Tanh(), torch.nn.Linear(288, 64)).cuda()
+    assert torch.equal(fa.linear_relu_chain(odd, x), odd(x))
