@@ -785,6 +785,13 @@ class GraphedTrainStep:
         return self._pad_tokens(BatchEncoding(out))
 
     def __call__(self, inputs, targets, next_inputs=None):
+        # The host may not run a whole step ahead of the device in the two-piece (overlapped exchange) step: on a
+        # 90-step soak the free-running two-piece step ended 0.8 loss units away from the same step with this wait
+        # (and from the single-graph step), although every replay's gradients equal the eager ones (DESIGN.md section 7,
+        # open observation).  BUTD_STEP_SYNC=0 / 1 overrides (default: only the two-piece step waits).
+        sync = os.environ.get("BUTD_STEP_SYNC")
+        if sync == "1" or (sync is None and self.split):
+            torch.cuda.current_stream().synchronize()
         # host work stays in the step; a batch announced by the previous call was tokenised then
         cache = getattr(self, "_tok_cache", None)
         tok = cache[1] if (cache is not None and cache[0] is inputs) else self._tokenize(inputs)

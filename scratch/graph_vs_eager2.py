@@ -8,6 +8,10 @@ from butd_detr_amd import fused_attention as fa
 from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, synthetic_batch
 args = bench.parse()
 dev = torch.device("cuda", 0)
+if os.environ.get("SPLIT") == "1":
+    import torch.distributed as dist
+    os.environ["BUTD_FORCE_COLLECTIVE"] = "1"
+    dist.init_process_group("gloo", init_method="file:///tmp/gve2_init_%d" % os.getpid(), rank=0, world_size=1)
 base, _ = bench.build_model(args, dev)
 base.text_encoder.eval()
 for m in base.text_projector.modules():

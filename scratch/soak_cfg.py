@@ -5,6 +5,11 @@ import torch, bench
 from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, synthetic_batch
 args = bench.parse()
 dev = torch.device("cuda", 0)
+if os.environ.get("SPLIT") == "1":
+    import torch.distributed as dist
+    os.environ["BUTD_FORCE_COLLECTIVE"] = "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group(os.environ.get("BACKEND", "nccl"), init_method="env://", rank=0, world_size=1)
 model, _ = bench.build_model(args, dev)
 crit = bench.make_criterion(args)
 if os.environ.get("STOCK_DROPOUT", "1") == "0":
