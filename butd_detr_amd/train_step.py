@@ -449,7 +449,9 @@ class GraphedTrainStep:
     encoder outputs, 1b = backward through the encoder and the backbone.  The decoder-side bucket (the first
     ``optimizer.boundary_offset`` floats, ~60 % of the 85.7 MB) is all-reduced asynchronously while 1b
     replays, the rest after it -- DistributedDataParallel's bucket overlap (main_utils.py:310-313) with two
-    buckets and no per-parameter hooks.
+    buckets and no per-parameter hooks.  OPT-IN (default off) since the end of round 2: free-running, the two-piece
+    step trained measurably worse than the single-graph step although each replay is right (open
+    problem); with it on, the host waits for the previous step before enqueueing the next.
 
     Shapes are static: every (batch, points, tokens) signature is captured once and cached.  The reference
     pads the utterances to the longest of the batch (bdetr.py:160-163), and its contrastive loss takes a
@@ -467,7 +469,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
-                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=True, token_bucket=None):
+                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=False, token_bucket=None):
         import torch.distributed as dist
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
         self.criterion = criterion or surrogate_loss
@@ -849,6 +851,8 @@ class GraphedTrainStep:
         s.announced = nxt if (next_inputs is not None and text_ok) else None
         if self.flat_opt:
             self.optimizer.sync_hyper()                        # a scheduler may have moved the learning rates
+        if os.environ.get("BUTD_SYNC_AT") == "after_copy":
+            torch.cuda.current_stream().synchronize()
         if self.split:
             s.g_stage1.replay()
             work = self.flat_a.all_reduce_sum(self.group, force=self.force_collective, async_op=True)
@@ -859,5 +863,9 @@ class GraphedTrainStep:
         else:
             s.g_fwd_bwd.replay()
             self._exchange_whole()
+        if os.environ.get("BUTD_SYNC_AT") == "before_update":
+            torch.cuda.current_stream().synchronize()
         s.g_update.replay()
+        if os.environ.get("BUTD_SYNC_AT") == "end":
+            torch.cuda.current_stream().synchronize()
         return s.loss

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, init_file, out_dir):
+def _worker(rank, world, init_file, out_dir, overlap):
     sys.path.insert(0, ROOT)
     import warnings
     from butd_detr_amd import attention_blocks
@@ -37,7 +37,9 @@ def _worker(rank, world, init_file, out_dir):
                            text_encoder_factory=offline_factory(0)).to(dev).train()
     opt = FlatAdamW(model)
     # the reference's criterion: its box count is averaged over the ranks (losses.py:527-534) outside the graph
-    step = GraphedTrainStep(model, opt, warmup=1, criterion=HungarianCriterion(num_decoder_layers=1))
+    step = GraphedTrainStep(model, opt, warmup=1, criterion=HungarianCriterion(num_decoder_layers=1),
+                            overlap_exchange=overlap)
+    assert step.split == overlap
     batches = [synthetic_batch(2, dev, seed=11 + 5 * i, n_points=4096, tokens=16, rank=rank) for i in range(3)]
     losses = []
     for i, (inp, tgt) in enumerate(batches):
@@ -49,10 +51,11 @@ def _worker(rank, world, init_file, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_ranks_stay_in_lockstep():
+@pytest.mark.parametrize("overlap", [False, True], ids=["one all-reduce", "two-piece overlapped exchange"])
+def test_two_ranks_stay_in_lockstep(overlap):
     with tempfile.TemporaryDirectory() as tmp:
         init_file = os.path.join(tmp, "init")
-        mp.spawn(_worker, args=(2, init_file, tmp), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, init_file, tmp, overlap), nprocs=2, join=True)
         r0, r1 = (torch.load(os.path.join(tmp, f"r{r}.pt")) for r in (0, 1))
     assert r0["losses"] != r1["losses"]                     # different scenes per rank
     assert torch.equal(r0["flat_g"], r1["flat_g"])          # identical averaged gradients
