@@ -851,8 +851,6 @@ class GraphedTrainStep:
         s.announced = nxt if (next_inputs is not None and text_ok) else None
         if self.flat_opt:
             self.optimizer.sync_hyper()                        # a scheduler may have moved the learning rates
-        if os.environ.get("BUTD_SYNC_AT") == "after_copy":
-            torch.cuda.current_stream().synchronize()
         if self.split:
             s.g_stage1.replay()
             work = self.flat_a.all_reduce_sum(self.group, force=self.force_collective, async_op=True)
@@ -863,9 +861,5 @@ class GraphedTrainStep:
         else:
             s.g_fwd_bwd.replay()
             self._exchange_whole()
-        if os.environ.get("BUTD_SYNC_AT") == "before_update":
-            torch.cuda.current_stream().synchronize()
         s.g_update.replay()
-        if os.environ.get("BUTD_SYNC_AT") == "end":
-            torch.cuda.current_stream().synchronize()
         return s.loss

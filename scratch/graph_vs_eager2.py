@@ -20,7 +20,9 @@ batches = [synthetic_batch(args.batch, dev, seed=1184 + 50 * i, n_points=args.po
 crit = bench.make_criterion(args)
 me, mg = copy.deepcopy(base), copy.deepcopy(base)
 opt = FlatAdamW(mg)
-step = GraphedTrainStep(mg, opt, criterion=bench.make_criterion(args), warmup=1)
+step = GraphedTrainStep(mg, opt, criterion=bench.make_criterion(args), warmup=1, overlap_exchange=os.environ.get('SPLIT') == '1',
+                        prefetch_text=os.environ.get('PT', '1') == '1', prefetch_sampling=os.environ.get('PS', '1') == '1')
+print('split', step.split, 'prefetch_text', step.prefetch_text, 'prefetch_sampling', step.prefetch_sampling)
 step(*batches[0], next_inputs=batches[1][0]); torch.cuda.synchronize()
 names = [n for n, p in mg.named_parameters() if p.requires_grad]
 for it in range(int(os.environ.get("STEPS", "12"))):

@@ -17,7 +17,7 @@ if os.environ.get("STOCK_DROPOUT", "1") == "0":
     for m in model.text_projector.modules():
         if isinstance(m, torch.nn.Dropout): m.p = 0.0
 kw = dict(prefetch_sampling=os.environ.get("PS", "1") == "1", prefetch_text=os.environ.get("PT", "1") == "1",
-          zero_arena=os.environ.get("ZA", "1") == "1")
+          zero_arena=os.environ.get("ZA", "1") == "1", overlap_exchange=os.environ.get("OVERLAP", "0") == "1")
 eps = float(os.environ.get("LOSS_EPS", "0"))
 if eps:
     inner = crit
