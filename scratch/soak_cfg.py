@@ -31,5 +31,10 @@ losses = []
 for it in range(int(os.environ.get("STEPS", "90"))):
     inp, tgt = batches[it % 3]
     loss = step(inp, tgt, next_inputs=batches[(it + 1) % 3][0])
+    if it == 0 and os.environ.get("EMPTY_CACHE") == "1":
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_reserved()
+        torch.cuda.empty_cache()                     # cached free blocks of the default pool go back to the driver:
+        print("empty_cache released MB:", (before - torch.cuda.memory_reserved()) / 1e6)   # a baked-in stale address would fault
     if it % 10 == 9: losses.append(round(float(loss), 2))
 print(kw, {k: os.environ.get(k) for k in ("BUTD_ENCODER_FORK", "BUTD_TEXT_OVERLAP")}, losses)
