@@ -9,6 +9,7 @@
 // `*_kernel_wrapper` prototypes of src/{sampling,ball_query,group_points,interpolate}.cpp become calls of the
 // butd_* entry points.  Built by butd_detr_amd/binding/build.py (torch.utils.cpp_extension, in-tree); the
 // product path itself binds the same C ABI with ctypes (butd_detr_amd/_hiplib.py) and does not need it.
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/extension.h>
 
@@ -25,7 +26,10 @@ struct Arg {
   at::ScalarType dtype;
   const char *name;
 };
-void need(std::initializer_list<Arg> args) {
+// ... and make that GPU the current device for the rest of the entry point: output allocations, the workspace
+// queries and the launches inside the C ABI all act on the CURRENT device, which need not be the tensors' one
+using DeviceGuard = c10::hip::HIPGuardMasqueradingAsCUDA;
+DeviceGuard need(std::initializer_list<Arg> args) {
   for (const Arg &a : args) {
     TORCH_CHECK(a.t.is_contiguous(), a.name, " must be a contiguous tensor");
     TORCH_CHECK(a.t.scalar_type() == a.dtype, a.name, " must be a ", a.dtype == at::kFloat ? "float" : "int", " tensor");
@@ -34,6 +38,7 @@ void need(std::initializer_list<Arg> args) {
   TORCH_CHECK(anchor.is_cuda(), "CPU not supported");
   for (const Arg &a : args)
     TORCH_CHECK(a.t.is_cuda() && a.t.device() == anchor.device(), a.name, " must be a CUDA tensor on ", anchor.device());
+  return DeviceGuard(anchor.device());
 }
 
 butd_stream_t stream_of(const at::Tensor &t) {
@@ -45,7 +50,7 @@ void ok(int err, const char *what) { TORCH_CHECK(err == 0, what, ": ", butd_erro
 at::TensorOptions like(const at::Tensor &t, at::ScalarType dtype) { return at::device(t.device()).dtype(dtype); }
 
 at::Tensor furthest_point_sampling(at::Tensor points, const int nsamples) {   // sampling.cpp:70-91
-  need({{points, at::kFloat, "points"}});
+  DeviceGuard on_device = need({{points, at::kFloat, "points"}});
   const int b = points.size(0), n = points.size(1);
   at::Tensor idx = torch::zeros({b, nsamples}, like(points, at::kInt));
   at::Tensor temp = torch::empty({b, n}, like(points, at::kFloat));
@@ -64,7 +69,7 @@ at::Tensor furthest_point_sampling(at::Tensor points, const int nsamples) {   //
 }
 
 at::Tensor gather_points(at::Tensor points, at::Tensor idx) {   // sampling.cpp:20-45
-  need({{points, at::kFloat, "points"}, {idx, at::kInt, "idx"}});
+  DeviceGuard on_device = need({{points, at::kFloat, "points"}, {idx, at::kInt, "idx"}});
   at::Tensor out = torch::empty({points.size(0), points.size(1), idx.size(1)}, like(points, at::kFloat));
   ok(butd_gather_points(points.size(0), points.size(1), points.size(2), idx.size(1), points.data_ptr<float>(),
                         idx.data_ptr<int>(), out.data_ptr<float>(), stream_of(points)),
@@ -73,7 +78,7 @@ at::Tensor gather_points(at::Tensor points, at::Tensor idx) {   // sampling.cpp:
 }
 
 at::Tensor gather_points_grad(at::Tensor grad_out, at::Tensor idx, const int n) {   // sampling.cpp:47-69
-  need({{grad_out, at::kFloat, "grad_out"}, {idx, at::kInt, "idx"}});
+  DeviceGuard on_device = need({{grad_out, at::kFloat, "grad_out"}, {idx, at::kInt, "idx"}});
   at::Tensor out = torch::zeros({grad_out.size(0), grad_out.size(1), n}, like(grad_out, at::kFloat));
   ok(butd_gather_points_grad(grad_out.size(0), grad_out.size(1), n, idx.size(1), grad_out.data_ptr<float>(),
                              idx.data_ptr<int>(), out.data_ptr<float>(), stream_of(grad_out)),
@@ -83,7 +88,7 @@ at::Tensor gather_points_grad(at::Tensor grad_out, at::Tensor idx, const int n) 
 
 // note the argument order: centres first (include/ball_query.h:9-10)
 at::Tensor ball_query(at::Tensor new_xyz, at::Tensor xyz, const float radius, const int nsample) {
-  need({{new_xyz, at::kFloat, "new_xyz"}, {xyz, at::kFloat, "xyz"}});
+  DeviceGuard on_device = need({{new_xyz, at::kFloat, "new_xyz"}, {xyz, at::kFloat, "xyz"}});
   const int b = xyz.size(0), n = xyz.size(1), m = new_xyz.size(1);
   at::Tensor idx = torch::empty({b, m, nsample}, like(new_xyz, at::kInt));
   const size_t ws_bytes = butd_ball_query_workspace_bytes(b, n, m);
@@ -95,7 +100,7 @@ at::Tensor ball_query(at::Tensor new_xyz, at::Tensor xyz, const float radius, co
 }
 
 at::Tensor group_points(at::Tensor points, at::Tensor idx) {   // group_points.cpp:17-39
-  need({{points, at::kFloat, "points"}, {idx, at::kInt, "idx"}});
+  DeviceGuard on_device = need({{points, at::kFloat, "points"}, {idx, at::kInt, "idx"}});
   at::Tensor out = torch::empty({points.size(0), points.size(1), idx.size(1), idx.size(2)}, like(points, at::kFloat));
   ok(butd_group_points(points.size(0), points.size(1), points.size(2), idx.size(1), idx.size(2),
                        points.data_ptr<float>(), idx.data_ptr<int>(), out.data_ptr<float>(), stream_of(points)),
@@ -104,7 +109,7 @@ at::Tensor group_points(at::Tensor points, at::Tensor idx) {   // group_points.c
 }
 
 at::Tensor group_points_grad(at::Tensor grad_out, at::Tensor idx, const int n) {   // group_points.cpp:41-65
-  need({{grad_out, at::kFloat, "grad_out"}, {idx, at::kInt, "idx"}});
+  DeviceGuard on_device = need({{grad_out, at::kFloat, "grad_out"}, {idx, at::kInt, "idx"}});
   at::Tensor out = torch::zeros({grad_out.size(0), grad_out.size(1), n}, like(grad_out, at::kFloat));
   ok(butd_group_points_grad(grad_out.size(0), grad_out.size(1), n, idx.size(1), idx.size(2),
                             grad_out.data_ptr<float>(), idx.data_ptr<int>(), out.data_ptr<float>(),
@@ -114,7 +119,7 @@ at::Tensor group_points_grad(at::Tensor grad_out, at::Tensor idx, const int n) {
 }
 
 std::vector<at::Tensor> three_nn(at::Tensor unknowns, at::Tensor knows) {   // interpolate.cpp:19-46
-  need({{unknowns, at::kFloat, "unknowns"}, {knows, at::kFloat, "knows"}});
+  DeviceGuard on_device = need({{unknowns, at::kFloat, "unknowns"}, {knows, at::kFloat, "knows"}});
   at::Tensor idx = torch::zeros({unknowns.size(0), unknowns.size(1), 3}, like(unknowns, at::kInt));
   at::Tensor dist2 = torch::zeros({unknowns.size(0), unknowns.size(1), 3}, like(unknowns, at::kFloat));
   ok(butd_three_nn(unknowns.size(0), unknowns.size(1), knows.size(1), unknowns.data_ptr<float>(),
@@ -124,7 +129,7 @@ std::vector<at::Tensor> three_nn(at::Tensor unknowns, at::Tensor knows) {   // i
 }
 
 at::Tensor three_interpolate(at::Tensor points, at::Tensor idx, at::Tensor weight) {   // interpolate.cpp:48-76
-  need({{points, at::kFloat, "points"}, {idx, at::kInt, "idx"}, {weight, at::kFloat, "weight"}});
+  DeviceGuard on_device = need({{points, at::kFloat, "points"}, {idx, at::kInt, "idx"}, {weight, at::kFloat, "weight"}});
   at::Tensor out = torch::empty({points.size(0), points.size(1), idx.size(1)}, like(points, at::kFloat));
   ok(butd_three_interpolate(points.size(0), points.size(1), points.size(2), idx.size(1), points.data_ptr<float>(),
                             idx.data_ptr<int>(), weight.data_ptr<float>(), out.data_ptr<float>(), stream_of(points)),
@@ -133,7 +138,7 @@ at::Tensor three_interpolate(at::Tensor points, at::Tensor idx, at::Tensor weigh
 }
 
 at::Tensor three_interpolate_grad(at::Tensor grad_out, at::Tensor idx, at::Tensor weight, const int m) {
-  need({{grad_out, at::kFloat, "grad_out"}, {idx, at::kInt, "idx"}, {weight, at::kFloat, "weight"}});   // interpolate.cpp:78-104
+  DeviceGuard on_device = need({{grad_out, at::kFloat, "grad_out"}, {idx, at::kInt, "idx"}, {weight, at::kFloat, "weight"}});   // interpolate.cpp:78-104
   at::Tensor out = torch::zeros({grad_out.size(0), grad_out.size(1), m}, like(grad_out, at::kFloat));
   ok(butd_three_interpolate_grad(grad_out.size(0), grad_out.size(1), grad_out.size(2), m,
                                  grad_out.data_ptr<float>(), idx.data_ptr<int>(), weight.data_ptr<float>(),

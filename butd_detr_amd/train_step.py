@@ -232,6 +232,13 @@ class FlatAdamW:
             self.segments.append((begin, off, l))
             self.param_groups.append({"params": ps, "lr": l, "weight_decay": weight_decay})
         self.params = [p for g in self.param_groups for p in g["params"]]
+        # (name, offset, numel) of every parameter inside the flat buffers: a checkpoint carries it, so moments
+        # saved under another ordering (e.g. another `pre_boundary_prefixes`) are re-mapped by name, never
+        # silently applied to the wrong parameters
+        names = {id(p): n for n, p in named}
+        base = self.flat_g.data_ptr()
+        self.layout = [(names[id(p)], (v.data_ptr() - base) // 4, p.numel())
+                       for p, v in zip(self.params, self.grad_views)]
         # offset (in floats, a multiple of 4) where the gradients of the first `n_first` parameters end
         self.boundary_offset = ((self.grad_views[self.n_first].data_ptr() - self.flat_g.data_ptr()) // 4
                                 if 0 < self.n_first < len(self.params) else 0)
@@ -313,13 +320,28 @@ class FlatAdamW:
                 "step_count": self.step_count.clone(),
                 "param_groups": [{"lr": g["lr"], "weight_decay": g["weight_decay"],
                                   "numel": sum(p.numel() for p in g["params"])} for g in self.param_groups],
+                "layout": [list(e) for e in self.layout],
                 "betas": self.betas, "eps": self.eps}
 
     def load_state_dict(self, sd):
         if [g["numel"] for g in sd["param_groups"]] != [sum(p.numel() for p in g["params"]) for g in self.param_groups]:
             raise ValueError("FlatAdamW.load_state_dict: parameter groups of a different model")
-        self.flat_m.copy_(sd["flat_m"])
-        self.flat_v.copy_(sd["flat_v"])
+        theirs = [tuple(e) for e in sd.get("layout", [])]
+        if not theirs:
+            raise ValueError("FlatAdamW.load_state_dict: the checkpoint has no parameter layout (saved before the "
+                             "layout was recorded): its moments cannot be matched to parameters safely")
+        strip = lambda n: n[7:] if n.startswith("module.") else n
+        if theirs == self.layout:
+            self.flat_m.copy_(sd["flat_m"])
+            self.flat_v.copy_(sd["flat_v"])
+        else:                                            # same parameters, another ordering: re-map by name
+            mine = {strip(n): (o, m) for n, o, m in self.layout}
+            if sorted((strip(n), m) for n, _, m in theirs) != sorted((n, m) for n, (_, m) in mine.items()):
+                raise ValueError("FlatAdamW.load_state_dict: parameter names / sizes of a different model")
+            for name, off, numel in theirs:
+                o, _ = mine[strip(name)]
+                self.flat_m[o:o + numel].copy_(sd["flat_m"][off:off + numel])
+                self.flat_v[o:o + numel].copy_(sd["flat_v"][off:off + numel])
         self.step_count.copy_(sd["step_count"])
         for g, s_g in zip(self.param_groups, sd["param_groups"]):
             g["lr"], g["weight_decay"] = s_g["lr"], s_g["weight_decay"]
@@ -358,27 +380,43 @@ class FlatGradients:
         grads = [g if g.is_contiguous() else g.contiguous() for g in grads]
         key = tuple(g.data_ptr() for g in grads)
         n = len(grads)
-        if getattr(self, "_gather_host", None) is None:
-            # allocated on the first (eager, warm-up) call: pinned allocations are not capturable
-            self._gather_host = torch.empty(4 * n + 1, dtype=torch.int64).pin_memory()
-            self._gather_table = torch.empty(4 * n + 1, dtype=torch.int64, device=self.flat.device)
-            self._gather_key, self._gather_blocks = None, 0
-        if self._gather_key != key:
+        capturing = torch.cuda.is_current_stream_capturing()
+        # One pointer table per CAPTURE, never rewritten: the captured upload is a node that re-reads its pinned
+        # source at every replay, and several captured signatures (GraphedTrainStep's slots) replay alternately --
+        # a shared table would hand slot A the gradient addresses of slot B.  Eager calls (whose gradient
+        # addresses change from step to step) share one scratch table that is rewritten behind a synchronise.
+        # Pinned allocations are not capturable, so every eager call leaves one spare table for the next capture.
+        if getattr(self, "_gather_tables", None) is None:
+            self._gather_tables, self._gather_spare, self._gather_eager = {}, None, None
+        make = lambda: [torch.empty(4 * n + 1, dtype=torch.int64).pin_memory(),
+                        torch.empty(4 * n + 1, dtype=torch.int64, device=self.flat.device), None, 0]
+        if not capturing:
+            if self._gather_spare is None:
+                self._gather_spare = make()
+            if self._gather_eager is None:
+                self._gather_eager = make()
+            ent = self._gather_eager
+        else:
+            ent = self._gather_tables.get(key)
+            if ent is None:
+                if self._gather_spare is None:
+                    raise RuntimeError("FlatGradients.gather: captured without an eager warm-up call before it "
+                                       "(the pinned pointer table cannot be allocated during a capture)")
+                ent, self._gather_spare = self._gather_spare, None
+                self._gather_tables[key] = ent
+        if ent[2] != key:
             base = self.flat.data_ptr()
             dst = [(v.data_ptr() - base) // 4 for v in self.views]
             numel = [g.numel() for g in grads]
             blk = [0]
             for m in numel:
                 blk.append(blk[-1] + (m + self.GATHER_CHUNK - 1) // self.GATHER_CHUNK)
-            capturing = torch.cuda.is_current_stream_capturing()
             if not capturing:
                 torch.cuda.current_stream(self.flat.device).synchronize()   # an earlier upload may still read it
-            self._gather_host.copy_(torch.tensor(list(key) + dst + numel + blk, dtype=torch.int64))
-            # captured: the upload becomes a node that re-reads the pinned buffer at every replay, so the
-            # buffer must not change afterwards (replays do not run this code)
-            self._gather_table.copy_(self._gather_host, non_blocking=True)
-            self._gather_key, self._gather_blocks = key, blk[-1]
-        table, total = self._gather_table, self._gather_blocks
+            ent[0].copy_(torch.tensor(list(key) + dst + numel + blk, dtype=torch.int64))
+            ent[1].copy_(ent[0], non_blocking=True)
+            ent[2], ent[3] = key, blk[-1]
+        table, total = ent[1], ent[3]
         lib = _hiplib.load()
         with torch.cuda.device(self.flat.device):
             err = lib.butd_gather_segments(n, table.data_ptr(), self.flat.data_ptr(),
@@ -469,7 +507,8 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
-                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=False, token_bucket=None):
+                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=False, token_bucket=None,
+                 max_slots=None, verbose=False):
         import torch.distributed as dist
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
         self.criterion = criterion or surrogate_loss
@@ -482,6 +521,8 @@ class GraphedTrainStep:
         cache = getattr(self._module(), "text_cache", None)
         self.text_outside = bool(self.prefetch_text and cache is not None and cache.cache_in_training)
         self.token_bucket = token_bucket
+        self.max_slots = int(os.environ.get("BUTD_MAX_SLOTS", "8")) if max_slots is None else max_slots
+        self.verbose = verbose or os.environ.get("BUTD_STEP_VERBOSE", "0") == "1"
         self.arena = None
         from . import attention_blocks
         if zero_arena and attention_blocks.get_backend() == "hip":   # only the fused blocks draw from it
@@ -803,12 +844,23 @@ class GraphedTrainStep:
         sig = (tuple(inputs["point_clouds"].shape), tuple(tok["input_ids"].shape))
         if sig != self._sig:
             if sig in self._slots:
-                self._slot = self._slots[sig]
+                self._slot = self._slots.pop(sig)              # (re-inserted below: most recently used last)
                 self._slot.announced = None
             else:
+                # a slot owns graphs, a private memory pool and static buffers (several GB at 8 x 50 000 points):
+                # least recently used signatures are dropped first so a dataset with many token lengths cannot
+                # exhaust HBM (max_slots; `token_bucket` keeps the number of signatures small in the first place)
+                while len(self._slots) >= max(1, self.max_slots):
+                    old_sig = next(iter(self._slots))
+                    torch.cuda.synchronize()                   # its last replay may still run
+                    del self._slots[old_sig]
+                self._slot = None
                 self._capture(inputs, targets, tok)
-                self._slots[sig] = self._slot
                 self._slot.announced = inputs
+                if self.verbose:
+                    print(f"[GraphedTrainStep] captured signature {sig}: {len(self._slots) + 1} slot(s), "
+                          f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB reserved", flush=True)
+            self._slots[sig] = self._slot
             self._sig = sig
         s = self._slot
         self._copy_in(inputs, targets, tok)
