@@ -54,9 +54,9 @@ def parse():
                          "matrix cores, fp32 accumulation (BASELINE configs[3]).  The default run reports the bf16 "
                          "mode as an extra field next to the fp32 headline")
     ap.add_argument("--no-bf16-row", action="store_true")
-    ap.add_argument("--overlap-exchange", action="store_true",
-                    help="N > 1: two-piece capture with the decoder-side gradient bucket all-reduced under the encoder / "
-                         "backbone backward (opt-in: see DESIGN.md section 7, open problem)")
+    ap.add_argument("--no-overlap-exchange", dest="overlap_exchange", action="store_false",
+                    help="N > 1: one graph + ONE all-reduce of the whole packed buffer instead of the default two-piece "
+                         "capture whose decoder-side gradient bucket is all-reduced under the encoder / backbone backward")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="the timed steps rotate over this many different synthetic batches (scene geometry decides "
                          "how much the pruned FPS and the ball query do; one batch replayed is its best case)")

@@ -93,6 +93,8 @@ OPTIM_SYMBOLS = {
     "butd_adamw_flat": (_c_int, [_P] * 4 + [_c_long, _c_long] + [_c_float] * 5 + [_P, _P, _P, _P]),
     "butd_gather_segments": (_c_int, [_c_int, _P, _P, _P, _c_long]),
     "butd_sum_tensors": (_c_int, [_c_int, _P, _c_long, _P, _P]),
+    "butd_clip_workspace_bytes": (ctypes.c_size_t, []),
+    "butd_clip_coefficient": (_c_int, [_P, _c_long, _c_float, _c_float, _P, _P, _P, _P]),
 }
 
 MLP_MAX_SEGMENTS = 8  # BUTD_MLP_MAX_SEGMENTS
@@ -140,6 +142,11 @@ AUGMENT_SYMBOLS = {
     "butd_instance_boxes": (_c_int, [_c_int] * 4 + [_P] * 6 + [_P]),
 }
 
+GRAPH_SYMBOLS = {
+    "butd_graph_replace_memset_nodes": (_c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
+    "butd_graph_node_counts": (_c_int, [_P, ctypes.POINTER(ctypes.c_int * 16)]),
+}
+
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
 ALL_SYMBOLS.update(ATTENTION_SYMBOLS)
 ALL_SYMBOLS.update(SA_SYMBOLS)
@@ -148,6 +155,7 @@ ALL_SYMBOLS.update(MLP_SYMBOLS)
 ALL_SYMBOLS.update(LSAP_SYMBOLS)
 ALL_SYMBOLS.update(CRITERION_SYMBOLS)
 ALL_SYMBOLS.update(AUGMENT_SYMBOLS)
+ALL_SYMBOLS.update(GRAPH_SYMBOLS)
 
 _lib = None
 

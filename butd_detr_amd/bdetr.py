@@ -172,10 +172,21 @@ class BeaUTyDETR(nn.Module):
                 hidden = self.encode_text(tokenized, texts)
             else:
                 hidden = self.text_encoder(**tokenized).last_hidden_state
-        end_points["text_feats"] = self.text_projector(hidden)
+        end_points["text_feats"] = self._project_text(hidden)
         # HF masks are 1 = token; torch attention wants True = padding (bdetr.py:171)
         end_points["text_attention_mask"] = tokenized.attention_mask.ne(1).bool()
         end_points["tokenized"] = tokenized
+
+    def _fused(self, t):
+        return t.is_cuda and attention_blocks.get_backend() == "hip"
+
+    def _project_text(self, hidden):
+        """``text_projector`` = Linear -> LayerNorm -> Dropout (bdetr.py:76-79); the Linear on the grouped GEMM."""
+        if not self._fused(hidden):
+            return self.text_projector(hidden)
+        from .fused_attention import linear
+        lin, norm, drop = self.text_projector
+        return drop(norm(linear(lin, hidden)))
 
     def _run_backbones(self, inputs, tokenized=None):
         """Visual and text towers.  They are independent until the cross-encoder, and the FPS chain of
@@ -189,18 +200,21 @@ class BeaUTyDETR(nn.Module):
         if hidden is not None:          # language model already run (prefetched): projector only
             end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
             self._run_text_tower(tokenized, text_out, hidden)
-        elif pc.is_cuda and self.overlap_text_tower:
+        elif pc.is_cuda and self.overlap_text_tower and self.text_encoder_is_frozen():
+            # only the FROZEN language model is forked (no autograd nodes on the side stream: every node's backward
+            # runs on the stream of its forward, and tensors that cross streams inside autograd are where captured
+            # graphs get their hidden hazards); the trainable projector runs on the main stream after the join
             main = torch.cuda.current_stream(pc.device)
             if self._side_stream is None:
                 self._side_stream = torch.cuda.Stream(pc.device)
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._run_text_tower(tokenized, text_out, texts=inputs.get("text"))
+                hidden = self.encode_text(tokenized, inputs.get("text"))
             end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
             main.wait_stream(side)
-            for v in (text_out["text_feats"], text_out["text_attention_mask"]):
-                v.record_stream(main)
+            hidden.record_stream(main)
+            self._run_text_tower(tokenized, text_out, hidden)
         else:
             end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
             self._run_text_tower(tokenized, text_out, texts=inputs.get("text"))
@@ -251,8 +265,12 @@ class BeaUTyDETR(nn.Module):
         detected_mask = detected_feats = None
         if self.butd:
             detected_mask = ~inputs["det_bbox_label_mask"]
-            class_feats = self.class_embeddings(_embedding_lookup(self.butd_class_embeddings.weight,
-                                                                  inputs["det_class_ids"]))
+            class_feats = _embedding_lookup(self.butd_class_embeddings.weight, inputs["det_class_ids"])
+            if self._fused(class_feats):
+                from .fused_attention import linear
+                class_feats = linear(self.class_embeddings, class_feats)
+            else:
+                class_feats = self.class_embeddings(class_feats)
             detected_feats = torch.cat(
                 [self.box_embeddings(inputs["det_boxes"]), class_feats.transpose(1, 2)], 1
             ).transpose(1, 2).contiguous()                       # (B, D, d)

@@ -2,6 +2,8 @@
 // Bandwidth-trivial kernels (one pass over B x N x 6 floats); the point is that the cloud never leaves HBM.
 // -ffp-contract=off: every numpy step is one rounding.
 #include <hip/hip_runtime.h>
+
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -208,7 +210,7 @@ int butd_instance_boxes(int B, int N, int ldp, int G, const float *pc, const int
   if (B <= 0 || G <= 0) return 0;
   if (ldp < 3) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(scratch, 0, sizeof(uint32_t) * 6 * (size_t)B * G, s);
+  hipError_t e = butd_zero_async(scratch, sizeof(uint32_t) * 6 * (size_t)B * G, s);
   if (e != hipSuccess) return (int)e;
   if (N > 0)
     hipLaunchKernelGGL(instance_hull_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ldp, G, pc, instance,

@@ -28,6 +28,8 @@
 // extents or a non-positive / non-finite radius collapse the axis (or the grid) to one cell: slower,
 // still exact.
 #include <hip/hip_runtime.h>
+
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -387,7 +389,7 @@ int butd_ball_query_ws(int b, int n, int m, float radius, int nsample, const flo
   int *count = (int *)(ws + L.count);
   unsigned *bbox = (unsigned *)(ws + L.bbox);
   SceneGrid *grids = (SceneGrid *)(ws + L.grids);
-  hipError_t e = hipMemsetAsync(count, 0, L.grids - L.count, s);
+  hipError_t e = butd_zero_async(count, L.grids - L.count, s);
   if (e != hipSuccess) return (int)e;
   const dim3 pgrid((n + 255) / 256, b);
   int bbox_blocks = (n + 255) / 256;

@@ -7,6 +7,8 @@
 // Compiled with -ffp-contract=off: the cost tensor feeds an arg-min (the assignment), so its arithmetic
 // follows the reference's separate multiply / add launches.
 #include <hip/hip_runtime.h>
+
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 
@@ -484,7 +486,7 @@ int butd_box_loss_bwd(int P, int B, int Q, int G, const int *match, const float 
                       float *grad_pred, butd_stream_t stream) {
   if (P <= 0 || B <= 0 || Q <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(grad_pred, 0, sizeof(float) * (size_t)P * B * Q * 6, s);
+  hipError_t e = butd_zero_async(grad_pred, sizeof(float) * (size_t)P * B * Q * 6, s);
   if (e != hipSuccess) return (int)e;
   const int total = P * B * G;
   if (total > 0)
@@ -535,7 +537,7 @@ int butd_seed_objectness(int B, int K, int G, int N, int topk, const float *seed
   if (B <= 0 || K <= 0) return 0;
   if (topk < 0 || topk > 32 || G <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(label, 0, (size_t)B * K, s);
+  hipError_t e = butd_zero_async(label, (size_t)B * K, s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(objectness_label_kernel, dim3((unsigned)(B * G)), dim3(kWave), sizeof(float) * K, s, K, G, N,
                      topk, seed_xyz, seed_inds, point_instance_label, gt_center, gt_size, box_mask, label);

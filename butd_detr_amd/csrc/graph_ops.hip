@@ -1,0 +1,96 @@
+// graph_ops.hip -- hipGraph hygiene (include/butd_graph.h): memset nodes -> kernel nodes.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/butd_graph.h"
+
+namespace {
+// value replicated over `width` elements of `esize` bytes in each of `height` rows `pitch` bytes apart
+__global__ __launch_bounds__(256) void memset_node_kernel(unsigned char *dst, unsigned value, unsigned esize,
+                                                          size_t width, size_t height, size_t pitch) {
+  for (size_t row = blockIdx.y; row < height; row += gridDim.y) {
+    unsigned char *p = dst + row * pitch;
+    const size_t bytes = width * esize;
+    unsigned word = value;                                     // the 32-bit pattern of four / two / one element(s)
+    if (esize == 1) word = (value & 0xffu) * 0x01010101u;
+    else if (esize == 2) word = (value & 0xffffu) * 0x00010001u;
+    const size_t head = (16 - ((uintptr_t)p & 15)) & 15;       // (element sizes divide 16: patterns stay in phase)
+    const size_t h = head < bytes ? head : bytes;
+    const size_t n16 = (bytes - h) >> 4;
+    uint4 *q = reinterpret_cast<uint4 *>(p + h);
+    const uint4 w4 = make_uint4(word, word, word, word);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) q[i] = w4;
+    if (blockIdx.x == 0) {
+      const size_t tail = h + (n16 << 4);
+      for (size_t i = threadIdx.x; i < h; i += 256) p[i] = (unsigned char)(word >> (8 * ((((uintptr_t)(p + i)) & 3))));
+      for (size_t i = tail + threadIdx.x; i < bytes; i += 256)
+        p[i] = (unsigned char)(word >> (8 * ((((uintptr_t)(p + i)) & 3))));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int butd_graph_node_counts(void *graph, int counts[16]) {
+  for (int i = 0; i < 16; ++i) counts[i] = 0;
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes((hipGraph_t)graph, nullptr, &n);
+  if (e != hipSuccess) return (int)e;
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n && (e = hipGraphGetNodes((hipGraph_t)graph, nodes.data(), &n)) != hipSuccess) return (int)e;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if ((e = hipGraphNodeGetType(nodes[i], &t)) != hipSuccess) return (int)e;
+    if ((int)t >= 0 && (int)t < 16) counts[(int)t]++;
+  }
+  return 0;
+}
+
+extern "C" int butd_graph_replace_memset_nodes(void *graph_, int *replaced) {
+  hipGraph_t graph = (hipGraph_t)graph_;
+  if (replaced) *replaced = 0;
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+  if (e != hipSuccess) return (int)e;
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n && (e = hipGraphGetNodes(graph, nodes.data(), &n)) != hipSuccess) return (int)e;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if ((e = hipGraphNodeGetType(nodes[i], &t)) != hipSuccess) return (int)e;
+    if (t != hipGraphNodeTypeMemset) continue;
+    hipMemsetParams mp;
+    if ((e = hipGraphMemsetNodeGetParams(nodes[i], &mp)) != hipSuccess) return (int)e;
+    if (mp.elementSize != 1 && mp.elementSize != 2 && mp.elementSize != 4) return (int)hipErrorInvalidValue;
+    size_t nd = 0, nn = 0;
+    if ((e = hipGraphNodeGetDependencies(nodes[i], nullptr, &nd)) != hipSuccess) return (int)e;
+    std::vector<hipGraphNode_t> deps(nd);
+    if (nd && (e = hipGraphNodeGetDependencies(nodes[i], deps.data(), &nd)) != hipSuccess) return (int)e;
+    if ((e = hipGraphNodeGetDependentNodes(nodes[i], nullptr, &nn)) != hipSuccess) return (int)e;
+    std::vector<hipGraphNode_t> next(nn);
+    if (nn && (e = hipGraphNodeGetDependentNodes(nodes[i], next.data(), &nn)) != hipSuccess) return (int)e;
+
+    unsigned char *dst = (unsigned char *)mp.dst;
+    unsigned value = mp.value, esize = mp.elementSize;
+    size_t width = mp.width, height = mp.height ? mp.height : 1, pitch = mp.pitch;
+    void *args[] = {&dst, &value, &esize, &width, &height, &pitch};
+    const size_t bytes = width * esize;
+    size_t bx = ((bytes >> 4) + 255) / 256;
+    if (bx > 1024) bx = 1024;
+    if (bx < 1) bx = 1;
+    hipKernelNodeParams kp = {};
+    kp.func = (void *)memset_node_kernel;
+    kp.gridDim = dim3((unsigned)bx, (unsigned)(height < 1024 ? height : 1024), 1);
+    kp.blockDim = dim3(256, 1, 1);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = args;
+    kp.extra = nullptr;
+    hipGraphNode_t fill;
+    if ((e = hipGraphAddKernelNode(&fill, graph, deps.data(), deps.size(), &kp)) != hipSuccess) return (int)e;
+    for (size_t k = 0; k < nn; ++k)
+      if ((e = hipGraphAddDependencies(graph, &fill, &next[k], 1)) != hipSuccess) return (int)e;
+    if ((e = hipGraphDestroyNode(nodes[i])) != hipSuccess) return (int)e;
+    if (replaced) ++*replaced;
+  }
+  return 0;
+}

@@ -66,6 +66,67 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(int n, const int64
 }
 }  // namespace
 
+// clip_grad_norm_ coefficient of the packed gradient buffer in two launches, without a zero-initialised
+// semaphore or atomics: per-workgroup sums of squares (fp64) into a workspace, then one workgroup folds them.
+namespace {
+constexpr int kClipBlocks = 1024;
+__device__ inline double block_sum_256(double v, double *lds) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return lds[0] + lds[1] + lds[2] + lds[3];
+}
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *__restrict__ g, long n,
+                                                            double *__restrict__ partial) {
+  __shared__ double lds[4];
+  const long n4 = n >> 2;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;     // four independent fp32 chains per lane, folded in fp64
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4 *>(g)[i];
+    a0 = fmaf(v.x, v.x, a0); a1 = fmaf(v.y, v.y, a1); a2 = fmaf(v.z, v.z, a2); a3 = fmaf(v.w, v.w, a3);
+  }
+  double acc = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float t = g[(n & ~3L) + threadIdx.x];
+    acc += (double)t * (double)t;
+  }
+  const double s = block_sum_256(acc, lds);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void clip_finalize_kernel(const double *__restrict__ partial, int blocks,
+                                                            float max_norm, float grad_div,
+                                                            float *__restrict__ grad_scale,
+                                                            float *__restrict__ norm_out) {
+  __shared__ double lds[4];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += 256) acc += partial[i];
+  const double s = block_sum_256(acc, lds);
+  if (threadIdx.x == 0) {
+    const float norm = (float)sqrt(s) / grad_div;
+    float c = max_norm > 0.f ? fminf(max_norm / (norm + 1e-6f), 1.f) : 1.f;
+    if (!(norm == norm)) c = norm;                 // NaN gradients stay visible (torch.clamp propagates NaN)
+    *grad_scale = c / grad_div;
+    if (norm_out) *norm_out = norm;
+  }
+}
+}  // namespace
+
+extern "C" size_t butd_clip_workspace_bytes(void) { return kClipBlocks * sizeof(double); }
+
+extern "C" int butd_clip_coefficient(const float *g, long n, float max_norm, float grad_div, void *workspace,
+                                     float *grad_scale, float *norm_out, butd_stream_t stream) {
+  if (n < 0 || !workspace || !grad_scale || !(grad_div > 0.f)) return (int)hipErrorInvalidValue;
+  if ((uintptr_t)g & 15) return (int)hipErrorInvalidValue;
+  long blocks = ((n >> 2) + 255) / 256;
+  if (blocks > kClipBlocks) blocks = kClipBlocks;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, n,
+                     (double *)workspace);
+  hipLaunchKernelGGL(clip_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double *)workspace,
+                     (int)blocks, max_norm, grad_div, grad_scale, norm_out);
+  return (int)hipGetLastError();
+}
+
 extern "C" int butd_gather_segments(int n, const int64_t *table, float *dst, butd_stream_t stream,
                                     long total_blocks) {
   if (n <= 0 || total_blocks <= 0) return 0;

@@ -13,6 +13,8 @@
 //                                 lane, coalesced), v_cmp mask + popcount = ordered compaction.
 //   gather/group/interpolate      bandwidth kernels, coalesced on the index/output side.
 #include <hip/hip_runtime.h>
+
+#include "zero_fill.h"
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -499,7 +501,7 @@ int butd_ball_query(int b, int n, int m, float radius, int nsample, const float 
                     const float *xyz, int *idx, butd_stream_t stream) {
   if (b <= 0 || m <= 0 || nsample <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (n <= 0) return (int)hipMemsetAsync(idx, 0, sizeof(int) * (size_t)b * m * nsample, s);
+  if (n <= 0) return (int)butd_zero_async(idx, sizeof(int) * (size_t)b * m * nsample, s);
   const float radius2 = radius * radius;  // ball_query_gpu.cu:27 (fp32 product)
   // centres per wave: as many as keep >= ~2 waves per SIMD busy (1024 SIMDs), at most 8
   const long long total = (long long)b * m;

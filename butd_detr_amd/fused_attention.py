@@ -421,6 +421,18 @@ def linear_relu_chain(seq, x):
     return _LinearReluChain.apply(x, *params)
 
 
+def linear(lin, x):
+    """``nn.Linear`` on the grouped GEMM (bias in the epilogue; weight AND bias gradient from one split-K product
+    with a ones column).  Besides the launch count this keeps torch's ``sum`` for the bias gradient out of the
+    captured step: a multi-block torch reduction zeroes its semaphore with hipMemsetAsync, i.e. a MEMSET node
+    (graph_audit.py)."""
+    if (not x.is_cuda or x.dtype != torch.float32 or lin.in_features % 4 or lin.out_features % 4):
+        return lin(x)
+    x = x.contiguous()
+    _check(x)
+    return _LinearReluChain.apply(x, lin.weight, lin.bias)
+
+
 def _as_mask(mask):
     if mask is None:
         return None

@@ -1,0 +1,47 @@
+"""hipGraph hygiene of the captured training step (include/butd_graph.h).
+
+Why it exists: on ROCm 7.2 a MEMSET node of a replayed hipGraph is unreliable --
+replayed behind a still-running graph (any size), or simply a second time (multi-megabyte ranges), it writes a
+garbage pattern instead of its value (scratch/graph_node_order.py; correct with
+``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0``).  Every captured ``hipMemsetAsync`` is affected, e.g. the semaphore reset of
+torch's multi-block reductions (ATen/native/cuda/Reduce.cuh): ``vector_norm`` of the packed gradient buffer then
+never wrote its result, the clip coefficient became 1.0 and the update was applied unclipped -- round 2's
+"free-running divergence".  The training step therefore (i) issues no hipMemsetAsync of its own (csrc/zero_fill.h),
+(ii) rewrites the memset nodes torch ops leave in a captured graph into kernel nodes (``make_safe``), and
+(iii) checks that none is left (``inventory``).
+"""
+import collections
+import ctypes
+
+from . import _hiplib
+
+NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
+              7: "event_record", 8: "ext_sem_signal", 9: "ext_sem_wait", 10: "mem_alloc", 11: "mem_free",
+              12: "memcpy_from_symbol", 13: "memcpy_to_symbol"}
+
+
+def new_graph():
+    """A ``torch.cuda.CUDAGraph`` whose hipGraph_t stays accessible after capture (instantiated at first replay)."""
+    import torch
+    return torch.cuda.CUDAGraph(keep_graph=True)
+
+
+def inventory(cuda_graph):
+    """Counter of node kinds of a captured ``new_graph()``."""
+    counts = (ctypes.c_int * 16)()
+    _hiplib.check(_hiplib.load().butd_graph_node_counts(cuda_graph.raw_cuda_graph(), ctypes.byref(counts)),
+                  "butd_graph_node_counts")
+    return collections.Counter({NODE_TYPES.get(i, f"type{i}"): c for i, c in enumerate(counts) if c})
+
+
+def make_safe(cuda_graph):
+    """Rewrite the memset nodes of a captured, not yet replayed ``new_graph()`` into kernel nodes; returns how many
+    were rewritten and raises if any memset node is left."""
+    n = ctypes.c_int(0)
+    _hiplib.check(_hiplib.load().butd_graph_replace_memset_nodes(cuda_graph.raw_cuda_graph(), ctypes.byref(n)),
+                  "butd_graph_replace_memset_nodes")
+    left = inventory(cuda_graph).get("memset", 0)
+    if left:
+        raise RuntimeError(f"{left} memset node(s) left in a captured graph: replaying it is unsafe on this ROCm "
+                           "(butd_detr_amd/graph_audit.py)")
+    return n.value

@@ -245,6 +245,7 @@ class FlatAdamW:
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.step_count = torch.zeros(1, device=dev)
         self.grad_scale = torch.ones(1, device=dev)
+        self._clip_ws, self.grad_norm = None, None
         # {lr, weight_decay} per group on the device: the kernel reads them, so a captured step follows
         # whatever a scheduler writes into param_groups (main_utils.py:438 steps one every iteration)
         self.hyper = torch.zeros(len(self.param_groups), 2, device=dev)
@@ -276,7 +277,22 @@ class FlatAdamW:
     def clip_(self, max_norm, grad_div=1.0):
         """clip_grad_norm_ on the flat gradient buffer: only the coefficient is computed here.  ``grad_div``:
         the buffer holds the SUM over that many ranks (the all-reduce's division is folded into the
-        coefficient the kernel applies anyway: one pass over the 85.7 MB less)."""
+        coefficient the kernel applies anyway: one pass over the 85.7 MB less).  On the device this is
+        ``butd_clip_coefficient`` (two launches, no semaphore): ``torch.linalg.vector_norm`` of a 21 M-element
+        buffer is a multi-block reduction that relies on a memset of its semaphore inside the captured graph,
+        and replayed behind a still-running graph it intermittently left the norm unwritten -> coefficient 1.0
+        -> an unclipped update (the round-2 "free-running" divergence)."""
+        if self.flat_g.is_cuda:
+            if self._clip_ws is None:
+                self._clip_ws = torch.empty(int(self._lib.butd_clip_workspace_bytes()), dtype=torch.uint8,
+                                            device=self.flat_g.device)
+                self.grad_norm = torch.zeros(1, device=self.flat_g.device)
+            err = self._lib.butd_clip_coefficient(
+                self.flat_g.data_ptr(), self.flat_g.numel(), float(max_norm), float(grad_div),
+                self._clip_ws.data_ptr(), self.grad_scale.data_ptr(), self.grad_norm.data_ptr(),
+                torch.cuda.current_stream(self.flat_g.device).cuda_stream)
+            self._check(err, "butd_clip_coefficient")
+            return self.grad_norm[0]
         norm = torch.linalg.vector_norm(self.flat_g) / grad_div
         torch.clamp(max_norm / (norm + 1e-6), max=1.0, out=self.grad_scale[0])
         if grad_div != 1.0:
@@ -487,9 +503,8 @@ class GraphedTrainStep:
     encoder outputs, 1b = backward through the encoder and the backbone.  The decoder-side bucket (the first
     ``optimizer.boundary_offset`` floats, ~60 % of the 85.7 MB) is all-reduced asynchronously while 1b
     replays, the rest after it -- DistributedDataParallel's bucket overlap (main_utils.py:310-313) with two
-    buckets and no per-parameter hooks.  OPT-IN (default off) since the end of round 2: free-running, the two-piece
-    step trained measurably worse than the single-graph step although each replay is right (open
-    problem); with it on, the host waits for the previous step before enqueueing the next.
+    buckets and no per-parameter hooks.  The default whenever gradients are exchanged (world size > 1);
+    ``overlap_exchange=False`` keeps the single graph + one all-reduce of the whole buffer.
 
     Shapes are static: every (batch, points, tokens) signature is captured once and cached.  The reference
     pads the utterances to the longest of the batch (bdetr.py:160-163), and its contrastive loss takes a
@@ -507,7 +522,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
-                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=False, token_bucket=None,
+                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=True, token_bucket=None,
                  max_slots=None, verbose=False):
         import torch.distributed as dist
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
@@ -743,22 +758,34 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self._restore(snap)
         torch.cuda.synchronize()
+        # graphs keep their hipGraph_t until the first replay: memset nodes (hipMemsetAsync of a stock torch op, e.g.
+        # the semaphore reset of a multi-block reduction) are rewritten into kernel nodes first -- replayed memset
+        # nodes are unreliable on ROCm 7.2 (graph_audit.py)
+        from . import graph_audit
+        s.graphs = {}
         if self.split:
-            s.g_stage1 = torch.cuda.CUDAGraph()
+            s.g_stage1 = s.graphs["stage1"] = graph_audit.new_graph()
             with torch.cuda.graph(s.g_stage1, capture_error_mode=self._capture_mode):
                 s.loss = self._stage1()
-            s.g_stage2 = torch.cuda.CUDAGraph()
+            s.g_stage2 = s.graphs["stage2"] = graph_audit.new_graph()
             with torch.cuda.graph(s.g_stage2, pool=s.g_stage1.pool(), capture_error_mode=self._capture_mode):
                 self._stage2()
             pool = s.g_stage1.pool()
         else:
-            s.g_fwd_bwd = torch.cuda.CUDAGraph()
+            s.g_fwd_bwd = s.graphs["fwd_bwd"] = graph_audit.new_graph()
             with torch.cuda.graph(s.g_fwd_bwd, capture_error_mode=self._capture_mode):
                 s.loss = self._fwd_bwd()
             pool = s.g_fwd_bwd.pool()
-        s.g_update = torch.cuda.CUDAGraph()
+        s.g_update = s.graphs["update"] = graph_audit.new_graph()
         with torch.cuda.graph(s.g_update, pool=pool, capture_error_mode=self._capture_mode):
             self._update()
+        if os.environ.get("BUTD_GRAPH_REWRITE", "1") == "0":      # debug hook: leave the memset nodes in place
+            s.memset_nodes_rewritten = {k: 0 for k in s.graphs}
+        else:
+            s.memset_nodes_rewritten = {k: graph_audit.make_safe(g) for k, g in s.graphs.items()}
+        s.node_inventory = {k: dict(graph_audit.inventory(g)) for k, g in s.graphs.items()}
+        for g in s.graphs.values():
+            g.instantiate()
         # the captures above ran the optimizer once more under capture semantics only (nothing executed)
 
     def _pad_tokens(self, tok):
@@ -828,12 +855,11 @@ class GraphedTrainStep:
         return self._pad_tokens(BatchEncoding(out))
 
     def __call__(self, inputs, targets, next_inputs=None):
-        # The host may not run a whole step ahead of the device in the two-piece (overlapped exchange) step: on a
-        # 90-step soak the free-running two-piece step ended 0.8 loss units away from the same step with this wait
-        # (and from the single-graph step), although every replay's gradients equal the eager ones (DESIGN.md section 7,
-        # open observation).  BUTD_STEP_SYNC=0 / 1 overrides (default: only the two-piece step waits).
-        sync = os.environ.get("BUTD_STEP_SYNC")
-        if sync == "1" or (sync is None and self.split):
+        # BUTD_STEP_SYNC=1 (debug hook): wait for the previous step before enqueueing this one.  Round 2 needed it for
+        # the two-piece step; the cause was a replayed MEMSET node (torch's vector_norm semaphore) -- gone since the
+        # clip coefficient is butd_clip_coefficient and captured graphs are scrubbed of memset nodes (graph_audit.py),
+        # pinned by tests/test_gpu_free_running.py.
+        if os.environ.get("BUTD_STEP_SYNC") == "1":
             torch.cuda.current_stream().synchronize()
         # host work stays in the step; a batch announced by the previous call was tokenised then
         cache = getattr(self, "_tok_cache", None)
@@ -859,7 +885,8 @@ class GraphedTrainStep:
                 self._slot.announced = inputs
                 if self.verbose:
                     print(f"[GraphedTrainStep] captured signature {sig}: {len(self._slots) + 1} slot(s), "
-                          f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB reserved", flush=True)
+                          f"{torch.cuda.memory_reserved() / 2**30:.1f} GiB reserved; nodes {self._slot.node_inventory}; "
+                          f"memset nodes rewritten {self._slot.memset_nodes_rewritten}", flush=True)
             self._slots[sig] = self._slot
             self._sig = sig
         s = self._slot

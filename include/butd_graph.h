@@ -1,0 +1,28 @@
+/*
+ * butd_graph.h -- C ABI of the hipGraph hygiene pass of the training step (gfx950, ROCm 7.2).
+ *
+ * The reference's step is eager PyTorch (main_utils.py:415-438); this build replays it as hipGraphs
+ * (butd_detr_amd/train_step.py).  On ROCm 7.2 a MEMSET node of a replayed graph is unreliable: replayed behind a
+ * still-running graph (any size) or a second time (multi-megabyte ranges) it writes a garbage pattern instead of
+ * its value (scratch/graph_node_order.py) -- which silently breaks every captured
+ * hipMemsetAsync, e.g. the semaphore reset of torch's multi-block reductions.  Kernel and memcpy nodes are sound.
+ */
+#ifndef BUTD_GRAPH_H
+#define BUTD_GRAPH_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Rewrites every MEMSET node of `graph` (a hipGraph_t that has not been instantiated yet) into a KERNEL node with
+ * the same destination, value, element size (1, 2 or 4 bytes), width, height and pitch, the same dependencies and
+ * the same dependents, and destroys the memset node.  *replaced receives the number of rewritten nodes.
+ * Returns 0 or a hipError_t. */
+int butd_graph_replace_memset_nodes(void *graph, int *replaced);
+
+/* Number of nodes of `graph` by hipGraphNodeType (counts[0..15], others ignored). */
+int butd_graph_node_counts(void *graph, int counts[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

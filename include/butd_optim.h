@@ -26,6 +26,18 @@ int butd_adamw_flat(float *p, const float *g, float *m, float *v, long begin, lo
                     float beta1, float beta2, float eps, float weight_decay, const float *step,
                     const float *grad_scale, const float *hyper, butd_stream_t stream);
 
+/* clip_grad_norm_ (main_utils.py:432-436) on the packed gradient buffer g[0:n): writes the coefficient the AdamW
+ * kernel applies,
+ *   norm = ||g||_2 / grad_div;   *grad_scale = min(max_norm / (norm + 1e-6), 1) / grad_div   (max_norm <= 0: 1 / grad_div)
+ * (grad_div: the buffer holds the SUM over that many ranks), and the norm itself to *norm_out (may be NULL).
+ * Two launches: per-workgroup fp64 sums of squares into `workspace` (butd_clip_workspace_bytes() bytes, no
+ * initialisation needed), then one workgroup folds them -- no zero-initialised semaphore, no atomics, so the
+ * result does not depend on a memset having run (torch's multi-block reduction inside a
+ * replayed hipGraph). */
+size_t butd_clip_workspace_bytes(void);
+int butd_clip_coefficient(const float *g, long n, float max_norm, float grad_div, void *workspace,
+                          float *grad_scale, float *norm_out, butd_stream_t stream);
+
 /* Gradient packing: dst[dst_off[i] : dst_off[i] + numel[i]) = src[i][0 : numel[i]) for n segments in ONE
  * launch (the step gathers ~330 freshly produced parameter gradients into the flat all-reduce / AdamW
  * buffer; torch's multi-tensor copy takes 10 launches and 0.28 ms for the 85.7 MB).  table: device int64

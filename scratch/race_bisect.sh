@@ -1,15 +1,9 @@
 #!/bin/bash
-# round 3: bisect of the free-running divergence over the debug hooks
 cd /root/repo
-export STOCK_DROPOUT=0 STEPS=60
-run() { echo "== $*"; env "$@" timeout 300 python scratch/soak_cfg.py 2>&1 | tail -1; }
-run TAG=A_default
-run TAG=B_fo0 BUTD_FAN_OUT=0
-run TAG=C_fo0_sync BUTD_FAN_OUT=0 BUTD_STEP_SYNC=1
-run TAG=D_fo0_nofork BUTD_FAN_OUT=0 BUTD_ENCODER_FORK=0
-run TAG=E_split_free SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=0
-run TAG=F_split_free_nofork SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=0 BUTD_ENCODER_FORK=0
-run TAG=G_split_nopre_free SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=0 PS=0 PT=0
-run TAG=H_split_nopre_free_nofork SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=0 PS=0 PT=0 BUTD_ENCODER_FORK=0 BUTD_TEXT_OVERLAP=0
-run TAG=I_split_nopre_sync SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=1 PS=0 PT=0
-run TAG=J_split_nopre_sync_nofork SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=1 PS=0 PT=0 BUTD_ENCODER_FORK=0 BUTD_TEXT_OVERLAP=0
+export BUTD_STEP_VERBOSE=1
+run() { echo "== $*"; env "$@" timeout 300 python scratch/race_probe3.py > /tmp/o.txt 2>&1; grep -E "LR0|loss seq|GraphedTrainStep|fault" /tmp/o.txt | cut -c1-600; grep -qE "LR0|loss seq" /tmp/o.txt || tail -8 /tmp/o.txt; }
+run TAG=S1_inline LR0=1 PS=0 PT=0
+run TAG=S1b_inline_split LR0=1 PS=0 PT=0 SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=0
+run TAG=S1c_inline_notextov_nofork_split LR0=1 PS=0 PT=0 SPLIT=1 OVERLAP=1 BUTD_STEP_SYNC=0 BUTD_ENCODER_FORK=0 BUTD_TEXT_OVERLAP=0
+unset BUTD_STEP_VERBOSE
+timeout 1800 python -m pytest tests/test_gpu_free_running.py -x -q -s > /tmp/t.log 2>&1; grep -v "^  File\|^Extension" /tmp/t.log | tail -40
