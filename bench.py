@@ -75,6 +75,7 @@ def build_model(args, device):
     # fallback); the stock-torch blocks only run when asked for by name (--backend torch, the A/B leg)
     backend = "hip" if args.backend == "auto" else args.backend
     attention_blocks.set_backend(backend)
+    attention_blocks.set_strict(backend == "hip")     # a level that would fall back to stock torch raises
     torch.manual_seed(0)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")

@@ -35,6 +35,26 @@ def get_backend():
     return _BACKEND
 
 
+_STRICT = False
+
+
+def set_strict(flag):
+    """With the 'hip' backend: raise instead of silently running a set-abstraction level or a feature-propagation
+    MLP on the stock-torch ops when the fused path does not cover its configuration (bench.py and the timed-shape
+    tests set it, so a fallback cannot hide behind a green run).  Returns the previous setting."""
+    global _STRICT
+    prev, _STRICT = _STRICT, bool(flag)
+    return prev
+
+
+def fell_back(what, module):
+    """Called by a module that takes its stock-torch path while the 'hip' backend is selected."""
+    module.last_path = "torch"
+    if _STRICT:
+        raise RuntimeError(f"{what}: the fused gfx950 path does not cover this configuration and strict mode is on "
+                           "(attention_blocks.set_strict)")
+
+
 def new_step(device):
     """Called once per model forward: advances the fused kernels' dropout step counter."""
     if _BACKEND == "hip" and torch.device(device).type == "cuda":

@@ -71,7 +71,10 @@ class PointnetSAModuleVotes(nn.Module):
                 features_pm, feat_offset = features.transpose(1, 2).contiguous(), 0
             new_features, self.last_features_pm = fused_sa.sa_mlp_pool(
                 self, xyz, new_xyz, idx, features_pm, feat_offset)
+            self.last_path = "fused"
             return new_xyz, new_features, inds
+        if attention_blocks.get_backend() == "hip" and xyz.is_cuda:
+            attention_blocks.fell_back("PointnetSAModuleVotes", self)
         grouped = self.grouper(xyz, new_xyz, features)
         if self.ret_unique_cnt:
             grouped_features, grouped_xyz, unique_cnt = grouped
@@ -113,7 +116,10 @@ class PointnetFPModule(nn.Module):
             b, c, n = interpolated.shape
             x_pm = interpolated.transpose(1, 2).reshape(b * n, c)
             out = mlp_chains(x_pm, [([(l.conv, l.bn.bn) for l in self.mlp], None, 0.0)], self.training)[0]
+            self.last_path = "fused"
             return out.view(b, n, -1).transpose(1, 2)
+        if attention_blocks.get_backend() == "hip" and interpolated.is_cuda:
+            attention_blocks.fell_back("PointnetFPModule", self)
         return self.mlp(interpolated.unsqueeze(-1)).squeeze(-1)
 
     def _chain_ok(self):

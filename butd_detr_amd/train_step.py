@@ -24,10 +24,13 @@ from .offline_text import synthetic_utterances
 PREFIXES = ("proposal_", "0head_", "1head_", "2head_", "3head_", "4head_", "last_")
 
 
-def synthetic_batch(batch, device, *, seed=1184, n_points=50000, tokens=80, rank=0, max_targets=16):
-    """The ``inputs`` dict of train_dist_mod.py:103-110 for ``batch`` scenes (rank-dependent seeds)."""
+def synthetic_batch(batch, device, *, seed=1184, n_points=50000, tokens=80, rank=0, max_targets=16,
+                    dense_cluster=False):
+    """The ``inputs`` dict of train_dist_mod.py:103-110 for ``batch`` scenes (rank-dependent seeds).
+    ``dense_cluster``: one piece of furniture shrunk to a quarter of its size and sampled 10x as densely
+    (irregular density)."""
     base = seed + 1000 * rank
-    pc = synthetic_scenes.scene_batch(batch, base, n_points)
+    pc = synthetic_scenes.scene_batch(batch, base, n_points, dense_cluster=dense_cluster)
     boxes, mask, cls = synthetic_scenes.detected_boxes(batch, seed=base)
     rng = np.random.default_rng(base + 99)
     targets = {

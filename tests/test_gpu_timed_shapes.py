@@ -185,6 +185,7 @@ def test_config2_model_train_mode_hip_vs_torch():
         outs = {}
         for name, model, backend in (("torch", ref, "torch"), ("hip", fused, "hip")):
             attention_blocks.set_backend(backend)
+            attention_blocks.set_strict(backend == "hip")          # a silent stock-torch fallback raises
             ep = model(inputs)
             loss = surrogate_loss(ep, targets)
             loss.backward()
@@ -192,6 +193,13 @@ def test_config2_model_train_mode_hip_vs_torch():
                           {n: p.grad for n, p in model.named_parameters() if p.grad is not None})
         ep_t, loss_t, g_t = outs["torch"]
         ep_h, loss_h, g_h = outs["hip"]
+        # every set-abstraction level and both feature-propagation MLPs took the fused gfx950 path
+        for lvl in ("sa1", "sa2", "sa3", "sa4"):
+            sa = getattr(fused.backbone_net, lvl)
+            assert sa.last_features_pm is not None and sa.last_path == "fused", lvl
+        for lvl in ("fp1", "fp2"):
+            fp = getattr(fused.backbone_net, lvl)
+            assert fp._chain_ok() and fp.last_path == "fused", lvl
         assert ep_h["last_sem_cls_scores"].shape == (8, 256, 256) and ep_h["text_feats"].shape[1] == 80
         for key in ("sa1_inds", "sa2_inds", "fp2_inds", "seed_inds"):
             assert torch.equal(ep_h[key], ep_t[key]), key
@@ -215,6 +223,56 @@ def test_config2_model_train_mode_hip_vs_torch():
                   "prediction_heads.4.center_residual_head.net.0.weight", "text_projector.0.weight"):
             _close(g_h[n], g_t[n], 1e-2 if n.startswith("backbone_net") else 3e-3, n, frac=1e-3)
     finally:
+        attention_blocks.set_strict(False)
+        attention_blocks.set_backend("torch")
+
+
+def test_six_encoder_layers_hip_vs_torch():
+    """BASELINE configs[2] words the encoder as "6-layer BiEncoder" (the reference hard-codes 3, bdetr.py:104):
+    the same comparison with ``num_encoder_layers=6`` (2 scenes x 50 000 points, train mode, dropout 0)."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from butd_detr_amd.offline_text import offline_factory
+    from butd_detr_amd.train_step import surrogate_loss, synthetic_batch
+    from tests.golden.cases import zero_dropout
+    try:
+        torch.manual_seed(0)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=256,
+                             num_decoder_layers=6, num_encoder_layers=6, self_position_embedding="loc_learned",
+                             contrastive_align_loss=True, butd=True, self_attend=True,
+                             text_encoder_factory=offline_factory(0)).cuda()
+        assert len(ref.cross_encoder.layers) == 6
+        zero_dropout(ref.train())
+        fused = copy.deepcopy(ref)
+        inputs, targets = synthetic_batch(2, torch.device("cuda", 0), seed=1190, n_points=50000, tokens=80)
+        outs = {}
+        for name, model, backend in (("torch", ref, "torch"), ("hip", fused, "hip")):
+            attention_blocks.set_backend(backend)
+            attention_blocks.set_strict(backend == "hip")
+            ep = model(inputs)
+            loss = surrogate_loss(ep, targets)
+            loss.backward()
+            outs[name] = (ep, float(loss.detach()),
+                          {n: p.grad for n, p in model.named_parameters() if p.grad is not None})
+        ep_t, loss_t, g_t = outs["torch"]
+        ep_h, loss_h, g_h = outs["hip"]
+        for key in ("seed_features", "text_memory", "seeds_obj_cls_logits", "proj_tokens"):
+            _close(ep_h[key], ep_t[key], 1e-3, key)
+        for pre in ("proposal_", "2head_", "last_"):
+            for k in ("center", "pred_size", "sem_cls_scores", "proj_queries"):
+                _close(ep_h[pre + k], ep_t[pre + k], 1e-3, pre + k, frac=1e-2)
+        assert abs(loss_h - loss_t) <= 1e-3 * max(abs(loss_t), 1.0)
+        assert set(g_h) == set(g_t)
+        for n in ("cross_encoder.layers.0.self_attention_visual.self_attn.in_proj_weight",
+                  "cross_encoder.layers.3.cross_layer.cross_lv.in_proj_weight",
+                  "cross_encoder.layers.5.cross_layer.ffn_vl.0.weight",
+                  "cross_encoder.layers.5.self_attention_lang.self_attn.out_proj.weight",
+                  "decoder.5.cross_v.in_proj_weight", "text_projector.0.weight"):
+            _close(g_h[n], g_t[n], 3e-3, n, frac=1e-3)
+    finally:
+        attention_blocks.set_strict(False)
         attention_blocks.set_backend("torch")
 
 
