@@ -1,0 +1,98 @@
+"""TEST helper (round 3, review item 8): where does the fused path lose gradient precision on the train-mode 3+6-layer golden
+model?  Truth = the same modules in float64 on the CPU (index ops from the oracle, gather / group / interpolate in
+torch double); compared: stock torch fp32 on the GPU, the fused gfx950 path.  Queries pinned to the truth's top-k."""
+import os, sys, warnings, types
+import numpy as np, torch
+from butd_detr_amd import attention_blocks, pointnet2_utils
+from butd_detr_amd.bdetr import BeaUTyDETR
+from tests.golden import text_stub, weights
+from tests.golden.cases import bdetr_inputs, train_loss, zero_dropout
+from oracle import ext_adapter as orc_ext
+
+
+class Ext64:
+    """pointnet2._ext surface for float64 CPU tensors: index ops by the fp32 oracle, data movement in double."""
+    furthest_point_sampling = staticmethod(lambda p, n: orc_ext.furthest_point_sampling(p.float(), n))
+    ball_query = staticmethod(lambda c, x, r, ns: orc_ext.ball_query(c.float(), x.float(), r, ns))
+
+    @staticmethod
+    def three_nn(u, k):
+        d, i = orc_ext.three_nn(u.float(), k.float())
+        return [d.to(u.dtype), i]
+
+    @staticmethod
+    def gather_points(p, idx):
+        return torch.gather(p, 2, idx.long()[:, None, :].expand(-1, p.shape[1], -1))
+
+    @staticmethod
+    def gather_points_grad(g, idx, n):
+        out = torch.zeros(g.shape[0], g.shape[1], n, dtype=g.dtype)
+        return out.scatter_add_(2, idx.long()[:, None, :].expand(-1, g.shape[1], -1), g)
+
+    @staticmethod
+    def group_points(p, idx):
+        b, m, s = idx.shape
+        return Ext64.gather_points(p, idx.reshape(b, m * s)).view(b, p.shape[1], m, s)
+
+    @staticmethod
+    def group_points_grad(g, idx, n):
+        b, m, s = idx.shape
+        return Ext64.gather_points_grad(g.reshape(b, g.shape[1], m * s), idx.reshape(b, m * s), n)
+
+    @staticmethod
+    def three_interpolate(p, idx, w):
+        b, n, _ = idx.shape
+        return (Ext64.gather_points(p, idx.reshape(b, n * 3)).view(b, p.shape[1], n, 3) * w[:, None]).sum(-1)
+
+    @staticmethod
+    def three_interpolate_grad(g, idx, w, m):
+        b, n, _ = idx.shape
+        return Ext64.gather_points_grad((g[..., None] * w[:, None]).reshape(b, g.shape[1], n * 3), idx.reshape(b, n * 3), m)
+
+
+FIXED = {}
+
+
+def pinned_queries(self, xyz, features, end_points, features_pm=None):
+    logits = self.points_obj_cls(features, features_pm=features_pm)
+    end_points["seeds_obj_cls_logits"] = logits
+    if "inds" not in FIXED:
+        FIXED["inds"] = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int().cpu()
+    xyz, features, sample_inds = self.gsample_module(xyz, features, FIXED["inds"].to(logits.device))
+    end_points["query_points_xyz"], end_points["query_points_feature"] = xyz, features
+    end_points["query_points_sample_inds"] = sample_inds
+    return end_points
+
+
+def build():
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=82, num_decoder_layers=6,
+                       self_position_embedding="loc_learned", contrastive_align_loss=True, butd=True, pointnet_ckpt=None,
+                       self_attend=True, text_encoder_factory=text_stub.factory, class_embeddings_path="/nonexistent")
+    weights.fill_(m, seed=15, skip_prefixes=("text_encoder.",))
+    m._generate_queries = types.MethodType(pinned_queries, m)
+    return zero_dropout(m.train())
+
+
+def run(dev, dtype, backend):
+    attention_blocks.set_backend(backend)
+    if dev == "cpu":
+        pointnet2_utils._ext = Ext64
+    else:
+        from butd_detr_amd import pointnet2_ext
+        pointnet2_utils._ext = pointnet2_ext
+    model = build().to(dev)
+    if dtype == torch.float64:
+        model = model.double()
+        enc = model.text_encoder
+        fwd = enc.forward
+        enc.forward = lambda **kw: types.SimpleNamespace(last_hidden_state=fwd(**kw).last_hidden_state.double())
+    inp = {k: (v.to(dev).to(dtype) if torch.is_tensor(v) and v.is_floating_point() else (v.to(dev) if torch.is_tensor(v) else v))
+           for k, v in bdetr_inputs().items()}
+    ep = model(inp)
+    train_loss(ep).backward()
+    return {n: p.grad.detach().double().cpu() for n, p in model.named_parameters() if p.grad is not None}, \
+           {k: v.detach().double().cpu() for k, v in ep.items() if torch.is_tensor(v) and v.is_floating_point()}
+
+

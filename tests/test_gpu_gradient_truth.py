@@ -1,0 +1,47 @@
+"""-m gpu: gradient precision of the fused path measured against a float64 run of the same modules.
+
+Round 2 compared gradients of the train-mode 3+6-layer model with the CPU-fp32 reference golden and saw the fused
+path at 1.6e-2 where stock torch on the GPU sat at 4e-3 -- "a 4x error nobody has located".  Against float64
+(profiles/r03_gradient_error_vs_fp64.txt) the picture is: EVERY fp32 implementation of this model, stock torch
+included, is 0.5-1.6e-2 (of a tensor's largest gradient) away from the truth on the last decoder layer; the fused path
+is within ~2x of stock torch block by block; what is left are isolated discrete decisions -- a ReLU gate or a max-pool
+winner of ONE channel deciding the other way for a pre-activation within rounding of zero -- which move that channel's
+gradients by 1e-2..1e-1 (5 such channels among ~2 M gated activations; stock torch: 0-1).  Pinned here: the typical
+(mean) error per parameter, the worst error per parameter outside a small budget of such flips."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fused_gradients_against_float64_truth():
+    from butd_detr_amd import attention_blocks, pointnet2_ext, pointnet2_utils
+    from tests import grad_truth
+    try:
+        grad_truth.FIXED.clear()
+        truth, _ = grad_truth.run("cpu", torch.float64, "torch")
+        torch32, _ = grad_truth.run("cuda", torch.float32, "torch")
+        hip32, ep = grad_truth.run("cuda", torch.float32, "hip")
+    finally:
+        attention_blocks.set_backend("torch")
+        pointnet2_utils._ext = pointnet2_ext
+    top = max(float(t.abs().max()) for t in truth.values())
+    flips, checked = [], 0
+    for n, t in truth.items():
+        scale = float(t.abs().max())
+        if scale < 1e-6 * top:            # a bias in front of a BatchNorm: the true gradient is exactly 0
+            continue
+        checked += 1
+        eh = (hip32[n] - t).abs() / scale
+        et = (torch32[n] - t).abs() / scale
+        # typical error: within 3x of stock torch (+ a floor for tensors torch happens to get to the last bit;
+        # observed worst: 2.5x on SA1's first BatchNorm weight, a sum over 262 144 grouped rows)
+        assert float(eh.mean()) <= 3.0 * float(et.mean()) + 5e-4, (n, float(eh.mean()), float(et.mean()))
+        if float(eh.max()) > max(3.0 * float(et.max()), 6e-3):
+            flips.append((n, float(eh.max()), float(et.max())))
+        assert float(eh.max()) <= 0.25, (n, float(eh.max()))
+    assert checked > 500
+    # discrete gate / arg-max flips: each touches a handful of parameters of one chain (weight, BatchNorm weight / bias
+    # of the layers below it); the budget is ~4 % of the parameters
+    assert len(flips) <= 24, flips
