@@ -54,6 +54,13 @@ def parse():
                          "matrix cores, fp32 accumulation (BASELINE configs[3]).  The default run reports the bf16 "
                          "mode as an extra field next to the fp32 headline")
     ap.add_argument("--no-bf16-row", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra operating points and kernel microbenchmarks (bf16 row, utterance cache, "
+                         "6-layer encoder, attention / ball-query / matcher sections): the command the committed "
+                         "rocprofv3 kernel statistics under profiles/ are taken with")
+    ap.add_argument("--roofline-child", action="store_true",
+                    help="internal: run only the captured training step (warm-up + steps) and print the grouped GEMM's "
+                         "algorithmic work per step; the parent runs this under rocprofv3 --kernel-trace --stats")
     ap.add_argument("--no-overlap-exchange", dest="overlap_exchange", action="store_false",
                     help="N > 1: one graph + ONE all-reduce of the whole packed buffer instead of the default two-piece "
                          "capture whose decoder-side gradient bucket is all-reduced under the encoder / backbone backward")
@@ -87,55 +94,89 @@ def build_model(args, device):
     return model.to(device).train(), backend
 
 
-def gemm_roofline(step_fn):
-    """Dominant hand-written kernel of the step: ``gemm_kernel`` (fp32 MFMA grouped GEMM: every
-    projection / FFN / 1x1-conv product of the attention stack and of the set-abstraction MLPs and all
-    their gradient products, the Conv1d chains of the heads; ~35 % of the GPU time of a step, rocprof
-    profiles/).  One EAGER training step
-    is replayed with a HIP-event pair around every launch on the launch stream; algorithmic FLOPs =
-    sum over the problems of a launch of 2*M*N*K, achieved = sum FLOPs / sum duration."""
+def gemm_work(step_fn):
+    """Algorithmic work of the grouped GEMM launches of ONE eager training step (no timing): number of launches,
+    sum over their problems of 2*M*N*K flops and of (M*K + N*K + M*N)*4 bytes (every operand and the result once)."""
     from butd_detr_amd import fused_attention as fa
-    stream = torch.cuda.current_stream()
-    records = []
-    orig = fa._gemm
-
-    def timed(problems, ref):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        orig(problems, ref)
-        e1.record(stream)
-        records.append((sum(2.0 * p.M * p.N * p.K for p in problems), e0, e1))
-
-    fa._gemm = timed
     import butd_detr_amd.fused_mlp as fmlp
     import butd_detr_amd.fused_sa as fsa
-    fsa._gemm = timed
-    fmlp._gemm = timed
+    work = {"launches": 0, "flops": 0.0, "bytes": 0.0}
+    orig = fa._gemm
+
+    def counted(problems, ref):
+        work["launches"] += 1
+        work["flops"] += sum(2.0 * p.M * p.N * p.K for p in problems)
+        work["bytes"] += sum(4.0 * (p.M * p.K + p.N * p.K + p.M * p.N) for p in problems)
+        orig(problems, ref)
+
+    fa._gemm = fsa._gemm = fmlp._gemm = counted
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
-        fa._gemm = orig
-        fsa._gemm = orig
-        fmlp._gemm = orig
-    flops = sum(r[0] for r in records)
-    # an event pair adds the time between the event packets and the kernel's own start/end to every
-    # launch; calibrate that on empty pairs and take it off (rocprofv3's pure kernel durations are the
-    # reference the two numbers must agree with: profiles/r01_hip_bench_kernel_stats.csv)
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-    for a, b in pairs:
-        a.record(stream)
-        b.record(stream)
-    torch.cuda.synchronize()
-    overhead = sorted(a.elapsed_time(b) for a, b in pairs)[len(pairs) // 2]
-    ms = sum(max(r[1].elapsed_time(r[2]) - overhead, 0.0) for r in records)
-    achieved = flops / (ms * 1e-3) / 1e12
-    return {"kernel": "gemm_kernel (grouped fp32 MFMA GEMM, all %d launches of one training step)" % len(records),
+        fa._gemm = fsa._gemm = fmlp._gemm = orig
+    return work
+
+
+def _rocprof_kernel_stats(argv, kernel, timeout=600):
+    """Run ``python bench.py <argv>`` under ``rocprofv3 --kernel-trace --stats`` and return (calls, total ns) of the
+    kernels whose name contains ``kernel`` plus the child's last stdout line.  Pure kernel durations from the
+    dispatch timestamps -- the same source as the committed profiles/*_kernel_stats.csv."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    out_dir = tempfile.mkdtemp(prefix="butd_rocprof_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    cmd = [exe, "--kernel-trace", "--stats", "--output-format", "csv", "-d", out_dir, "-o", "rf", "--",
+           sys.executable, os.path.join(ROOT, "bench.py")] + argv
+    try:
+        res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout)
+        files = glob.glob(os.path.join(out_dir, "**", "*kernel_stats.csv"), recursive=True)
+        if res.returncode != 0 or not files:
+            raise RuntimeError(f"rocprofv3 child failed (rc {res.returncode}): {res.stderr[-400:]}")
+        calls, total = 0, 0
+        for row in csv.DictReader(open(files[0])):
+            if kernel in row["Name"]:
+                calls += int(row["Calls"])
+                total += int(row["TotalDurationNs"])
+        lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+        return calls, total, (json.loads(lines[-1]) if lines else {})
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def gemm_roofline(args):
+    """Dominant hand-written kernel of the step: ``gemm_kernel`` (fp32 MFMA grouped GEMM: every projection / FFN /
+    1x1-conv product of the attention stack and of the set-abstraction MLPs, all their gradient products, the Conv1d
+    chains of the heads; ~45 % of the GPU time of a step).  Duration: the captured training step is run once more in
+    a CHILD process under ``rocprofv3 --kernel-trace --stats`` (this command with --roofline-child) and the kernel's
+    dispatch durations are summed -- in situ, next to the concurrent sampling / language-model branches, no event
+    overhead to calibrate away; the same method as profiles/r03_hip_bench_kernel_stats.csv, which must agree.
+    achieved = algorithmic flops per step (2*M*N*K over the problems of every launch, counted in the child)
+    / (average launch duration x launches per step)."""
+    child = ["--roofline-child", "--steps", "12", "--warmup", "3", "--batch", str(args.batch), "--points",
+             str(args.points), "--queries", str(args.queries), "--tokens", str(args.tokens), "--encoder-layers",
+             str(args.encoder_layers), "--max-targets", str(args.max_targets), "--criterion", args.criterion,
+             "--dtype", args.dtype, "--distinct-batches", str(args.distinct_batches)]
+    calls, total_ns, work = _rocprof_kernel_stats(child, "gemm_kernel")
+    avg_ms = total_ns / max(calls, 1) * 1e-6
+    ms_step = avg_ms * work["launches"]
+    achieved = work["flops"] / (ms_step * 1e-3) / 1e12
+    traffic = _pmc_traffic("gemm_kernel")
+    return {"kernel": "gemm_kernel (grouped fp32 MFMA GEMM, all %d launches of one training step)" % work["launches"],
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
-            "frac": round(achieved / FP32_MATRIX_PEAK_TF, 4), "traffic": _pmc_traffic("gemm_kernel"),
-            "launches_per_step": len(records), "avg_launch_ms": round(ms / max(len(records), 1), 5),
-            "event_pair_overhead_ms": round(overhead, 5),
-            "algorithmic_flops_per_step": flops}
+            "frac": round(achieved / FP32_MATRIX_PEAK_TF, 4), "traffic": traffic,
+            "launches_per_step": work["launches"], "avg_launch_ms": round(avg_ms, 5),
+            "ms_per_step_in_kernel": round(ms_step, 3),
+            "duration_source": "rocprofv3 --kernel-trace --stats of the captured step in a child process "
+                               "(%d launches profiled)" % calls,
+            "algorithmic_flops_per_step": work["flops"], "algorithmic_bytes_per_step": work["bytes"],
+            "algorithmic_bytes_per_launch": round(work["bytes"] / max(work["launches"], 1)),
+            "traffic_over_algorithmic": (round(traffic / (work["bytes"] / max(work["launches"], 1)), 3)
+                                         if traffic else None)}
 
 
 def attention_roofline(batch, reps=10, bf16=False):
@@ -365,10 +406,9 @@ def bf16_row(args, model, opt, criterion, batches):
     try:
         inputs, targets = batches[0]
         dt, loss = _time_recaptured(args, model, opt, criterion, batches)
-        from butd_detr_amd.train_step import make_optimizer, train_step as eager_step
-        local_targets = criterion.prepare(targets) if criterion is not None else targets
-        gemm = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, local_targets,
-                                                criterion=criterion))
+        ns = argparse.Namespace(**vars(args))
+        ns.dtype = "bf16"
+        gemm = gemm_roofline(ns)
         gemm["peak"] = BF16_MATRIX_PEAK_TF
         gemm["frac"] = round(gemm["achieved"] / BF16_MATRIX_PEAK_TF, 4)
         gemm["traffic"] = None
@@ -385,6 +425,19 @@ def bf16_row(args, model, opt, criterion, batches):
     finally:
         fused_attention.set_compute_dtype("f32")
         model.text_precision = "f32"
+
+
+def encoder6_row(args, device, criterion, batches):
+    """BASELINE configs[2] words the encoder as a "6-layer BiEncoder" (the reference hard-codes 3, bdetr.py:104):
+    the same step with num_encoder_layers = 6 as an EXTRA operating point."""
+    from butd_detr_amd.train_step import FlatAdamW
+    ns = argparse.Namespace(**vars(args))
+    ns.encoder_layers = 6
+    model, _ = build_model(ns, device)
+    dt, loss = _time_recaptured(args, model, FlatAdamW(model), criterion, batches)
+    return {"value": round(args.batch * args.steps / dt, 3), "unit": "scenes/s",
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "encoder_layers": 6, "decoder_layers": 6,
+            "final_loss": round(float(loss), 4)}
 
 
 def _flush_c_stdio():
@@ -459,6 +512,15 @@ def main():
             i, t = batches[k % len(batches)]
             return graphed(i, t, next_inputs=batches[(k + 1) % len(batches)][0])
 
+    if args.roofline_child:
+        # under rocprofv3 (parent: gemm_roofline): the captured step a few times, then the GEMM work of one step
+        for k in range(args.warmup + args.steps):
+            train_step(k)
+        torch.cuda.synchronize()
+        work = gemm_work(lambda: eager_step(model, make_optimizer(model), inputs, local_targets, criterion=criterion))
+        _flush_c_stdio()
+        print(json.dumps(work), flush=True)
+        return
     for k in range(args.warmup):
         train_step(k)
     _flush_c_stdio()            # RCCL's start-up banner sits in the C stdio buffer of every rank: out with it now, so
@@ -500,16 +562,20 @@ def main():
         }
         if backend == "hip":
             # rank 0 only from here on: no collective may run (the criterion's box count was all-reduced above)
-            out["roofline"] = gemm_roofline(lambda: eager_step(model, make_optimizer(model), inputs, local_targets,
-                                                                   criterion=criterion))
-            out["roofline_ball_query"] = ball_query_roofline(inputs)
-            out["roofline_attention"] = attention_roofline(args.batch)
-            out["matcher_detection_split"] = matcher_at_detection_size(args.batch)
+            out["roofline"] = gemm_roofline(args)
+            if not args.no_extras:
+                out["roofline_ball_query"] = ball_query_roofline(inputs)
+                out["roofline_attention"] = attention_roofline(args.batch)
+                out["matcher_detection_split"] = matcher_at_detection_size(args.batch)
         else:
             out["roofline"] = ball_query_roofline(inputs)
-        if backend == "hip" and world == 1 and args.dtype == "f32" and not args.eager and not args.no_bf16_row:
+        extras = (backend == "hip" and world == 1 and args.dtype == "f32" and not args.eager and not args.no_extras)
+        if extras and not args.no_bf16_row:
             out["bf16_operating_point"] = bf16_row(args, model, opt, criterion, batches)
+        if extras:
             out["text_cache_operating_point"] = text_cache_row(args, model, opt, criterion, batches)
+            if args.encoder_layers != 6:
+                out["encoder6_operating_point"] = encoder6_row(args, device, criterion, batches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
         _flush_c_stdio()
