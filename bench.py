@@ -198,6 +198,8 @@ def gemm_roofline(args, fallback_step=None):
              "--dtype", args.dtype, "--distinct-batches", str(args.distinct_batches)]
     source = None
     try:
+        if os.environ.get("BUTD_BENCH_NO_CHILD") == "1":   # the parent itself runs under a profiler (scratch/*.sh)
+            raise RuntimeError("BUTD_BENCH_NO_CHILD=1")
         calls, total_ns, work = _rocprof_kernel_stats(child, "gemm_kernel")
         if not calls or not work.get("launches"):
             raise RuntimeError("no gemm_kernel dispatches in the child's trace")
@@ -274,12 +276,15 @@ def attention_roofline(batch, reps=10, bf16=False):
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC profile (profiles/r02_pmc.json), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
-    try:
-        return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
-    except Exception:
-        return None
+    """HBM bytes per launch from the committed PMC profile (profiles/r03_pmc.json, else r02), or None."""
+    for name in ("r03_pmc.json", "r02_pmc.json"):
+        try:
+            v = json.load(open(os.path.join(ROOT, "profiles", name))).get(kernel, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            v = None
+        if v is not None:
+            return v
+    return None
 
 
 def ball_query_roofline(inputs, steps=20):

@@ -1,4 +1,4 @@
-"""gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}.json -> profiles/r02_pmc.json (HBM bytes per launch, corrected as
+"""gpurun_out/pmc/{FETCH_SIZE,WRITE_SIZE}.json -> profiles/r0N_pmc.json (HBM bytes per launch, corrected as
 MI355X_MICROARCH.md's HBM section prescribes for gfx950)."""
 import json, sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
