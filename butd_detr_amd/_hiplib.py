@@ -110,7 +110,7 @@ MLP_SYMBOLS = {
     "butd_mlp_bn_finalize": (_c_int, [_c_int, _c_int, _c_long, _P, _P, ctypes.POINTER(BnSegment), _c_float,
                                       _c_float, _c_int, _P, _P, _P, _P, _P]),
     "butd_mlp_mask_stats": (_c_int, [_c_long, _c_int, _c_long] + [_P] * 6 + [_c_float, _c_u32, _c_int, _P, _P, _P, _P]),
-    "butd_mlp_dz": (_c_int, [_c_long, _c_int, _c_long] + [_P] * 7 + [_c_int, _P]),
+    "butd_mlp_dz": (_c_int, [_c_long, _c_int, _c_long] + [_P] * 7 + [_c_int, _P, _P, _P]),
     "butd_mlp_bn_relu_apply": (_c_int, [_c_long, _c_int, _c_long, _P, _P, _P, _P, _P]),
 }
 

@@ -301,7 +301,8 @@ class BeaUTyDETR(nn.Module):
 
         center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
                                           end_points=end_points, prefix="proposal_")
-        base_xyz, base_size = center.detach().clone(), size.detach().clone()
+        base_xyz, base_size = center.detach(), size.detach()   # (the reference clones: bdetr.py:275-276; the cat /
+            # position embedding below copy them anyway and nothing writes the head outputs in place)
 
         # the encoder outputs feed all decoder layers: one gradient sum per stream (fan_out.py)
         n_dec = len(self.decoder)
@@ -326,7 +327,8 @@ class BeaUTyDETR(nn.Module):
                 proj_inputs.append((prefix, q_proj))
             center, size = head(q_head.transpose(1, 2), base_xyz=cluster_xyz,
                                 end_points=end_points, prefix=prefix, features_pm=q_head)
-            base_xyz, base_size = center.detach().clone(), size.detach().clone()
+            base_xyz, base_size = center.detach(), size.detach()   # (the reference clones: bdetr.py:275-276; the cat /
+            # position embedding below copy them anyway and nothing writes the head outputs in place)
         if proj_inputs:
             proj = unstack(self._normalized_proj(torch.stack([q for _, q in proj_inputs])))
             for i, (prefix, _) in enumerate(proj_inputs):

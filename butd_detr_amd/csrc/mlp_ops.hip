@@ -115,10 +115,18 @@ __global__ __launch_bounds__(256) void mlp_dz_kernel(long P, int C, long ld, flo
                                                      const float *__restrict__ mean,
                                                      const float *__restrict__ rstd,
                                                      const double *__restrict__ S1,
-                                                     const double *__restrict__ S2, int training) {
+                                                     const double *__restrict__ S2, int training,
+                                                     float *__restrict__ S1f, float *__restrict__ S2f) {
   const int cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.y * 256 + cq * 4;
   if (c >= C) return;
+  if (S1f && blockIdx.x == 0 && ph == 0) {   // the BatchNorm bias / weight gradients as fp32 (they ARE the two sums)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      S1f[c + e] = (float)S1[c + e];
+      S2f[c + e] = (float)S2[c + e];
+    }
+  }
   const float4 sc = *reinterpret_cast<const float4 *>(scale + c);
   const float4 mu = *reinterpret_cast<const float4 *>(mean + c);
   const float4 rs = *reinterpret_cast<const float4 *>(rstd + c);
@@ -194,11 +202,11 @@ int butd_mlp_mask_stats(long P, int C, long ld, float *dH, const float *Z, const
 
 int butd_mlp_dz(long P, int C, long ld, float *g, const float *Z, const float *scale,
                 const float *mean, const float *rstd, const double *S1, const double *S2,
-                int training, butd_stream_t stream) {
+                int training, float *S1f, float *S2f, butd_stream_t stream) {
   if (P < 1 || C < 4 || (C & 3) || (ld & 3)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(mlp_dz_kernel, dim3((unsigned)((P + kRows - 1) / kRows), (C + 255) / 256),
                      dim3(256), 0, (hipStream_t)stream, P, C, ld, g, Z, scale, mean, rstd, S1, S2,
-                     training);
+                     training, S1f, S2f);
   return launch_status();
 }
 

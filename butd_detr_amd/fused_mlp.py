@@ -147,6 +147,7 @@ class _MlpChains(torch.autograd.Function):
         dW = [[(views[i * stride + 2 * l], views[i * stride + 2 * l + 1]) for l in range(nh)]
               for i in range(G)]
         S = zeros((nh, 2, G * Hmax), dtype=torch.float64, device=dev)
+        Sf = torch.empty((nh, 2, G * Hmax), device=dev)         # fp32 copies, written by butd_mlp_dz
 
         def operand(l, i):
             if l == 0:
@@ -169,16 +170,23 @@ class _MlpChains(torch.autograd.Function):
             if dH.data_ptr() == d_outs[0].data_ptr():
                 dH = dH.clone()                       # mask_stats works in place
         else:
-            d_outs = [zeros((P, spec.outs[i]), device=dev) if d is None else d.contiguous()
-                      for i, d in enumerate(d_outs)]
+            # a gradient that arrives as a column slice of a wider matrix (the criterion hands the box heads the two
+            # halves of d(pred_boxes)) is read in place through its row stride instead of being copied
+            def rows(i, d):
+                if d is None:
+                    return zeros((P, spec.outs[i]), device=dev)
+                if d.dim() == 2 and d.stride(1) == 1 and d.stride(0) >= d.shape[1] and d.dtype == torch.float32:
+                    return d
+                return d.contiguous()
+            d_outs = [rows(i, d) for i, d in enumerate(d_outs)]
             dWo = [(views[i * stride + 2 * nh], views[i * stride + 2 * nh + 1]) for i in range(G)]
             dH = torch.empty((P, GHl), device=dev)
             probs = []
             for i in range(G):
-                n_out = spec.outs[i]
-                probs.append(wgrad(d_outs[i], n_out, n_out, nh, i, dWo[i][0], dWo[i][1]))
+                n_out, ldo = spec.outs[i], d_outs[i].stride(0)
+                probs.append(wgrad(d_outs[i], ldo, n_out, nh, i, dWo[i][0], dWo[i][1]))
                 probs.append(_problem(d_outs[i], outp[i][0], dH[:, sl(nh - 1, i)], P, Hs[-1], n_out,
-                                      (n_out, 1), (1, Hs[-1]), GHl))
+                                      (ldo, 1), (1, Hs[-1]), GHl))
             _gemm(probs, x)
         need_dx = ctx.needs_input_grad[0]
         dx = None
@@ -191,7 +199,7 @@ class _MlpChains(torch.autograd.Function):
                   spec.site0 + l * G, H, rng_counter(dev).data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr())
             _call("butd_mlp_dz", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
                   aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr(),
-                  int(spec.training))
+                  int(spec.training), Sf[l, 0].data_ptr(), Sf[l, 1].data_ptr())
             dZ = dH
             if l > 0:
                 dH = torch.empty((P, G * Hs[l - 1]), device=dev)
@@ -209,7 +217,6 @@ class _MlpChains(torch.autograd.Function):
                     probs.append(_problem(dZ[:, sl(l, i)], w, dx, P, Cin, H, (GH, 1), (1, Cin), Cin,
                                           accumulate=G > 1))
             _gemm(probs, x)
-        Sf = S.float()
         grads = []
         for i in range(G):
             for l in range(nh):

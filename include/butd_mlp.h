@@ -57,10 +57,11 @@ int butd_mlp_mask_stats(long P, int C, long ld, float *dH, const float *Z, const
                         double *S2, butd_stream_t stream);
 
 /* Backward through BatchNorm, in place on g -> dZ = scale*(g - S1/P - zhat*S2/P)  (training == 0:
- * running statistics, dZ = scale*g). */
+ * running statistics, dZ = scale*g).  S1f / S2f (may be NULL): fp32 copies of the two sums, i.e. the BatchNorm
+ * bias / weight gradients in the parameters' dtype, written by the same launch. */
 int butd_mlp_dz(long P, int C, long ld, float *g, const float *Z, const float *scale,
                 const float *mean, const float *rstd, const double *S1, const double *S2,
-                int training, butd_stream_t stream);
+                int training, float *S1f, float *S2f, butd_stream_t stream);
 
 /* out[p, c] = relu(scale[c] * Z[p, c] + shift[c])  (P x C, row stride ld for both): the materialised
  * output of a chain that ENDS in BatchNorm + ReLU (the SharedMLP of PointnetFPModule,
