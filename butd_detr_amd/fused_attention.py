@@ -57,10 +57,14 @@ class ZeroArena:
     def __init__(self, device):
         self.device = torch.device(device)
         self.chunks, self.index, self.offset = [], 0, 0
+        self.captured = False
 
     def reset(self):
         capturing = self.device.type == "cuda" and torch.cuda.is_current_stream_capturing()
-        if len(self.chunks) > 1 and not capturing:
+        # once a captured graph has the chunks' addresses baked in they are never released or replaced: a later
+        # signature's eager warm-up merging them would leave the earlier graph replaying into freed memory
+        self.captured = self.captured or capturing
+        if len(self.chunks) > 1 and not capturing and not self.captured:
             total = sum(c.numel() for c in self.chunks)
             self.chunks = [torch.zeros(total, dtype=torch.uint8, device=self.device)]
         else:

@@ -157,6 +157,42 @@ def test_warmup_does_not_train_signatures_are_cached_and_the_scheduler_is_follow
         attention_blocks.set_backend("torch")
 
 
+def test_alternating_signatures_replay_their_own_gradients():
+    """Advisor finding of round 2: every captured signature (slot) must replay with ITS gradient pointer table -- a
+    table shared between slots handed slot A the gradient addresses of slot B's private pool.  Learning rate 0 and a
+    pinned dropout counter: every visit of a batch reproduces the loss AND the packed gradients of its first visit,
+    whichever slot replayed in between; the least recently used slot is dropped at ``max_slots``."""
+    from butd_detr_amd import attention_blocks, fused_attention as fa
+    from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, HungarianCriterion, synthetic_batch
+    try:
+        dev = torch.device("cuda", 0)
+        batches = [synthetic_batch(2, dev, seed=5 + i, n_points=4096, tokens=t) for i, t in enumerate((24, 16, 20))]
+        lens = [len(step_in[0]["text"]) for step_in in batches]
+        model = _model()
+        opt = FlatAdamW(model, lr=0.0, lr_backbone=0.0, weight_decay=0.0)
+        step = GraphedTrainStep(model, opt, warmup=1, criterion=HungarianCriterion(num_decoder_layers=2), max_slots=2)
+        ctr = fa.rng_counter(dev)
+        seen = {}
+        order = [0, 1, 0, 1, 1, 0, 2, 0, 2, 1, 0]          # (slot 1 is evicted when 2 arrives, re-captured later)
+        for k, i in enumerate(order):
+            ctr.fill_(100 + i)
+            loss = float(step(*batches[i]))
+            g = opt.flat_g.clone()
+            assert len(step._slots) <= 2
+            if i in seen:
+                l0, g0 = seen[i]
+                assert abs(loss - l0) <= 1e-5 * max(abs(l0), 1.0), (k, i, loss, l0)
+                assert float((g - g0).abs().max() / g0.abs().max()) <= 1e-4, (k, i)
+            else:
+                seen[i] = (loss, g)
+        sigs = {tuple(b[0]["point_clouds"].shape) for b in batches}
+        assert len(seen) == 3 and len(sigs) == 1 and float(seen[0][1].abs().max()) > 0
+        # the three batches really are three signatures (token lengths differ)
+        assert len({s[1] for s in step._slots} | {None}) >= 2
+    finally:
+        attention_blocks.set_backend("torch")
+
+
 def test_overlapped_exchange_equals_the_single_graph_step(tmp_path):
     """The two-piece capture (backward cut at the encoder outputs, the decoder-side bucket all-reduced while the
     encoder / backbone backward replays) must train exactly like the single-graph step.  World size 1 over
