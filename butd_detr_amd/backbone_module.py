@@ -64,6 +64,9 @@ class Pointnet2Backbone(nn.Module):
             xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off,
                                      inds=None if sample_inds is None else sample_inds[level - 1])
             feats_pm, off = sa.last_features_pm, 0
+            # (a module attribute that holds a tensor with a grad_fn keeps this iteration's autograd graph -- and the
+            #  parameters' AccumulateGrad nodes with the stream they were created on -- alive into the next one)
+            sa.last_features_pm = None
             if level <= 2:  # the reference only records inds of the first two levels (:127,:132)
                 end_points[f"sa{level}_inds"] = inds
             end_points[f"sa{level}_xyz"] = xyz
