@@ -140,6 +140,7 @@ AUGMENT_SYMBOLS = {
     "butd_augment_points": (_c_int, [_c_int] * 4 + [_P] * 4 + [_c_double] * 3 + [_c_u64, _P, _P]),
     "butd_augment_boxes": (_c_int, [_c_int, _c_int, _P, _P, _P, _P]),
     "butd_instance_boxes": (_c_int, [_c_int] * 4 + [_P] * 6 + [_P]),
+    "butd_object_boxes": (_c_int, [_c_int] * 4 + [_P, _P, ctypes.c_longlong] + [_P] * 8 + [_P]),
 }
 
 GRAPH_SYMBOLS = {

@@ -146,6 +146,36 @@ __global__ __launch_bounds__(256) void instance_hull_kernel(int N, int ldp, int 
   }
 }
 
+// Target objects given as POINT LISTS (the resident scene store: all objects of all scenes as one CSR array): for target
+// slot t of sample b, object target_ids[b][t] of scene scene[b]: (i) point_instance_label[b][p] = t for its points --
+// the reference assigns in slot order, so the LAST slot that contains a point wins (joint_det_dataset.py:507-508) =
+// a max over slots; (ii) the hull of ALL its points (Scan.get_object_bbox, visual_data_handlers.py:217-219), also of
+// points a later slot claims.
+__global__ __launch_bounds__(256) void object_scan_kernel(int N, int ldp, int G, const int *__restrict__ scene,
+                                                          const long long *__restrict__ obj_ptr, long long ptr_stride,
+                                                          const int *__restrict__ obj_points,
+                                                          const int *__restrict__ target_ids,
+                                                          const float *__restrict__ pc, long long *__restrict__ label,
+                                                          uint32_t *__restrict__ scratch) {
+  const int b = blockIdx.z, t = blockIdx.y;
+  const int tid = target_ids[(size_t)b * G + t];
+  if (tid < 0) return;
+  const long long *ptr = obj_ptr + (size_t)scene[b] * ptr_stride;
+  const long long begin = ptr[tid], end = ptr[tid + 1];
+  uint32_t *s = scratch + ((size_t)b * G + t) * 6;
+  for (long long i = begin + (long long)blockIdx.x * 256 + threadIdx.x; i < end; i += (long long)gridDim.x * 256) {
+    const int n = obj_points[i];
+    if (n < 0 || n >= N) continue;
+    if (label) atomicMax(label + (size_t)b * N + n, (long long)t);
+    const float *p = pc + ((size_t)b * N + n) * ldp;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      atomicMax(s + a, ordered_key(-p[a]));
+      atomicMax(s + 3 + a, ordered_key(p[a]));
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void instance_box_kernel(int total, const uint32_t *__restrict__ scratch,
                                                            const double *__restrict__ jitter,
                                                            float *__restrict__ out, float *__restrict__ mask) {
@@ -215,6 +245,23 @@ int butd_instance_boxes(int B, int N, int ldp, int G, const float *pc, const int
   if (N > 0)
     hipLaunchKernelGGL(instance_hull_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, N, ldp, G, pc, instance,
                        scratch);
+  const int total = B * G;
+  hipLaunchKernelGGL(instance_box_kernel, dim3((total + 255) / 256), dim3(256), 0, s, total, scratch, jitter,
+                     center_size, mask);
+  return (int)hipGetLastError();
+}
+
+int butd_object_boxes(int B, int N, int ldp, int G, const int *scene, const long long *obj_ptr, long long ptr_stride,
+                      const int *obj_points, const int *target_ids, const float *pc, const double *jitter,
+                      long long *point_instance_label, uint32_t *scratch, float *center_size, float *mask,
+                      butd_stream_t stream) {
+  if (B <= 0 || G <= 0) return 0;
+  if (ldp < 3 || N <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = butd_zero_async(scratch, sizeof(uint32_t) * 6 * (size_t)B * G, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(object_scan_kernel, dim3(8, G, B), dim3(256), 0, s, N, ldp, G, scene, obj_ptr, ptr_stride,
+                     obj_points, target_ids, pc, point_instance_label, scratch);
   const int total = B * G;
   hipLaunchKernelGGL(instance_box_kernel, dim3((total + 255) / 256), dim3(256), 0, s, total, scratch, jitter,
                      center_size, mask);

@@ -58,6 +58,19 @@ int butd_instance_boxes(int B, int N, int ldp, int G, const float *pc, const int
                         const double *jitter, uint32_t *scratch, float *center_size, float *mask,
                         butd_stream_t stream);
 
+/* The same target boxes for scenes that are RESIDENT in HBM with their objects as point lists (the reference keeps the
+ * pickled Scan objects in host memory, joint_det_dataset.py:96-99, and every __getitem__ walks
+ * scan.three_d_objects[tid]['points'], :507-512): obj_points = every object's point indices of every scene, one after
+ * the other; obj_ptr[s * ptr_stride + k] = where object k of scene s starts (k = 0 .. number of objects).  For sample b
+ * (scene scene[b]) and slot t < G with target_ids[b][t] >= 0: point_instance_label[b][p] = t for the object's points
+ * (point_instance_label (B, N) int64, pre-filled with -1 by the caller, may be NULL; a point of several target objects
+ * keeps the LAST slot, :507-508) and the hull of all the object's points in pc (B, N, ldp) as centre + size times
+ * jitter; empty / absent slots: centre 1000, size 0, mask 0.  scratch: 6 * B * G uint32. */
+int butd_object_boxes(int B, int N, int ldp, int G, const int *scene, const long long *obj_ptr, long long ptr_stride,
+                      const int *obj_points, const int *target_ids, const float *pc, const double *jitter,
+                      long long *point_instance_label, uint32_t *scratch, float *center_size, float *mask,
+                      butd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
