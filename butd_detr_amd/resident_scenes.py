@@ -66,11 +66,12 @@ class ResidentScenes:
         self.cloud = None
 
     # ------------------------------------------------------------------ filling
-    def add_scan(self, scan_id, pc, color, objects, detected=None):
+    def add_scan(self, scan_id, pc, color, objects, detected=None, object_class_ids=None):
         """One scene: ``pc`` (N, 3) axis-aligned coordinates (``scan.orig_pc``), ``color`` (N, 3) in [0, 1),
         ``objects`` = ``scan.three_d_objects``; ``detected``: {'box': (K, 6) corners, 'class_ids': (K,) int,
         optional 'logits'} -- the detector's boxes of ``group_free_pred_bboxes_{split}/{scan_id}.npy`` with its class
-        NAMES already mapped to ids (joint_det_dataset.py:573-582)."""
+        NAMES already mapped to ids (joint_det_dataset.py:573-582).  ``object_class_ids``: class id of every object
+        (``DC.nyu40id2class[label_map[instance_label]]`` or 325, :536-541), only needed by ``scene_objects``."""
         if self.cloud is not None:
             raise RuntimeError("ResidentScenes.add_scan after finalize()")
         pc = np.asarray(pc, dtype=np.float64)
@@ -88,46 +89,80 @@ class ResidentScenes:
             cls = np.zeros(self.slots, np.int64)
             cls[:k] = np.asarray(detected["class_ids"], dtype=np.int64)
             det = (box, mask, cls)
+        cls_ids = np.zeros(self.slots, np.int64)
+        if object_class_ids is not None:
+            k = min(len(points), self.slots)
+            cls_ids[:k] = np.asarray(object_class_ids, dtype=np.int64)[:k]
         self.index[scan_id] = len(self._pending)
-        self._pending.append((cloud, points, det))
+        self._pending.append((cloud, points, det, cls_ids))
 
     @classmethod
-    def from_scans(cls, scans, device, detected=None, **kw):
+    def from_scans(cls, scans, device, detected=None, object_class_ids=None, **kw):
         """``scans``: {scan_id: Scan-like} (``read_scans``); ``detected``: {scan_id: dict} as for ``add_scan``."""
         store = cls(device, **kw)
         for scan_id, scan in scans.items():
             pc = getattr(scan, "orig_pc", None)
             store.add_scan(scan_id, scan.pc if pc is None else pc, scan.color, scan.three_d_objects,
-                           None if detected is None else detected.get(scan_id))
+                           None if detected is None else detected.get(scan_id),
+                           None if object_class_ids is None else object_class_ids.get(scan_id))
         return store.finalize()
 
     def finalize(self):
-        n = {c.shape[0] for c, _, _ in self._pending}
+        n = {c.shape[0] for c, _, _, _ in self._pending}
         if len(n) != 1:
             raise ValueError(f"scenes of different sizes {sorted(n)}: the reference keeps 50 000 points per scene "
                              "(visual_data_handlers.py:111-118)")
         self.n_points = n.pop()
         dev = self.device
-        self.cloud = torch.from_numpy(np.stack([c for c, _, _ in self._pending])).to(dev)          # (S, N, 6)
-        self.max_objects = max(len(p) for _, p, _ in self._pending)
+        self.cloud = torch.from_numpy(np.stack([c for c, _, _, _ in self._pending])).to(dev)          # (S, N, 6)
+        self.max_objects = max(len(p) for _, p, _, _ in self._pending)
         ptr = np.zeros((len(self._pending), self.max_objects + 1), np.int64)
         flat, off = [], 0
-        for s, (_, points, _) in enumerate(self._pending):
+        for s, (_, points, _, _) in enumerate(self._pending):
             for k, p in enumerate(points):
                 ptr[s, k] = off
                 flat.append(p)
                 off += p.size
             ptr[s, len(points):] = off
-        self.n_objects = np.asarray([len(p) for _, p, _ in self._pending])
+        self.n_objects = np.asarray([len(p) for _, p, _, _ in self._pending])
         self.obj_ptr = torch.from_numpy(ptr).to(dev)
         self.obj_points = torch.from_numpy(np.concatenate(flat) if flat else np.zeros(0, np.int32)).to(dev)
-        self.has_detected = all(d is not None for _, _, d in self._pending)
+        self.has_detected = all(d is not None for _, _, d, _ in self._pending)
         if self.has_detected:
-            self.det_boxes = torch.from_numpy(np.stack([d[0] for _, _, d in self._pending])).to(dev)
-            self.det_mask = torch.from_numpy(np.stack([d[1] for _, _, d in self._pending])).to(dev)
-            self.det_class = torch.from_numpy(np.stack([d[2] for _, _, d in self._pending])).to(dev)
+            self.det_boxes = torch.from_numpy(np.stack([d[0] for _, _, d, _ in self._pending])).to(dev)
+            self.det_mask = torch.from_numpy(np.stack([d[1] for _, _, d, _ in self._pending])).to(dev)
+            self.det_class = torch.from_numpy(np.stack([d[2] for _, _, d, _ in self._pending])).to(dev)
+        self.obj_class = torch.from_numpy(np.stack([c for _, _, _, c in self._pending])).to(dev)
         self._pending = None
         return self
+
+    def scene_objects(self, scan_ids, point_clouds=None, jitter=None):
+        """``_get_scene_objects`` (joint_det_dataset.py:524-560): the boxes of ALL objects of every scene (first 132),
+        from ``point_clouds`` (B, N, >= 3) -- the batch's augmented clouds -- or the stored ones -> ``all_bboxes``
+        (B, 132, 6) centre + size (zeros in unused slots), ``all_bbox_label_mask`` (B, 132) bool, ``all_class_ids``
+        (B, 132).  ``jitter`` (B, 132, 6): the training split's ``0.95 + 0.1 * random`` (:553-554)."""
+        dev, B, G = self.device, len(scan_ids), self.slots
+        rows = [self.index[s] for s in scan_ids]
+        scene = torch.tensor(rows, dtype=torch.int32, device=dev)
+        pc = self.cloud.index_select(0, scene.long()) if point_clouds is None else point_clouds.contiguous().float()
+        tids = np.full((B, G), -1, np.int32)
+        for b, r in enumerate(rows):
+            k = min(int(self.n_objects[r]), G)
+            tids[b, :k] = np.arange(k)
+        t_dev = torch.from_numpy(tids).to(dev)
+        jit = None if jitter is None else torch.as_tensor(np.asarray(jitter, dtype=np.float64)).to(dev)
+        scratch = torch.empty((B, G, 6), dtype=torch.int32, device=dev)
+        boxes, mask = torch.empty((B, G, 6), device=dev), torch.empty((B, G), device=dev)
+        lib = _hiplib.load()
+        with torch.cuda.device(dev):
+            err = lib.butd_object_boxes(B, pc.shape[1], pc.shape[-1], G, scene.data_ptr(), self.obj_ptr.data_ptr(),
+                                        self.obj_ptr.shape[1], self.obj_points.data_ptr(), t_dev.data_ptr(),
+                                        pc.data_ptr(), None if jit is None else jit.data_ptr(), None,
+                                        scratch.data_ptr(), boxes.data_ptr(), mask.data_ptr(),
+                                        torch.cuda.current_stream(dev).cuda_stream)
+        _hiplib.check(err, "butd_object_boxes")
+        keep = t_dev >= 0                                    # :531-533: every listed object is kept
+        return boxes * keep[..., None], keep, self.obj_class.index_select(0, scene.long()) * keep
 
     def bytes(self):
         return sum(t.numel() * t.element_size() for t in (self.cloud, self.obj_ptr, self.obj_points))

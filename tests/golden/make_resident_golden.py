@@ -68,6 +68,8 @@ def main():
         np.save(f"{tmp}/group_free_pred_bboxes_train/{sid}.npy", det, allow_pickle=True)
         out[f"det_box_{i}"] = det["box"]
         out[f"det_class_ids_{i}"] = np.array([mod.DC.nyu40id2class[self.label_map[c]] for c in det["class"]])
+        out[f"obj_class_ids_{i}"] = np.array([mod.DC.nyu40id2class[self.label_map[o["instance_label"]]]
+                                              for o in scan.three_d_objects])
     cases = [(0, 3, True, 21), (1, [2, 5, 0, len(scans["scene7001_00"].three_d_objects) - 1], True, 22),
              (2, [0, len(scans["scene7002_00"].three_d_objects) - 1, 4], False, 23), (0, [1], False, 24)]
     from oracle import augment_oracle
@@ -85,6 +87,10 @@ def main():
         np.random.set_state(state)
         boxes, mask, label = mod.Joint3DDataset._get_target_boxes(self, {"target_id": tids}, scan)
         det_boxes, det_mask, det_cls, _ = mod.Joint3DDataset._get_detected_objects(self, "train", sid, aug)
+        state = np.random.get_state()
+        all_jitter = 0.95 + 0.1 * np.random.random((SLOTS, 6))                    # what :553-554 is about to draw
+        np.random.set_state(state)
+        cls_ids, all_boxes, all_mask = mod.Joint3DDataset._get_scene_objects(self, scan)
         np.random.seed(seed)
         replay = augment_oracle.draw(rotate, N, True, np.random)
         assert np.array_equal(replay["noise"], aug["noise"]) and replay["scale"] == aug["scale"]
@@ -95,7 +101,9 @@ def main():
                     f"c{c}_shift": aug["shift"].reshape(3), f"c{c}_scale": np.asarray(aug["scale"]),
                     f"c{c}_noise": aug["noise"], f"c{c}_color_gain": replay["color_gain"], f"c{c}_jitter": jitter,
                     f"c{c}_out_pc": pc, f"c{c}_out_color": color, f"c{c}_boxes": boxes, f"c{c}_mask": mask,
-                    f"c{c}_label": label, f"c{c}_det_boxes": det_boxes, f"c{c}_det_mask": det_mask, f"c{c}_det_cls": det_cls})
+                    f"c{c}_label": label, f"c{c}_det_boxes": det_boxes, f"c{c}_det_mask": det_mask, f"c{c}_det_cls": det_cls,
+                    f"c{c}_all_jitter": all_jitter, f"c{c}_all_boxes": all_boxes, f"c{c}_all_mask": all_mask,
+                    f"c{c}_all_cls": cls_ids})
         print(c, sid, tids, "targets labelled:", [(label == t).sum() for t in range(n_t)])
     out["n_cases"] = np.asarray(len(cases))
     np.savez_compressed(os.path.join(HERE, "resident_cases.npz"), **out)

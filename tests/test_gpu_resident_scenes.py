@@ -19,7 +19,8 @@ def store():
     z = np.load(os.path.join(HERE, "golden", "resident_cases.npz"))
     scans = read_scans(os.path.join(HERE, "golden", "resident_scans.pkl"))
     detected = {sid: {"box": z[f"det_box_{i}"], "class_ids": z[f"det_class_ids_{i}"]} for i, sid in enumerate(scans)}
-    return ResidentScenes.from_scans(scans, "cuda", detected=detected), list(scans), z
+    classes = {sid: z[f"obj_class_ids_{i}"] for i, sid in enumerate(scans)}
+    return ResidentScenes.from_scans(scans, "cuda", detected=detected, object_class_ids=classes), list(scans), z
 
 
 def test_batches_reproduce_the_reference_samples(store):
@@ -50,6 +51,12 @@ def test_batches_reproduce_the_reference_samples(store):
         np.testing.assert_allclose(inputs["det_boxes"].cpu().numpy()[0], g("det_boxes"), rtol=1e-5, atol=1e-5)
         np.testing.assert_array_equal(inputs["det_bbox_label_mask"].cpu().numpy()[0], g("det_mask"))
         np.testing.assert_array_equal(inputs["det_class_ids"].cpu().numpy()[0], g("det_cls").astype(np.int64))
+        # _get_scene_objects (:524-560): every object's box from the augmented cloud, jittered; zeros in unused slots
+        all_boxes, all_mask, all_cls = rs.scene_objects([sid], point_clouds=inputs["point_clouds"],
+                                                        jitter=g("all_jitter")[None])
+        np.testing.assert_allclose(all_boxes.cpu().numpy()[0], g("all_boxes"), rtol=2e-6, atol=2e-6)
+        np.testing.assert_array_equal(all_mask.cpu().numpy()[0], g("all_mask"))
+        np.testing.assert_array_equal(all_cls.cpu().numpy()[0], g("all_cls").astype(np.int64))
 
 
 def test_batch_of_several_scenes_feeds_the_model_shapes_and_eval_mode_is_the_stored_scene(store):
