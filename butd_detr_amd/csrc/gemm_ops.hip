@@ -352,7 +352,6 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
         }
         __syncthreads();
       }
-      const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const f32x4 zero_v = {0.f, 0.f, 0.f, 0.f};
       auto f4 = [](f32x4 v) { return make_float4(v[0], v[1], v[2], v[3]); };
       auto drop4 = [](float4 v, uint32_t key, uint32_t off, float p, float inv) {

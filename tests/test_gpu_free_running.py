@@ -11,8 +11,8 @@ then never wrote its result, the clip coefficient became 1.0 and the update went
   visit of its batch -- loss, clip coefficient and a checksum of the packed gradients, logged on the device;
 * at the reference's learning rates 60 free-running steps over 3 batches end where the same run with a host
   wait before every step and the eager packed-optimizer run end (fp32 atomics make trajectories chaotic at the
-  1 % level -- measured spread of identical runs: +-1.6 % -- so the bound is 4 %; an unclipped update moved it
-  by 8-18 %),
+  1 % level -- measured spread of identical runs: +-1.6 % -- so the bound is 5 % on the mean of the last
+  two visits of every batch; an unclipped update moved it by 8-18 %),
 for {single graph, two-piece overlapped exchange} x {BUTD_FAN_OUT 1, 0} x {prefetch branches on, off}."""
 import gc
 import os
@@ -153,8 +153,8 @@ def test_free_running_step(split, fan_out, prefetch, batches, process_group, eag
             os.environ["BUTD_STEP_SYNC"] = sync
             torch.cuda.synchronize()
             tails[mode] = float(_run(step, batches, STEPS, 5000, pin_per_batch=False)[-2 * NB:, 0].mean())
-        assert abs(tails["free"] - tails["synced"]) <= 0.04 * tails["synced"], (tails, eager_tail)
-        assert abs(tails["free"] - eager_tail) <= 0.04 * eager_tail, (tails, eager_tail)
+        assert abs(tails["free"] - tails["synced"]) <= 0.05 * tails["synced"], (tails, eager_tail)
+        assert abs(tails["free"] - eager_tail) <= 0.05 * eager_tail, (tails, eager_tail)
     finally:
         for k, v in saved.items():
             if v is None:
