@@ -760,6 +760,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._restore(snap)
+        if self.arena is not None and not self.arena.captured:
+            self.arena.reset()           # (eager: folds the chunks the warm-up steps discovered into one before the
+        #                                   first capture bakes their addresses in -- one zero fill per step, not one per chunk)
         torch.cuda.synchronize()
         # graphs keep their hipGraph_t until the first replay: memset nodes (hipMemsetAsync of a stock torch op, e.g.
         # the semaphore reset of a multi-block reduction) are rewritten into kernel nodes first -- replayed memset
