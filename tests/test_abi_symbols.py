@@ -134,3 +134,17 @@ def test_dropin_falls_through_to_the_reference_for_what_it_does_not_provide(libp
             models.APCalculator
     finally:
         attention_blocks.set_backend(prev)
+
+
+def test_no_hipmemset_on_the_path():
+    """A captured hipMemsetAsync becomes a MEMSET node, and a replayed memset node is unreliable on ROCm 7.2
+    (profiles/r03_hipgraph_memset_nodes.txt): the library zeroes with a kernel (csrc/zero_fill.h)."""
+    import glob
+    import re
+    offenders = []
+    for path in glob.glob(os.path.join(ROOT, "butd_detr_amd", "csrc", "*.hip")) + \
+            glob.glob(os.path.join(ROOT, "butd_detr_amd", "binding", "*.cpp")):
+        text = re.sub(r"//[^\n]*", "", open(path).read())              # (comments may name the call)
+        if re.search(r"\bhipMemset\w*\s*\(", text):
+            offenders.append(os.path.basename(path))
+    assert not offenders, offenders
