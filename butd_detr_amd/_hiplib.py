@@ -146,6 +146,7 @@ AUGMENT_SYMBOLS = {
 GRAPH_SYMBOLS = {
     "butd_graph_replace_memset_nodes": (_c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
     "butd_graph_node_counts": (_c_int, [_P, ctypes.POINTER(ctypes.c_int * 16)]),
+    "butd_runtime_versions": (_c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
 }
 
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)

@@ -32,24 +32,8 @@ __global__ __launch_bounds__(256) void memset_node_kernel(unsigned char *dst, un
 }
 }  // namespace
 
-extern "C" int butd_graph_node_counts(void *graph, int counts[16]) {
-  for (int i = 0; i < 16; ++i) counts[i] = 0;
-  size_t n = 0;
-  hipError_t e = hipGraphGetNodes((hipGraph_t)graph, nullptr, &n);
-  if (e != hipSuccess) return (int)e;
-  std::vector<hipGraphNode_t> nodes(n);
-  if (n && (e = hipGraphGetNodes((hipGraph_t)graph, nodes.data(), &n)) != hipSuccess) return (int)e;
-  for (size_t i = 0; i < n; ++i) {
-    hipGraphNodeType t;
-    if ((e = hipGraphNodeGetType(nodes[i], &t)) != hipSuccess) return (int)e;
-    if ((int)t >= 0 && (int)t < 16) counts[(int)t]++;
-  }
-  return 0;
-}
-
-extern "C" int butd_graph_replace_memset_nodes(void *graph_, int *replaced) {
-  hipGraph_t graph = (hipGraph_t)graph_;
-  if (replaced) *replaced = 0;
+namespace {
+int count_nodes(hipGraph_t graph, int counts[16]) {
   size_t n = 0;
   hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
   if (e != hipSuccess) return (int)e;
@@ -58,6 +42,31 @@ extern "C" int butd_graph_replace_memset_nodes(void *graph_, int *replaced) {
   for (size_t i = 0; i < n; ++i) {
     hipGraphNodeType t;
     if ((e = hipGraphNodeGetType(nodes[i], &t)) != hipSuccess) return (int)e;
+    if ((int)t >= 0 && (int)t < 16) counts[(int)t]++;
+    if (t == hipGraphNodeTypeGraph) {   // the nodes of an embedded child graph are replayed too: count them as well
+      hipGraph_t child;
+      if ((e = hipGraphChildGraphNodeGetGraph(nodes[i], &child)) != hipSuccess) return (int)e;
+      if (int err = count_nodes(child, counts)) return err;
+    }
+  }
+  return 0;
+}
+
+int replace_memsets(hipGraph_t graph, int *replaced) {
+  size_t n = 0;
+  hipError_t e = hipGraphGetNodes(graph, nullptr, &n);
+  if (e != hipSuccess) return (int)e;
+  std::vector<hipGraphNode_t> nodes(n);
+  if (n && (e = hipGraphGetNodes(graph, nodes.data(), &n)) != hipSuccess) return (int)e;
+  for (size_t i = 0; i < n; ++i) {
+    hipGraphNodeType t;
+    if ((e = hipGraphNodeGetType(nodes[i], &t)) != hipSuccess) return (int)e;
+    if (t == hipGraphNodeTypeGraph) {   // recurse: a memset inside a child graph is as unsafe as a top-level one
+      hipGraph_t child;
+      if ((e = hipGraphChildGraphNodeGetGraph(nodes[i], &child)) != hipSuccess) return (int)e;
+      if (int err = replace_memsets(child, replaced)) return err;
+      continue;
+    }
     if (t != hipGraphNodeTypeMemset) continue;
     hipMemsetParams mp;
     if ((e = hipGraphMemsetNodeGetParams(nodes[i], &mp)) != hipSuccess) return (int)e;
@@ -93,4 +102,21 @@ extern "C" int butd_graph_replace_memset_nodes(void *graph_, int *replaced) {
     if (replaced) ++*replaced;
   }
   return 0;
+}
+}  // namespace
+
+extern "C" int butd_graph_node_counts(void *graph, int counts[16]) {
+  for (int i = 0; i < 16; ++i) counts[i] = 0;
+  return count_nodes((hipGraph_t)graph, counts);
+}
+
+extern "C" int butd_graph_replace_memset_nodes(void *graph, int *replaced) {
+  if (replaced) *replaced = 0;
+  return replace_memsets((hipGraph_t)graph, replaced);
+}
+
+extern "C" int butd_runtime_versions(int *runtime, int *driver) {
+  hipError_t e = hipRuntimeGetVersion(runtime);
+  if (e != hipSuccess) return (int)e;
+  return (int)hipDriverGetVersion(driver);
 }

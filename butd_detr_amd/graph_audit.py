@@ -20,9 +20,29 @@ NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "
               12: "memcpy_from_symbol", 13: "memcpy_to_symbol"}
 
 
+# where the memset-node bug was observed (profiles/r03_hipgraph_memset_nodes.txt): HIP runtime 7.2 as shipped in
+# the ROCm 7.2.0 image (hipRuntimeGetVersion 70226015 -> "7.2.26015"), torch 2.10.0+rocm7.0, MI355X (gfx950).
+# tests/test_gpu_runtime_probe.py replays the reproducer and reports whether the running stack still has it.
+BUG_SEEN_ON = {"hip_runtime": "7.2", "torch": "2.10.0+rocm7.0", "arch": "gfx950"}
+
+
+def runtime_versions():
+    """{'hip_runtime': int, 'hip_driver': int, 'torch': str, 'torch_hip': str} of this process."""
+    import torch
+    rt, drv = ctypes.c_int(0), ctypes.c_int(0)
+    _hiplib.check(_hiplib.load().butd_runtime_versions(ctypes.byref(rt), ctypes.byref(drv)), "butd_runtime_versions")
+    return {"hip_runtime": rt.value, "hip_driver": drv.value, "torch": torch.__version__,
+            "torch_hip": str(torch.version.hip)}
+
+
 def new_graph():
     """A ``torch.cuda.CUDAGraph`` whose hipGraph_t stays accessible after capture (instantiated at first replay)."""
     import torch
+    need = ("raw_cuda_graph", "instantiate")
+    if any(not hasattr(torch.cuda.CUDAGraph, n) for n in need):
+        raise RuntimeError(f"graph_audit.new_graph: torch {torch.__version__} lacks CUDAGraph(keep_graph=True) / "
+                           f"{' / '.join(need)} (torch >= 2.8 has them): the captured step cannot be scrubbed of "
+                           "memset nodes on this torch, and replaying them is unsafe on ROCm 7.2")
     return torch.cuda.CUDAGraph(keep_graph=True)
 
 

@@ -295,7 +295,8 @@ class FlatAdamW:
                 self._clip_ws.data_ptr(), self.grad_scale.data_ptr(), self.grad_norm.data_ptr(),
                 torch.cuda.current_stream(self.flat_g.device).cuda_stream)
             self._check(err, "butd_clip_coefficient")
-            return self.grad_norm[0]
+            # (the buffer is persistent: outside a capture hand back a copy, not a view later steps overwrite)
+            return self.grad_norm[0] if torch.cuda.is_current_stream_capturing() else self.grad_norm[0].clone()
         norm = torch.linalg.vector_norm(self.flat_g) / grad_div
         torch.clamp(max_norm / (norm + 1e-6), max=1.0, out=self.grad_scale[0])
         if grad_div != 1.0:
@@ -342,13 +343,21 @@ class FlatAdamW:
                 "layout": [list(e) for e in self.layout],
                 "betas": self.betas, "eps": self.eps}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, allow_legacy_layout=False):
+        """``allow_legacy_layout``: accept a checkpoint written before the parameter layout was recorded, ASSUMING it
+        was packed in this optimizer's order (true for checkpoints of the same code version and model; a warning is
+        issued because it cannot be verified)."""
         if [g["numel"] for g in sd["param_groups"]] != [sum(p.numel() for p in g["params"]) for g in self.param_groups]:
             raise ValueError("FlatAdamW.load_state_dict: parameter groups of a different model")
         theirs = [tuple(e) for e in sd.get("layout", [])]
         if not theirs:
-            raise ValueError("FlatAdamW.load_state_dict: the checkpoint has no parameter layout (saved before the "
-                             "layout was recorded): its moments cannot be matched to parameters safely")
+            if not (allow_legacy_layout and sd["flat_m"].numel() == self.flat_m.numel()):
+                raise ValueError("FlatAdamW.load_state_dict: the checkpoint has no parameter layout (saved before the "
+                                 "layout was recorded): its moments cannot be matched to parameters safely "
+                                 "(allow_legacy_layout=True assumes this optimizer's packing order)")
+            import warnings
+            warnings.warn("FlatAdamW.load_state_dict: layout-less checkpoint taken in the current packing order")
+            theirs = list(self.layout)
         strip = lambda n: n[7:] if n.startswith("module.") else n
         if theirs == self.layout:
             self.flat_m.copy_(sd["flat_m"])
@@ -407,6 +416,7 @@ class FlatGradients:
         # Pinned allocations are not capturable, so every eager call leaves one spare table for the next capture.
         if getattr(self, "_gather_tables", None) is None:
             self._gather_tables, self._gather_spare, self._gather_eager = {}, None, None
+            self.captured_keys = []
         make = lambda: [torch.empty(4 * n + 1, dtype=torch.int64).pin_memory(),
                         torch.empty(4 * n + 1, dtype=torch.int64, device=self.flat.device), None, 0]
         if not capturing:
@@ -423,6 +433,7 @@ class FlatGradients:
                                        "(the pinned pointer table cannot be allocated during a capture)")
                 ent, self._gather_spare = self._gather_spare, None
                 self._gather_tables[key] = ent
+                self.captured_keys.append(key)
         if ent[2] != key:
             base = self.flat.data_ptr()
             dst = [(v.data_ptr() - base) // 4 for v in self.views]
@@ -506,8 +517,9 @@ class GraphedTrainStep:
     encoder outputs, 1b = backward through the encoder and the backbone.  The decoder-side bucket (the first
     ``optimizer.boundary_offset`` floats, ~60 % of the 85.7 MB) is all-reduced asynchronously while 1b
     replays, the rest after it -- DistributedDataParallel's bucket overlap (main_utils.py:310-313) with two
-    buckets and no per-parameter hooks.  The default whenever gradients are exchanged (world size > 1);
-    ``overlap_exchange=False`` keeps the single graph + one all-reduce of the whole buffer.
+    buckets and no per-parameter hooks.  Opt-in (``overlap_exchange=True`` or BUTD_OVERLAP_EXCHANGE=1): it has
+    been exercised next to RCCL at world size 1 only (tests/test_gpu_free_running.py); the default is the
+    single graph + one all-reduce of the whole buffer.
 
     Shapes are static: every (batch, points, tokens) signature is captured once and cached.  The reference
     pads the utterances to the longest of the batch (bdetr.py:160-163), and its contrastive loss takes a
@@ -525,7 +537,7 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, clip_norm=0.1, warmup=3, group=None, prefetch_sampling=True,
-                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=True, token_bucket=None,
+                 zero_arena=True, prefetch_text=True, criterion=None, overlap_exchange=None, token_bucket=None,
                  max_slots=None, verbose=False):
         import torch.distributed as dist
         self.model, self.optimizer, self.clip_norm, self.group = model, optimizer, clip_norm, group
@@ -555,6 +567,11 @@ class GraphedTrainStep:
         self.force_collective = (os.environ.get("BUTD_FORCE_COLLECTIVE", "0") == "1"
                                  and dist.is_available() and dist.is_initialized())
         exchanging = self.world > 1 or self.force_collective
+        # The two-bucket overlapped exchange has only ever run against a SELF all-reduce (one GPU, RCCL at world
+        # size 1): until a run on >= 2 GPUs has compared its loss trajectory with the single-graph one it is opt-in
+        # (``overlap_exchange=True`` or BUTD_OVERLAP_EXCHANGE=1); the default is one graph + one all-reduce.
+        if overlap_exchange is None:
+            overlap_exchange = os.environ.get("BUTD_OVERLAP_EXCHANGE", "0") == "1"
         self.split = bool(overlap_exchange and exchanging and self.flat_opt
                           and hasattr(self._module(), "cut_at_encoder_output")
                           and 0 < optimizer.n_first < len(optimizer.params))
@@ -721,9 +738,21 @@ class GraphedTrainStep:
                     p.copy_(v)
                 self.optimizer.load_state_dict(snap["opt"])
 
+    def _flats(self):
+        return [f for f in (self.flat, getattr(self, "flat_a", None), getattr(self, "flat_b", None)) if f is not None]
+
+    def _release(self, slot):
+        """Drop what an evicted slot pinned outside itself: the gradient pointer tables of its captures (pinned host +
+        device memory keyed by the slot's gradient addresses, FlatGradients.gather)."""
+        for flat, keys in getattr(slot, "gather_keys", []):
+            for key in keys:
+                flat._gather_tables.pop(key, None)
+        slot.gather_keys = []
+
     def _capture(self, inputs, targets, tok):
         from transformers import BatchEncoding
         s = self._slot = _Slot()
+        seen = [(f, len(getattr(f, "captured_keys", []))) for f in self._flats()]
         s.cut = None
         s.announced = None
         s.inputs = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()}
@@ -792,6 +821,7 @@ class GraphedTrainStep:
         s.node_inventory = {k: dict(graph_audit.inventory(g)) for k, g in s.graphs.items()}
         for g in s.graphs.values():
             g.instantiate()
+        s.gather_keys = [(f, list(getattr(f, "captured_keys", [])[n0:])) for f, n0 in seen]
         # the captures above ran the optimizer once more under capture semantics only (nothing executed)
 
     def _pad_tokens(self, tok):
@@ -885,8 +915,8 @@ class GraphedTrainStep:
                 while len(self._slots) >= max(1, self.max_slots):
                     old_sig = next(iter(self._slots))
                     torch.cuda.synchronize()                   # its last replay may still run
-                    del self._slots[old_sig]
-                self._slot = None
+                    self._release(self._slots.pop(old_sig))
+                self._slot, self._sig = None, None             # (a failed capture must not leave a stale signature)
                 self._capture(inputs, targets, tok)
                 self._slot.announced = inputs
                 if self.verbose:

@@ -19,8 +19,13 @@ extern "C" {
  * Returns 0 or a hipError_t. */
 int butd_graph_replace_memset_nodes(void *graph, int *replaced);
 
-/* Number of nodes of `graph` by hipGraphNodeType (counts[0..15], others ignored). */
+/* Number of nodes of `graph` by hipGraphNodeType (counts[0..15], others ignored); the nodes of embedded child
+ * graphs (hipGraphNodeTypeGraph) are counted too, and butd_graph_replace_memset_nodes rewrites inside them as well. */
 int butd_graph_node_counts(void *graph, int counts[16]);
+
+/* hipRuntimeGetVersion / hipDriverGetVersion of the process: recorded next to the memset-node finding (the bug was
+ * seen on HIP runtime 7.2, torch 2.10.0+rocm7.0; tests/test_gpu_runtime_probe.py reports whether it is still there). */
+int butd_runtime_versions(int *runtime, int *driver);
 
 #ifdef __cplusplus
 }

@@ -182,3 +182,150 @@ def test_bdetr_train_six_layers_golden(backend):
         assert err.max() <= 2e-2 and err.mean() <= 5e-3, (err.max(), err.mean())
 
     _check_train6(ep, model, g, close, grad_close, backbone_tol=grad_close)
+
+
+# ---- BASELINE configs[3]'s arithmetic ("bf16 attention / FFN") against the REFERENCE's vectors ------------------------
+# The bf16 mode rounds the operands of every grouped product and of the attention core's matrix steps to bf16
+# (8 bits of mantissa: 2^-9 = 2e-3 relative per operand element, fp32 accumulation).  Through a 3-layer encoder /
+# a decoder layer that is a few 1e-3 of the output scale, a few 1e-2 on gradients.  Bounds (of max|ref|): the
+# observed maxima on MI355X with ~2x head-room; they are what "bf16" means here, not the 1e-3 of the fp32 path.
+BF16_OUT_TOL, BF16_GRAD_TOL = 2e-2, 6e-2
+_BF16_OBSERVED = {}
+
+
+@pytest.fixture
+def bf16_mode():
+    from butd_detr_amd import attention_blocks, fused_attention as fa
+    prev_b = attention_blocks.get_backend()
+    attention_blocks.set_backend("hip")
+    prev = fa.set_compute_dtype("bf16")
+    yield
+    fa.set_compute_dtype(prev)
+    attention_blocks.set_backend(prev_b)
+    if _BF16_OBSERVED:
+        root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        try:
+            import json
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "bf16_golden_errors.json"), "w") as f:
+                json.dump(_BF16_OBSERVED, f, indent=1)
+        except OSError:
+            pass
+
+
+def _bf16_close(case):
+    def check(t, ref, tol, name):
+        a = t.detach().float().cpu().numpy()
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = np.abs(a - ref) / scale
+        q99 = float(np.quantile(err, 0.99))
+        _BF16_OBSERVED[f"{case}/{name}"] = [float(err.max()), q99, float(err.mean())]
+        # 99 % of the elements within tol, the mean within tol / 4, single outliers within 4 x tol (of max|ref|)
+        assert q99 <= tol and err.mean() <= tol / 4 and err.max() <= 4 * tol, \
+            f"{case}/{name}: max {err.max():.3e} q99 {q99:.3e} mean {err.mean():.3e} vs {tol}"
+    return check
+
+
+def test_encoder_golden_bf16(bf16_mode):
+    from butd_detr_amd.encoder_decoder_layers import BiEncoder, BiEncoderLayer
+    g = load("encoder_small.npz")
+    layer = BiEncoderLayer(288, dropout=0.1, activation="relu", n_heads=8, dim_feedforward=256,
+                           self_attend_lang=True, self_attend_vis=True, use_butd_enc_attn=True)
+    model = weights.fill_(BiEncoder(layer, 3), seed=11).cuda().eval()
+    inp = cuda(encoder_inputs())
+    for k in ("vis", "text", "pos", "boxes"):
+        inp[k].requires_grad_(True)
+    vis_out, text_out = model(inp["vis"], inp["pos"], inp["vis_mask"], inp["text"], inp["text_mask"],
+                              {}, detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
+    c = _bf16_close("encoder")
+    c(vis_out, g["vis_out"], BF16_OUT_TOL, "vis_out")
+    c(text_out, g["text_out"], BF16_OUT_TOL, "text_out")
+    ((vis_out * probe(vis_out.shape, 1).cuda()).sum() + (text_out * probe(text_out.shape, 2).cuda()).sum()).backward()
+    for k, gk in (("vis", "g_vis"), ("text", "g_text"), ("pos", "g_pos"), ("boxes", "g_boxes")):
+        c(inp[k].grad, g[gk], BF16_GRAD_TOL, gk)
+    p = dict(model.named_parameters())
+    c(p["layers.0.cross_layer.cross_lv.in_proj_weight"].grad, g["g_l0_cross_lv_in_proj_weight"], BF16_GRAD_TOL, "g_lv_in")
+    c(p["layers.1.cross_layer.ffn_vl.0.weight"].grad, g["g_l1_ffn_vl_0_weight"], BF16_GRAD_TOL, "g_ffn_vl")
+    c(p["layers.1.cross_layer.norm_d.weight"].grad, g["g_l1_norm_d_weight"], BF16_GRAD_TOL, "g_norm_d")
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_decoder_layer_golden_bf16(bf16_mode, mode):
+    from butd_detr_amd.encoder_decoder_layers import BiDecoderLayer
+    g = load(f"decoder_small_{mode}.npz")
+    layer = BiDecoderLayer(288, n_heads=8, dim_feedforward=256, dropout=0.1 if mode == "eval" else 0.0,
+                           activation="relu", self_position_embedding="loc_learned", butd=True)
+    weights.fill_(layer, seed=12).cuda()
+    layer.train(mode == "train")
+    inp = cuda(decoder_inputs())
+    for k in ("query", "vis", "text", "boxes"):
+        inp[k].requires_grad_(True)
+    out = layer(inp["query"], inp["vis"], inp["text"], inp["query_pos"], None, inp["text_mask"],
+                detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
+    c = _bf16_close(f"decoder_{mode}")
+    c(out, g["out"], BF16_OUT_TOL, "out")
+    (out * probe(out.shape, 3).cuda()).sum().backward()
+    for k in ("query", "vis", "text", "boxes"):
+        c(inp[k].grad, g["g_" + k], BF16_GRAD_TOL, "g_" + k)
+    p = dict(layer.named_parameters())
+    c(p["cross_v.in_proj_weight"].grad, g["g_cross_v_in_proj_weight"], BF16_GRAD_TOL, "g_cross_v_in")
+    c(p["ffn.3.weight"].grad, g["g_ffn_3_weight"], BF16_GRAD_TOL, "g_ffn_3")
+
+
+def test_bdetr_train_six_layers_golden_bf16(bf16_mode):
+    """configs[3]'s per-GPU arithmetic on the reference's train-mode vectors (3 + 6 layers, every prefix): indices
+    bit-exact (the index ops stay fp32), outputs within the bf16 bound, gradients direction-true."""
+    import warnings
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from tests.golden.cases import train_loss, zero_dropout
+    g = load("bdetr_4096_train6.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=82,
+                           num_decoder_layers=6, self_position_embedding="loc_learned",
+                           contrastive_align_loss=True, butd=True, pointnet_ckpt=None, self_attend=True,
+                           text_encoder_factory=text_stub.factory,
+                           class_embeddings_path="/nonexistent/class_embeddings3d.npy")
+    weights.fill_(model, seed=15, skip_prefixes=("text_encoder.",))
+    zero_dropout(model.cuda().train())
+    ep = model(cuda(bdetr_inputs()))
+    train_loss(ep).backward()
+    from tests.golden.cases import PREFIXES, TRAIN_GRAD_KEYS, by_seed
+    np.testing.assert_array_equal(ep["seed_inds"].cpu().numpy(), g["seed_inds"])       # index ops stay fp32
+    # The queries are the top-82 seeds by objectness logit: under bf16 rounding seeds near the cut may change
+    # places with their neighbours, so per-query rows are compared on the seeds BOTH runs selected.
+    mine = torch.sort(ep["query_points_sample_inds"].long(), dim=1)[0].cpu().numpy()
+    theirs = g["query_seeds_sorted"]
+    rows = []
+    for b in range(mine.shape[0]):
+        common = np.intersect1d(mine[b], theirs[b])
+        assert len(common) >= 0.9 * mine.shape[1], (b, len(common))
+        rows.append((np.searchsorted(mine[b], common), np.searchsorted(theirs[b], common)))
+    _BF16_OBSERVED["train6/common_queries"] = [float(min(len(r[0]) for r in rows)) / mine.shape[1]]
+
+    def out_close(t, ref, name, per_query=False):
+        a = t.detach().float().cpu().numpy()
+        if per_query:
+            a = np.concatenate([a[b][rows[b][0]] for b in range(len(rows))])
+            ref = np.concatenate([ref[b][rows[b][1]] for b in range(len(rows))])
+        scale = max(float(np.abs(ref).max()), 1e-6)
+        err = np.abs(a - ref) / scale
+        _BF16_OBSERVED[f"train6/{name}"] = [float(err.max()), float(err.mean())]
+        # (through the backbone's 14 BatchNorm'd layers + 3 + 6 attention layers; the heads' BatchNorm1d over 2 x 82
+        #  samples amplifies: 98 % of the elements within the bound, none beyond 5x)
+        assert (err > 6e-2).mean() <= 2e-2 and err.max() <= 0.3, (name, err.max(), err.mean())
+
+    for k in ("seeds_obj_cls_logits", "proj_tokens"):
+        out_close(ep[k], g[k], k)
+    out_close(ep["seed_features"][0], g["seed_features_b0"], "seed_features_b0")
+    out_close(by_seed(ep, ep["last_proj_queries"]), g["last_proj_queries"], "last_proj_queries", True)
+    for pre in PREFIXES:
+        out_close(by_seed(ep, ep[pre + "center"]), g[pre + "center"], pre + "center", True)
+        out_close(by_seed(ep, ep[pre + "pred_size"]), g[pre + "pred_size"], pre + "pred_size", True)
+        out_close(by_seed(ep, ep[pre + "sem_cls_scores"])[:, :, :32], g[pre + "sem_cls_scores_head"], pre + "cls", True)
+    p = dict(model.named_parameters())
+    for k in TRAIN_GRAD_KEYS:       # gradients: direction-true (a changed query near the cut moves them a little too)
+        a, b = p[k].grad.detach().double().cpu().numpy().ravel(), g["g_" + k].astype(np.float64).ravel()
+        cos = float((a * b).sum() / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+        _BF16_OBSERVED[f"train6/cos:{k}"] = [cos]
+        assert cos > 0.9, (k, cos)

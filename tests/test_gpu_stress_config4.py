@@ -31,6 +31,31 @@ def test_index_ops_bit_exact_at_200k_points(oracle):
     np.testing.assert_array_equal(got_idx, ref_idx)
 
 
+def test_dense_cluster_scene_index_ops_bit_exact_vs_oracle(oracle):
+    """The configs[4] scene WITH the 10x dense cluster (the case whose work depends on density: the pruned FPS's
+    chunk re-evaluations and the grid ball query's cell occupancy) against the oracle -- the same clouds the
+    train-mode test below feeds the model: SA1 (200 000 -> 2048, r = 0.2, 64 samples) of both scenes, and SA2
+    (2048 -> 1024, r = 0.4, 32 samples) on the sampled centres.  sampling_gpu.cu:74-178, ball_query_gpu.cu:14-49."""
+    from butd_detr_amd import pointnet2_ext as ext
+    from butd_detr_amd.train_step import synthetic_batch
+    inputs, _ = synthetic_batch(2, torch.device("cuda", 0), seed=311, n_points=200000, tokens=128, dense_cluster=True)
+    xyz_d = inputs["point_clouds"][..., :3].contiguous()
+    xyz = xyz_d.cpu().numpy()
+    ref = oracle.furthest_point_sampling(xyz, 2048, multithread=True)
+    got = ext.furthest_point_sampling(xyz_d, 2048).cpu().numpy()
+    np.testing.assert_array_equal(got, ref)
+    new_xyz = np.ascontiguousarray(np.take_along_axis(xyz, ref[..., None].astype(np.int64), 1))
+    ref_idx = oracle.ball_query(new_xyz, xyz, 0.2, 64)
+    got_idx = ext.ball_query(dev(new_xyz), xyz_d, 0.2, 64).cpu().numpy()
+    np.testing.assert_array_equal(got_idx, ref_idx)
+    ref2 = oracle.furthest_point_sampling(new_xyz, 1024)
+    got2 = ext.furthest_point_sampling(dev(new_xyz), 1024).cpu().numpy()
+    np.testing.assert_array_equal(got2, ref2)
+    xyz2 = np.ascontiguousarray(np.take_along_axis(new_xyz, ref2[..., None].astype(np.int64), 1))
+    np.testing.assert_array_equal(ext.ball_query(dev(xyz2), dev(new_xyz), 0.4, 32).cpu().numpy(),
+                                  oracle.ball_query(xyz2, new_xyz, 0.4, 32))
+
+
 def _close(a, b, tol, name, frac=1e-3):
     a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
     scale = max(np.abs(b).max(), 1e-6)
@@ -122,6 +147,8 @@ def test_stress_scene_with_dense_cluster_train_mode_full_depth():
         assert ep_h["last_sem_cls_scores"].shape == (2, 512, 256) and ep_h["text_feats"].shape[1] == 128
         for key in ("sa1_inds", "sa2_inds", "fp2_inds"):
             assert torch.equal(ep_h[key], ep_t[key]), key
+        # (both backends share the HIP index ops: the indices themselves are pinned against the ORACLE on this very
+        #  scene by test_dense_cluster_scene_index_ops_bit_exact_vs_oracle above)
         for key in ("fp2_features", "seed_features", "text_memory", "seeds_obj_cls_logits"):
             _close(ep_h[key], ep_t[key], 2e-3, key)
         same = (ep_h["query_points_sample_inds"] == ep_t["query_points_sample_inds"]).float().mean().item()

@@ -302,7 +302,7 @@ def test_bf16_operand_mode_tracks_fp32_and_trains():
         zero_dropout(model.train())
         trainee = copy.deepcopy(model)     # (fresh parameters: a hipGraph capture cannot follow gradient
         #                                     accumulators that an eager backward bound to the default stream)
-        inputs, targets = synthetic_batch(4, torch.device("cuda", 0), seed=1184, n_points=50000, tokens=80)
+        inputs, targets = synthetic_batch(8, torch.device("cuda", 0), seed=1184, n_points=50000, tokens=80)   # configs[3]'s per-GPU slice
         outs = {}
         for dt in ("f32", "bf16"):
             fa.set_compute_dtype(dt)
