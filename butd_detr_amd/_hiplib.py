@@ -62,6 +62,9 @@ ATTENTION_SYMBOLS = {
     "butd_attention_fwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_attention_bwd": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
                            + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+    "butd_attention_bwd_short_keys_max": (_c_int, []),
+    "butd_attention_bwd_short_keys": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
+                                      + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_attention_fwd_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_attention_bwd_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
                                 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
@@ -71,6 +74,22 @@ ATTENTION_SYMBOLS = {
                                            + [_c_float, _c_u32, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_bwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 10
                                        + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+}
+
+class PanelStage(ctypes.Structure):
+    """ctypes mirror of ``butd_panel_stage`` (include/butd_panel.h)."""
+    _fields_ = [("w", _c_void_p), ("bias", _c_void_p), ("N", _c_int), ("K", _c_int), ("scale", _c_float),
+                ("in_buf", _c_int), ("relu", _c_int), ("drop_p", _c_float), ("drop_site", _c_u32),
+                ("pre", _c_void_p), ("ln", _c_int), ("res", _c_void_p), ("res_buf", _c_int),
+                ("gamma", _c_void_p), ("beta", _c_void_p), ("eps", _c_float),
+                ("mean", _c_void_p), ("rstd", _c_void_p), ("out", _c_void_p), ("out_buf", _c_int),
+                ("pos", _c_void_p), ("out_pos", _c_void_p), ("pos_buf", _c_int)]
+
+
+PANEL_SYMBOLS = {
+    "butd_panel_chain": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
+                                  ctypes.POINTER(PanelStage), _c_int, _c_int, _c_void_p, _c_void_p]),
+    "butd_panel_set_rows": (_c_int, [_c_int]),
 }
 
 _P = _c_void_p
@@ -147,6 +166,7 @@ GRAPH_SYMBOLS = {
     "butd_graph_replace_memset_nodes": (_c_int, [_P, ctypes.POINTER(ctypes.c_int)]),
     "butd_graph_node_counts": (_c_int, [_P, ctypes.POINTER(ctypes.c_int * 16)]),
     "butd_runtime_versions": (_c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "butd_timeline_mark": (_c_int, [_P, _c_int, _P]),
 }
 
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
@@ -158,6 +178,7 @@ ALL_SYMBOLS.update(LSAP_SYMBOLS)
 ALL_SYMBOLS.update(CRITERION_SYMBOLS)
 ALL_SYMBOLS.update(AUGMENT_SYMBOLS)
 ALL_SYMBOLS.update(GRAPH_SYMBOLS)
+ALL_SYMBOLS.update(PANEL_SYMBOLS)
 
 _lib = None
 

@@ -1164,6 +1164,276 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
   }
 }
 
+// ---- single-pass backward for SHORT KEY SETS (Lk <= 16 * NKT <= 144: the 80 text tokens, the 132 boxes) -----------
+// The two-kernel backward above computes S and dP twice (once per kernel: 72 matrix instructions per 16 x 16 score
+// tile) and is two launches of 20 us for work worth 3 us at these sizes.  Here a workgroup keeps ALL keys of its
+// (b, h) in LDS (K, V as fragment images, K also transposed), a wave owns 16 queries per query tile and walks the key
+// sub-tiles once: S[q][key] and dP[q][key] (non-transposed: C layout lane (c = key, g) -> q = 4g + i, the B operand
+// of the dK^T / dV^T products as in attn_bwd_dkv_kernel), P and dS once; dV^T += dO^T P, dK^T += Q^T dS into
+// accumulators that stay in registers for every key sub-tile across the workgroup's query tiles; dS is transposed
+// through a wave-private 16 x 16 LDS patch (4 ds_write_b32 + 1 ds_read_b128 per lane, no barrier) for
+// dQ^T += K^T dS^T.  54 matrix instructions per score tile.  dQ rows are written once (every key is in this
+// workgroup); dK / dV are summed over the four waves through LDS and added to global memory with one atomic per
+// element and workgroup -- the caller zero-fills them (they sit in the step's zero arena).
+template <int NS, int NT, int NKT>
+__global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
+    int H, int Lq, int Lk, int D, int q_tiles_per_wg, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
+    const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
+    float *__restrict__ dq, float *__restrict__ dk, float *__restrict__ dv, long ld_dq, long ld_dkv, float dq_scale,
+    float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  using I = Img<NS>;
+  constexpr int KR = NKT * 16;    // staged key rows
+  constexpr int LDT = KR + 4;     // row stride of the transposed K image
+  constexpr int LDX = 20;         // row stride of a wave's transpose patch (conflict-free for both access patterns)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float(*Kimg)[I::LD] = reinterpret_cast<float(*)[I::LD]>(smem);
+  float(*Vimg)[I::LD] = Kimg + KR;
+  float *Kt = reinterpret_cast<float *>(Vimg + KR);   // [NT * 16][LDT]
+  float *X = Kt + NT * 16 * LDT;                       // [4 waves][16][LDX]
+  float *Del = X + 4 * 16 * LDX;                       // [4 waves][16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const TileId wg = tile_id();
+  const int b = wg.b, h = wg.h;
+  const long E = (long)H * D;
+  const float *qb = q + (long)b * Lq * E + h * D;
+  const float *gb = dout + (long)b * Lq * E + h * D;
+  const float *ob = out + (long)b * Lq * E + h * D;
+  const float *kb = k + (long)b * Lk * E + h * D;
+  const float *vb = v + (long)b * Lk * E + h * D;
+  const uint8_t *mb = mask ? mask + (long)b * Lk : nullptr;
+  const bool drop = p_drop > 0.f;
+  const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+
+  // ---- stage every key once: K, V as fragment images, K transposed as well
+  {
+    const int vpr = D >> 2;
+    for (int f = tid; f < KR * vpr; f += kAttnThreads) {
+      const int row = f / vpr, c4 = f - row * vpr;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (row < Lk) {
+        kv = *reinterpret_cast<const float4 *>(kb + (long)row * E + c4 * 4);
+        vv = *reinterpret_cast<const float4 *>(vb + (long)row * E + c4 * 4);
+      }
+      const float ke[4] = {kv.x, kv.y, kv.z, kv.w}, ve[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = c4 * 4 + i;
+        Kimg[row][I::col(d)] = ke[i];
+        Vimg[row][I::col(d)] = ve[i];
+        Kt[d * LDT + row] = ke[i];
+      }
+    }
+    for (int e = tid; e < (NT * 16 - D) * KR; e += kAttnThreads) {   // rows D .. of the transposed image: zero
+      const int r = D + e / KR, c = e - (e / KR) * KR;
+      Kt[r * LDT + c] = 0.f;
+    }
+  }
+  // per lane and key sub-tile: this lane's key is t * 16 + fr
+  float bias_t[NKT];
+  bool any_bias = false;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    bias_t[t] = key_bias(mb, t * 16 + fr, Lk);
+    any_bias = any_bias || bias_t[t] != 0.f;
+  }
+  const bool wave_masked = __any(any_bias);
+  const uint32_t field_shift = (uint32_t)(fr & 1) * 16u;
+  f32x4 ak[NKT][NT], av[NKT][NT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      ak[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      av[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  __syncthreads();
+
+  float *Xw = X + wave * 16 * LDX, *Dw = Del + wave * 16;
+  for (int qt = 0; qt < q_tiles_per_wg; ++qt) {
+    const int q0 = (wg.t * q_tiles_per_wg + qt) * 64 + wave * 16;
+    if (q0 >= Lq) continue;            // (wave-uniform; nothing below synchronises across waves)
+#ifdef ATTN_SK_ABL
+    if ((ATTN_SK_ABL & 4) && q0 >= 0) continue;
+#endif
+    const int qi = q0 + fr;
+    float qf[NS], gf[NS];
+    load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
+    load_row_frag<NS>(gf, gb, E, qi, Lq, fg, D);
+    {
+      float of[NS];
+      load_row_frag<NS>(of, ob, E, qi, Lq, fg, D);
+      float part = 0.f;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) part += gf[s] * of[s];
+      const float my_delta = quad_sum(part);
+      if (fg == 0) {
+        Dw[fr] = my_delta;
+        if (qi < Lq) delta[((long)b * H + h) * Lq + qi] = my_delta;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) gf[s] *= inv_keep;    // dP is only ever used as keep * dP / (1 - p)
+    // operands of the transposed products: element n of queries 4g .. 4g+3 (this wave's 16 queries)
+    float qT[NT][4], gT[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int n = nt * 16 + fr;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int qq = q0 + fg * 4 + s;
+        const bool ok = n < D && qq < Lq;
+        qT[nt][s] = ok ? qb[(long)qq * E + n] : 0.f;
+        gT[nt][s] = ok ? gb[(long)qq * E + n] : 0.f;
+      }
+    }
+    float lq[4], dl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qq = q0 + fg * 4 + i;
+      lq[i] = qq < Lq ? lse[((long)b * H + h) * Lq + qq] * kLog2e : INFINITY;   // +inf -> probability 0
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+      const float4 d4 = *reinterpret_cast<const float4 *>(Dw + fg * 4);
+      dl[0] = d4.x; dl[1] = d4.y; dl[2] = d4.z; dl[3] = d4.w;
+    }
+    const uint32_t pair_q = (uint32_t)(((long)b * H + h) * Lq + q0 + fg * 4) * LkP + (uint32_t)(fr >> 1);
+    f32x4 dqa[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dqa[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      if (t * 16 < Lk) {    // (uniform)
+        float kf[NS], vf[NS];
+        I::frag(kf, Kimg, t * 16 + fr, fg);
+        I::frag(vf, Vimg, t * 16 + fr, fg);
+        f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          st = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], kf[s], st, 0, 0, 0);   // S[q][key]
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[s], vf[s], dp, 0, 0, 0);   // dP[q][key] / (1 - p)
+        }
+        f32x4 ka[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          ka[nt] = *reinterpret_cast<const f32x4 *>(Kt + (nt * 16 + fr) * LDT + t * 16 + fg * 4);
+        if (wave_masked) {
+          st[0] += bias_t[t]; st[1] += bias_t[t]; st[2] += bias_t[t]; st[3] += bias_t[t];
+        }
+        f32x4 pd, ds;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pd[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lq[i]));
+        if (drop) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t hh = pair_hash(hkey, pair_q + (uint32_t)i * LkP + (uint32_t)(t * 8));
+            const bool keep = ((hh >> field_shift) & 0xffffu) >= thr;
+            ds[i] = pd[i] * ((keep ? dp[i] : 0.f) - dl[i]);
+            pd[i] = keep ? pd[i] : 0.f;                    // the 1/(1-p) of dV is applied once, at the end
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ds[i] = pd[i] * (dp[i] - dl[i]);
+        }
+        // dS -> dS^T through the wave's LDS patch: element (q = 4g + i, key = fr) written, (q = fr, keys 4g ..) read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xw[(fg * 4 + i) * LDX + fr] = ds[i];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            av[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gT[nt][s], pd[s], av[t][nt], 0, 0, 0);
+            ak[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qT[nt][s], ds[s], ak[t][nt], 0, 0, 0);
+          }
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 dst = *reinterpret_cast<const f32x4 *>(Xw + fr * LDX + fg * 4);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            dqa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][s], dst[s], dqa[nt], 0, 0, 0);   // dQ^T[d][q]
+      }
+    }
+    if (qi < Lq) {
+      float *op = dq + ((long)b * Lq + qi) * ld_dq + h * D;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int d = nt * 16 + fg * 4 + i;
+          if (d < D) op[d] = dqa[nt][i] * dq_scale;
+        }
+    }
+  }
+
+#ifdef ATTN_SK_ABL
+  if ((ATTN_SK_ABL & 1) && ak[0][0][0] != 12345.678f) return;
+#endif
+  // ---- dK, dV: sum of the four waves' shares through LDS (the key images are dead), one atomic per element
+  __syncthreads();
+  float *Rd = smem;     // [4 waves][8 * NT values][64 lanes]
+  constexpr int NV = 8 * NT;
+  static_assert(4 * NV * 64 <= 2 * KR * I::LD, "reduction area must fit the key images");
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    if (t * 16 < Lk) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          Rd[(wave * NV + nt * 4 + i) * 64 + lane] = ak[t][nt][i];
+          Rd[(wave * NV + 4 * NT + nt * 4 + i) * 64 + lane] = av[t][nt][i] * inv_keep;
+        }
+      __syncthreads();
+      const int key = t * 16 + fr;
+      for (int e = wave; e < NV; e += 4) {
+        const float sum = (Rd[(0 * NV + e) * 64 + lane] + Rd[(1 * NV + e) * 64 + lane]) +
+                          (Rd[(2 * NV + e) * 64 + lane] + Rd[(3 * NV + e) * 64 + lane]);
+        const bool is_v = e >= 4 * NT;
+        const int ee = is_v ? e - 4 * NT : e;
+        const int d = (ee >> 2) * 16 + fg * 4 + (ee & 3);
+#ifdef ATTN_SK_ABL
+        if ((ATTN_SK_ABL & 2) && sum != 12345.678f) continue;
+#endif
+        if (d < D && key < Lk) atomicAdd((is_v ? dv : dk) + ((long)b * Lk + key) * ld_dkv + h * D + d, sum);
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NS, int NT, int NKT>
+int launch_smallk(int B, int H, int Lq, int Lk, int D, const float *q, const float *k, const float *v,
+                         const uint8_t *mask, const float *out, const float *dout, const float *lse, float *delta,
+                         float *dq, float *dk, float *dv, long ld_dq, long ld_dkv, float dq_scale, float p,
+                         uint32_t site, const uint64_t *rng_counter, hipStream_t s) {
+  using I = Img<NS>;
+  constexpr int KR = NKT * 16;
+  const size_t bytes = sizeof(float) * ((size_t)2 * KR * I::LD + (size_t)NT * 16 * (KR + 4) + 4 * 16 * 20 + 64);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_smallk_kernel<NS, NT, NKT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    configured = true;
+  }
+  const int tiles = (Lq + 63) / 64;
+  // query tiles per workgroup: about one workgroup per CU (each stages the keys once and keeps the dK / dV
+  // accumulators of ALL keys in registers across its tiles)
+  int per = (int)(((long)tiles * H * B) / 256);
+  per = per < 1 ? 1 : (per > tiles ? tiles : per);
+  const dim3 grid((tiles + per - 1) / per, H, B);
+  hipLaunchKernelGGL((attn_bwd_smallk_kernel<NS, NT, NKT>), grid, dim3(kAttnThreads), bytes, s, H, Lq, Lk, D, per, q, k,
+                     v, mask, out, dout, lse, delta, dq, dk, dv, ld_dq, ld_dkv, dq_scale, p, site, rng_counter);
+  return (int)hipGetLastError();
+}
+
 }  // namespace
 
 extern "C" {
@@ -1228,6 +1498,35 @@ static int attention_bwd_impl(bool bf16, int B, int H, int Lq, int Lk, int D, co
   ATTN_DISPATCH_G(attn_bwd_dkv_kernel, split_keys(gk, Lq), gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
                 dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter);
   return (int)hipGetLastError();
+}
+
+int butd_attention_bwd_short_keys_max(void) { return 144; }
+
+int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                  const float *v, const uint8_t *key_padding_mask, const float *out,
+                                  const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                                  float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                                  uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream) {
+  if (B <= 0 || H <= 0 || Lq <= 0) return 0;
+  if (D <= 0 || D > 48 || (D & 3) || Lk <= 0 || Lk > 144) return (int)hipErrorInvalidValue;
+  if (ld_dq == 0) ld_dq = (long)H * D;
+  if (ld_dkv == 0) ld_dkv = (long)H * D;
+  if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+#define SMALLK(NS, NT)                                                                                              \
+  do {                                                                                                              \
+    if (Lk <= 80)                                                                                                   \
+      return launch_smallk<NS, NT, 5>(B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq, dk, dv, \
+                                      ld_dq, ld_dkv, dq_scale, dropout_p, dropout_site, rng_counter, s);            \
+    return launch_smallk<NS, NT, 9>(B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq, dk, dv,   \
+                                    ld_dq, ld_dkv, dq_scale, dropout_p, dropout_site, rng_counter, s);              \
+  } while (0)
+  if (D <= 16) SMALLK(4, 1);
+  else if (D <= 32) SMALLK(8, 2);
+  else if (D <= 36) SMALLK(9, 3);
+  else SMALLK(12, 3);
+#undef SMALLK
+  return 0;
 }
 
 int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,

@@ -115,6 +115,17 @@ extern "C" int butd_graph_replace_memset_nodes(void *graph, int *replaced) {
   return replace_memsets((hipGraph_t)graph, replaced);
 }
 
+namespace {
+__global__ void timeline_mark_kernel(unsigned long long *slots, int slot) {
+  if (threadIdx.x == 0) slots[slot] = wall_clock64();   // s_memrealtime: constant-rate counter (100 MHz)
+}
+}  // namespace
+
+extern "C" int butd_timeline_mark(unsigned long long *slots, int slot, void *stream) {
+  hipLaunchKernelGGL(timeline_mark_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, slots, slot);
+  return (int)hipGetLastError();
+}
+
 extern "C" int butd_runtime_versions(int *runtime, int *driver) {
   hipError_t e = hipRuntimeGetVersion(runtime);
   if (e != hipSuccess) return (int)e;

@@ -111,22 +111,32 @@ class CrossAttentionLayer(nn.Module):
                                      detected_feats, detected_mask)
         return vis_out, text_out
 
-    def language_branch(self, text_feats, vis_feats, vis_key_padding_mask):
-        """language attends to vision, then its FFN"""
-        text_feats = ab.block(self.cross_lv, self.dropout_lv, self.norm_lv, x=text_feats,
-                              memory=vis_feats, key_padding_mask=vis_key_padding_mask)
-        return ab.ffn_block(self.ffn_lv, self.norm_lv2, text_feats)
+    def language_branch(self, text_feats, vis_feats, vis_key_padding_mask, q_pre=None, kv_pre=None):
+        """language attends to vision, then its FFN (one chain: the FFN runs in the kernel behind the attention core)"""
+        return ab.block(self.cross_lv, self.dropout_lv, self.norm_lv, x=text_feats, memory=vis_feats,
+                        key_padding_mask=vis_key_padding_mask, q_pre=q_pre, kv_pre=kv_pre,
+                        ffn=(self.ffn_lv, self.norm_lv2))[0]
 
     def vision_branch(self, vis_feats, text_in, text_key_padding_mask, pos_feats,
-                      detected_feats=None, detected_mask=None):
+                      detected_feats=None, detected_mask=None, xq_pre=None, q_pre=None, kv_pre=None):
         """vision attends to language (keys/values = the layer INPUT text), [to the boxes], FFN"""
         # positional features only on the query (:79-80)
-        vis_feats = ab.block(self.cross_vl, self.dropout_vl, self.norm_vl, x=vis_feats, pos=pos_feats,
-                             memory=text_in, key_padding_mask=text_key_padding_mask)
-        if detected_feats is not None and self.use_butd_enc_attn:
-            vis_feats = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=vis_feats,
-                                 memory=detected_feats, key_padding_mask=detected_mask)
-        return ab.ffn_block(self.ffn_vl, self.norm_vl2, vis_feats)
+        boxes = detected_feats is not None and self.use_butd_enc_attn
+        vis_feats, _, em = ab.block(self.cross_vl, self.dropout_vl, self.norm_vl, x=vis_feats, pos=pos_feats,
+                                    memory=text_in, key_padding_mask=text_key_padding_mask, xq_pre=xq_pre,
+                                    q_pre=q_pre, kv_pre=kv_pre,
+                                    emit=[ab.q_projection(self.cross_d, False)] if boxes else None,
+                                    ffn=None if boxes else (self.ffn_vl, self.norm_vl2))
+        if boxes:
+            vis_feats = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=vis_feats, memory=detected_feats,
+                                 key_padding_mask=detected_mask, q_pre=em[0] if em else None,
+                                 ffn=(self.ffn_vl, self.norm_vl2))[0]
+        return vis_feats
+
+    def self_emits(self):
+        """What the two self-attention blocks in front of this layer emit for it: (vision side, language side)."""
+        return ([ab.q_projection(self.cross_vl, True)] + ab.kv_projections(self.cross_lv),
+                [ab.q_projection(self.cross_lv, False)] + ab.kv_projections(self.cross_vl))
 
 
 class TransformerEncoderLayerNoFFN(nn.Module):
@@ -138,19 +148,22 @@ class TransformerEncoderLayerNoFFN(nn.Module):
         self.norm1 = nn.LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)
 
-    def forward(self, src, src_mask=None, src_key_padding_mask=None):
+    def forward(self, src, src_mask=None, src_key_padding_mask=None, emit=None):
+        """``emit``: projections of the output for the blocks that follow -> (out, None, [projections])."""
         assert src_mask is None, "attn_mask is never used on this path"
         return ab.block(self.self_attn, self.dropout1, self.norm1, x=src,
-                        key_padding_mask=src_key_padding_mask)
+                        key_padding_mask=src_key_padding_mask, emit=emit)
 
 
 class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
     """Same, with the positional embedding added to query and key (not value)."""
 
-    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None):
+    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, emit=None):
+        """``emit``: as above; the output + pos is produced too -> (out, out + pos, [projections])."""
         assert src_mask is None, "attn_mask is never used on this path"
         return ab.block(self.self_attn, self.dropout1, self.norm1, x=src, pos=pos,
-                        key_padding_mask=src_key_padding_mask)
+                        key_padding_mask=src_key_padding_mask, emit=emit,
+                        next_pos=pos if emit is not None else None)
 
 
 _LANGUAGE_STREAMS = {}
@@ -184,50 +197,52 @@ class BiEncoderLayer(nn.Module):
 
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
                 end_points={}, detected_feats=None, detected_mask=None):
-        if _fork_language(vis_feats):
-            return self._forward_forked(vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
-                                        detected_feats, detected_mask)
-        if self.self_attention_visual is not None:
-            vis_feats = self.self_attention_visual(vis_feats, pos_feats,
-                                                   src_key_padding_mask=padding_mask)
-        if self.self_attention_lang is not None:
-            text_feats = self.self_attention_lang(text_feats,
-                                                  src_key_padding_mask=text_padding_mask)
-        return self.cross_layer(vis_feats=vis_feats, vis_key_padding_mask=padding_mask,
-                                text_feats=text_feats, text_key_padding_mask=text_padding_mask,
-                                pos_feats=pos_feats, detected_feats=detected_feats,
-                                detected_mask=detected_mask)
-
-    def _forward_forked(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
-                        detected_feats, detected_mask):
-        """The language side of the layer (self-attention over <= 80 tokens, language <- vision cross-attention,
-        its FFN: ~25 launches forward, ~60 backward, most of them 640-row kernels that leave the chip idle) on a
-        forked stream next to the vision side, which is several times longer.  The two sides only read each
-        other's self-attention outputs (encoder_decoder_layers.py:83,101-102), so there are two hand-over points;
-        fork / join are captured as parallel branches of the hipGraph, autograd runs each node's backward on the
-        stream of its forward."""
-        main = torch.cuda.current_stream(vis_feats.device)
-        side = _language_stream(vis_feats.device)
-        side.wait_stream(main)
-        text_feats.record_stream(side)
-        with torch.cuda.stream(side):
-            text_self = text_feats
-            if self.self_attention_lang is not None:
-                text_self = self.self_attention_lang(text_feats, src_key_padding_mask=text_padding_mask)
-        vis_self = vis_feats
-        if self.self_attention_visual is not None:
-            vis_self = self.self_attention_visual(vis_feats, pos_feats, src_key_padding_mask=padding_mask)
-        side.wait_stream(main)                  # language <- vision reads vis_self
-        main.wait_stream(side)                  # vision <- language reads text_self
-        vis_self.record_stream(side)
-        text_self.record_stream(main)
+        fork = _fork_language(vis_feats)
+        if fork:
+            main = torch.cuda.current_stream(vis_feats.device)
+            side = _language_stream(vis_feats.device)
+        else:
+            main = side = None
+        from contextlib import nullcontext
+        on_side = (lambda: torch.cuda.stream(side)) if fork else nullcontext
+        # The language side of the layer (self-attention over <= 80 tokens, language <- vision cross-attention, its
+        # FFN: 640-row kernels that leave the chip idle) runs on a forked stream next to the vision side, which is
+        # several times longer.  The two sides only read each other's self-attention outputs
+        # (encoder_decoder_layers.py:83,101-102), so there are two hand-over points; fork / join are captured as
+        # parallel branches of the hipGraph, autograd runs each node's backward on the stream of its forward.
+        # The self-attention blocks also emit the projections the cross layer needs from their outputs (its query
+        # projections on their own side, the key / value projections for the other side).
         cross = self.cross_layer
-        with torch.cuda.stream(side):
-            text_out = cross.language_branch(text_self, vis_self, padding_mask)
+        vis_emit, text_emit = cross.self_emits()
+        if fork:
+            side.wait_stream(main)
+            text_feats.record_stream(side)
+        with on_side():
+            text_self, text_em = text_feats, []
+            if self.self_attention_lang is not None:
+                text_self, _, text_em = self.self_attention_lang(text_feats, src_key_padding_mask=text_padding_mask,
+                                                                 emit=text_emit)
+        vis_self, vis_self_pos, vis_em = vis_feats, None, []
+        if self.self_attention_visual is not None:
+            vis_self, vis_self_pos, vis_em = self.self_attention_visual(vis_feats, pos_feats,
+                                                                        src_key_padding_mask=padding_mask,
+                                                                        emit=vis_emit)
+        if fork:
+            side.wait_stream(main)                  # language <- vision reads vis_self (+ its key / value projections)
+            main.wait_stream(side)                  # vision <- language reads text_self (+ ...)
+            for t in [vis_self] + list(vis_em[1:]):
+                t.record_stream(side)
+            for t in [text_self] + list(text_em[1:]):
+                t.record_stream(main)
+        q_vl, kv_lv = (vis_em[0], tuple(vis_em[1:])) if vis_em else (None, None)
+        q_lv, kv_vl = (text_em[0], tuple(text_em[1:])) if text_em else (None, None)
+        with on_side():
+            text_out = cross.language_branch(text_self, vis_self, padding_mask, q_pre=q_lv, kv_pre=kv_lv)
         vis_out = cross.vision_branch(vis_self, text_self, text_padding_mask, pos_feats, detected_feats,
-                                      detected_mask)
-        main.wait_stream(side)                  # join
-        text_out.record_stream(main)
+                                      detected_mask, xq_pre=vis_self_pos, q_pre=q_vl, kv_pre=kv_vl)
+        if fork:
+            main.wait_stream(side)                  # join
+            text_out.record_stream(main)
         return vis_out, text_out
 
 
@@ -295,17 +310,22 @@ class BiDecoderLayer(nn.Module):
 
         # the four blocks' position gradients arrive together and are summed in one pass (fan_out.py)
         pos_s, pos_l, pos_d, pos_v = fan_out(query_pos, 4)
-        # ... and every block writes `its output + query_pos` for the next one while the output is in registers
+        # ... and every block's kernel also writes `its output + query_pos` and the NEXT block's query projection
+        # while the rows are in LDS; the last one runs the FFN as well
         nxt = query_pos if query_pos is not None else None
-        two = lambda r: r if isinstance(r, tuple) else (r, None)
-        query, qp = two(ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s,
-                                 key_padding_mask=padding_mask, next_pos=nxt))
-        query, qp = two(ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l, xq_pre=qp,
-                                 memory=lang_feats, key_padding_mask=text_key_padding_mask, next_pos=nxt))
-        if detected_feats is not None:
-            query, qp = two(ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d, xq_pre=qp,
-                                     memory=detected_feats, key_padding_mask=detected_mask, next_pos=nxt))
-        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v, xq_pre=qp,
-                         memory=vis_feats, key_padding_mask=None)
-        query = ab.ffn_block(self.ffn, self.norm2, query)
+        has_pos = nxt is not None
+        first = lambda em: em[0] if em else None
+        boxes = detected_feats is not None
+        query, qp, em = ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s,
+                                 key_padding_mask=padding_mask, next_pos=nxt,
+                                 emit=[ab.q_projection(self.cross_l, has_pos)])
+        query, qp, em = ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l, xq_pre=qp,
+                                 q_pre=first(em), memory=lang_feats, key_padding_mask=text_key_padding_mask,
+                                 next_pos=nxt, emit=[ab.q_projection(self.cross_d if boxes else self.cross_v, has_pos)])
+        if boxes:
+            query, qp, em = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d, xq_pre=qp,
+                                     q_pre=first(em), memory=detected_feats, key_padding_mask=detected_mask,
+                                     next_pos=nxt, emit=[ab.q_projection(self.cross_v, has_pos)])
+        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v, xq_pre=qp, q_pre=first(em),
+                         memory=vis_feats, key_padding_mask=None, ffn=(self.ffn, self.norm2))[0]
         return query.contiguous()

@@ -14,6 +14,7 @@ once per model forward, so a captured hipGraph draws fresh masks on every replay
 """
 import ctypes
 import math
+import os
 
 import torch
 
@@ -140,6 +141,22 @@ def _attn_bwd():
     return _lib.butd_attention_bwd_bf16 if _compute_bf16[0] else _lib.butd_attention_bwd
 
 
+_short_keys = [os.environ.get("BUTD_ATTN_SHORT_KEYS", "1") != "0"]
+_SHORT_KEYS_MAX = int(_lib.butd_attention_bwd_short_keys_max())
+
+
+def set_short_keys(flag):
+    """A/B switch (also BUTD_ATTN_SHORT_KEYS=0): the one-kernel backward for key sets of <= 144 rows."""
+    prev, _short_keys[0] = _short_keys[0], bool(flag)
+    return prev
+
+
+def _short_key_bwd(Lk):
+    """The single-pass backward (``butd_attention_bwd_short_keys``: dk / dv accumulated, caller zero-fills) serves this
+    call: short key set, fp32 matrix steps."""
+    return _short_keys[0] and not _compute_bf16[0] and Lk <= _SHORT_KEYS_MAX
+
+
 def get_compute_dtype():
     return "bf16" if _compute_bf16[0] else "f32"
 
@@ -195,6 +212,47 @@ def _check(*tensors):
         if t is not None:
             assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), \
                 "fused attention kernels take contiguous fp32 CUDA tensors"
+
+
+# -------------------------------------------------------------------------------------------------
+# Row-panel chains (include/butd_panel.h): the row-wise operators behind an attention core -- out-projection, dropout,
+# residual, LayerNorm, + pos, projections of the result that the NEXT blocks need, the FFN -- as one launch.
+# -------------------------------------------------------------------------------------------------
+from ._hiplib import PanelStage  # noqa: E402
+
+# OFF by default: measured (profiles/r04_panel_chain.txt).  A stage of a 16-row panel is 360 dependent fp32 matrix
+# instructions per wave on at most 128 of the 256 CUs (2048 rows = 128 panels; the 16 x 16 x 4 tile cannot be cut
+# below 16 rows) = 10 us of matrix time per stage, 14 us with the weights streamed from L2 -- a grouped GEMM launch
+# serves the same product in 6.5-9.4 us on the whole chip.  Fusing therefore only pays where it removes launches
+# that do no matrix work: the step with every chain on is 0.9 ms SLOWER than with none (26.96 vs 26.09 ms).
+_panel_chain = [os.environ.get("BUTD_PANEL_CHAIN", "0") == "1"]
+
+
+def set_panel_chain(flag):
+    """A/B switch (also BUTD_PANEL_CHAIN=1): off = every operator of a block is its own launch, as in round 3."""
+    prev, _panel_chain[0] = _panel_chain[0], bool(flag)
+    return prev
+
+
+def _panel_ok(*dims):
+    return (_panel_chain[0] and not _compute_bf16[0] and all(d in (128, 256, 288) for d in dims))
+
+
+def _stage(w, bias, N, K, in_buf, out_buf, *, scale=1.0, relu=False, drop=(0.0, 0), pre=None, ln=None, res=None,
+           res_buf=-1, out=None, pos=None, out_pos=None, pos_buf=-1):
+    """ln = (gamma, beta, eps, mean, rstd) or None."""
+    g, b, eps, mean, rstd = ln if ln is not None else (None, None, 0.0, None, None)
+    return PanelStage(_ptr(w), _ptr(bias), N, K, float(scale), in_buf, int(relu), float(drop[0]), int(drop[1]),
+                      _ptr(pre), int(ln is not None), _ptr(res), res_buf, _ptr(g), _ptr(b), float(eps),
+                      _ptr(mean), _ptr(rstd), _ptr(out), out_buf, _ptr(pos), _ptr(out_pos), pos_buf)
+
+
+def _panel(rows, inp, in_cols, stages, nbuf, ref, in_buf=0, in_pos=None, in_sum=None, in_sum_buf=1):
+    arr = (PanelStage * len(stages))(*stages)
+    with torch.cuda.device(ref.device):
+        err = _lib.butd_panel_chain(rows, inp.data_ptr(), in_cols, in_buf, _ptr(in_pos), _ptr(in_sum), in_sum_buf,
+                                    arr, len(stages), nbuf, rng_counter(ref.device).data_ptr(), _stream(ref))
+    _hiplib.check(err, "butd_panel_chain")
 
 
 class _AttentionBlock(torch.autograd.Function):
@@ -268,12 +326,14 @@ class _AttentionBlock(torch.autograd.Function):
         d_att = torch.empty((B, Lq, E), device=dev)
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
                _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], xq)
+        short = _short_key_bwd(Lk)
         dq = torch.empty((B, Lq, E), device=dev)
-        dk = torch.empty((B, Lk, E), device=dev)
-        dv = torch.empty((B, Lk, E), device=dev)
+        dk = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
+        dv = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
         delta = torch.empty((B, H, Lq), device=dev)
         with torch.cuda.device(dev):
-            err = _attn_bwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            err = (_lib.butd_attention_bwd_short_keys if short else _attn_bwd())(
+                                          B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                           _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
                                           delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
                                           0, 0, 1.0, p_attn, site_attn, rng_counter(dev).data_ptr(),
@@ -295,23 +355,33 @@ class _AttentionBlock(torch.autograd.Function):
 
 class _FfnBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, p2, site1, site2):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, p2, site1, site2, pre=None):
         B, L, E = x.shape
         Fh = w1.shape[0]
         M = B * L
         dev = x.device
-        h = torch.empty((B, L, Fh), device=dev)
-        _gemm([_fwd(x, w1, h, M, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
-        o = torch.empty((B, L, E), device=dev)
-        _gemm([_fwd(h, w2, o, M, E, Fh, bias=b2)], x)
-        y = torch.empty((B, L, E), device=dev)
-        mean = torch.empty((M,), device=dev)
-        rstd = torch.empty((M,), device=dev)
-        with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_fwd(
-                M, E, o.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
-                mean.data_ptr(), rstd.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _stream(x))
-        _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
+        if pre is not None:
+            # the kernel that produced x ran the FFN on the rows it still held in LDS (block(..., ffn=...)): values only
+            # -- the gradients are this Function's as ever
+            h, o, mean, rstd, y = pre
+        else:
+            h = torch.empty((B, L, Fh), device=dev)
+            o = torch.empty((B, L, E), device=dev)
+            y = torch.empty((B, L, E), device=dev)
+            mean = torch.empty((M,), device=dev)
+            rstd = torch.empty((M,), device=dev)
+            if _panel_ok(E, Fh):
+                _panel(M, x, E, [_stage(w1, b1, Fh, E, 0, 1, relu=True, drop=(p1, site1), out=h),
+                                 _stage(w2, b2, E, Fh, 1, 2, pre=o, drop=(p2, site2),
+                                        ln=(gamma, beta, eps, mean, rstd), res_buf=0, out=y)], 3, x)
+            else:
+                _gemm([_fwd(x, w1, h, M, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
+                _gemm([_fwd(h, w2, o, M, E, Fh, bias=b2)], x)
+                with torch.cuda.device(dev):
+                    err = _lib.butd_add_dropout_layernorm_fwd(
+                        M, E, o.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
+                        mean.data_ptr(), rstd.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _stream(x))
+                _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
         ctx.save_for_backward(x, w1, w2, gamma, h, o, mean, rstd)
         ctx.cfg = (p1, p2, site1, site2)
         return y
@@ -349,7 +419,7 @@ class _FfnBlock(torch.autograd.Function):
                _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)], x)
         _gemm([_dgrad(d_h, w1, d_x, M, Fh, E, c_add=True),
                _wgrad(d_h, x, d_w1, d_b1, M, Fh, E)], x)
-        return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None
+        return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None, None
 
 
 class _LinearReluChain(torch.autograd.Function):
@@ -520,24 +590,59 @@ class _XpmBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, mem, mask, w_in, b_in, w_o, b_o, gamma, beta,
-                num_heads, eps, p_attn, p_out, site_attn, site_out, xq_pre=None, next_pos=None):
+                num_heads, eps, p_attn, p_out, site_attn, site_out, xq_pre=None, next_pos=None,
+                q_pre=None, kv_pre=None, emit=None, ffn=None):
+        """-> (y, y + next_pos | None, *emitted projections, *(h, o, mean2, rstd2, y2) of a chained FFN).
+
+        q_pre / kv_pre: this block's query / (key, value) projections as an earlier kernel already produced them
+        (values only: the gradients of x, pos, mem and of the projection weights are this block's as ever).
+        emit: [(weight (E, E), bias (E), scale, use_pos)]: projections of y (or y + next_pos) that later blocks take as
+        their q_pre / kv_pre.  ffn: (w1, b1, w2, b2, gamma2, beta2, eps2, p1, p2, site1, site2): LayerNorm(y + FFN(y))
+        computed on the rows while they are in LDS, handed to _FfnBlock as ``pre``."""
         B, Lq, E = x.shape
         H, D = num_heads, E // num_heads
         dev = x.device
         self_attn = mem is None
-        # xq_pre: x + pos as the PREVIOUS block's LayerNorm kernel already wrote it (data only: the gradients of x
-        # and pos are this block's as ever); next_pos: write y + next_pos for the next block the same way
-        xq = x if pos is None else (xq_pre if xq_pre is not None else x + pos)
+        scale = math.sqrt(1.0 / float(D))
+        chain = _panel_ok(E) and (ffn is None or _panel_ok(ffn[0].shape[0]))
+        Mq = B * Lq
+        q = q_pre
+        k, v = kv_pre if kv_pre is not None else (None, None)
+        xq = x if pos is None else xq_pre
+        if self_attn and q is None and k is None and chain:
+            # q, k, v of a self-attention block as one panel launch that also forms (and saves) x + pos
+            q = torch.empty((B, Lq, E), device=dev)
+            k = torch.empty((B, Lq, E), device=dev)
+            v = torch.empty((B, Lq, E), device=dev)
+            form = pos is not None and xq is None
+            if form:
+                xq = torch.empty((B, Lq, E), device=dev)
+            qk_in = 1 if pos is not None else 0
+            if form or pos is None:
+                _panel(Mq, x, E, [_stage(w_in[:E], b_in[:E], E, E, qk_in, 2, scale=scale, out=q),
+                                  _stage(w_in[E:2 * E], b_in[E:2 * E], E, E, qk_in, 2, out=k),
+                                  _stage(w_in[2 * E:], b_in[2 * E:], E, E, 0, 2, out=v)], 3, x,
+                       in_pos=pos if form else None, in_sum=xq if form else None)
+            else:       # x + pos arrived from the previous kernel: two inputs, one per launch
+                _panel(Mq, xq, E, [_stage(w_in[:E], b_in[:E], E, E, 0, 1, scale=scale, out=q),
+                                   _stage(w_in[E:2 * E], b_in[E:2 * E], E, E, 0, 1, out=k)], 2, x)
+                _panel(Mq, x, E, [_stage(w_in[2 * E:], b_in[2 * E:], E, E, 0, 1, out=v)], 2, x)
+        if xq is None:
+            xq = x + pos
         xk, xv = (xq, x) if self_attn else (mem, mem)
         Lk = xk.shape[1]
-        Mq, Mk = B * Lq, B * Lk
-        q = torch.empty((B, Lq, E), device=dev)
-        k = torch.empty((B, Lk, E), device=dev)
-        v = torch.empty((B, Lk, E), device=dev)
-        scale = math.sqrt(1.0 / float(D))
-        _gemm([_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale),
-               _fwd(xk, w_in[E:2 * E], k, Mk, E, E, bias=b_in[E:2 * E]),
-               _fwd(xv, w_in[2 * E:], v, Mk, E, E, bias=b_in[2 * E:])], x)
+        Mk = B * Lk
+        probs = []
+        if q is None:
+            q = torch.empty((B, Lq, E), device=dev)
+            probs.append(_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale))
+        if k is None:
+            k = torch.empty((B, Lk, E), device=dev)
+            v = torch.empty((B, Lk, E), device=dev)
+            probs += [_fwd(xk, w_in[E:2 * E], k, Mk, E, E, bias=b_in[E:2 * E]),
+                      _fwd(xv, w_in[2 * E:], v, Mk, E, E, bias=b_in[2 * E:])]
+        if probs:
+            _gemm(probs, x)
         att = torch.empty((B, Lq, E), device=dev)
         lse = torch.empty((B, H, Lq), device=dev)
         with torch.cuda.device(dev):
@@ -546,30 +651,70 @@ class _XpmBlock(torch.autograd.Function):
                                           rng_counter(dev).data_ptr(), _stream(x))
         _hiplib.check(err, "butd_attention_fwd")
         proj = torch.empty((B, Lq, E), device=dev)
-        _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
         y = torch.empty((B, Lq, E), device=dev)
         mean = torch.empty((Mq,), device=dev)
         rstd = torch.empty((Mq,), device=dev)
         y_pos = torch.empty((B, Lq, E), device=dev) if next_pos is not None else None
-        with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_fwd_pos(
-                Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
-                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
-                rng_counter(dev).data_ptr(), _ptr(next_pos), _ptr(y_pos), _stream(x))
-        _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
+        emit = emit or []
+        emitted = [torch.empty((B, Lq, E), device=dev) for _ in emit]
+        ffn_out = ()
+        if ffn is not None:
+            w1, b1, w2, b2, g2, be2, eps2, p1, p2, site1, site2 = ffn
+            Fh = w1.shape[0]
+            ffn_out = (torch.empty((B, Lq, Fh), device=dev), torch.empty((B, Lq, E), device=dev),
+                       torch.empty((Mq,), device=dev), torch.empty((Mq,), device=dev),
+                       torch.empty((B, Lq, E), device=dev))
+        if chain:
+            use_pos = any(e[3] for e in emit) and next_pos is not None
+            nbuf = 3
+            stages = [_stage(w_o, b_o, E, E, 0, 1, pre=proj, drop=(p_out, site_out), ln=(gamma, beta, eps, mean, rstd),
+                             res=x, out=y, pos=next_pos, out_pos=y_pos, pos_buf=2 if use_pos else -1)]
+            for (w_e, b_e, sc_e, pos_e), t in zip(emit, emitted):
+                stages.append(_stage(w_e, b_e, E, E, 2 if (pos_e and use_pos) else 1, 0, scale=sc_e, out=t))
+            if ffn is not None:
+                hb = 2
+                if use_pos:
+                    hb, nbuf = 3, 4
+                h, o2, mean2, rstd2, y2 = ffn_out
+                stages += [_stage(w1, b1, Fh, E, 1, hb, relu=True, drop=(p1, site1), out=h),
+                           _stage(w2, b2, E, Fh, hb, 0, pre=o2, drop=(p2, site2), ln=(g2, be2, eps2, mean2, rstd2),
+                                  res_buf=1, out=y2)]
+            _panel(Mq, att, E, stages, nbuf, x)
+        else:
+            _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
+            with torch.cuda.device(dev):
+                err = _lib.butd_add_dropout_layernorm_fwd_pos(
+                    Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
+                    y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
+                    rng_counter(dev).data_ptr(), _ptr(next_pos), _ptr(y_pos), _stream(x))
+            _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
+            if emit:
+                _gemm([_fwd(y_pos if (pos_e and y_pos is not None) else y, w_e, t, Mq, E, E, bias=b_e, scale=sc_e)
+                       for (w_e, b_e, sc_e, pos_e), t in zip(emit, emitted)], x)
+            if ffn is not None:
+                h, o2, mean2, rstd2, y2 = ffn_out
+                _gemm([_fwd(y, w1, h, Mq, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
+                _gemm([_fwd(h, w2, o2, Mq, E, Fh, bias=b2)], x)
+                with torch.cuda.device(dev):
+                    err = _lib.butd_add_dropout_layernorm_fwd(
+                        Mq, E, o2.data_ptr(), y.data_ptr(), g2.data_ptr(), be2.data_ptr(), eps2, y2.data_ptr(),
+                        mean2.data_ptr(), rstd2.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _stream(x))
+                _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
         ctx.save_for_backward(x, xq if pos is not None else None, mem, mask, w_in, w_o, gamma, q, k, v,
                               att, lse, proj, mean, rstd)
         ctx.cfg = (H, p_attn, p_out, site_attn, site_out)
-        if next_pos is None:
+        extras = ([y_pos] if y_pos is not None else []) + emitted + list(ffn_out)
+        if not extras:
             return y
-        ctx.mark_non_differentiable(y_pos)
-        ctx.set_materialize_grads(False)             # no zero tensor for y_pos's (non-existent) gradient
-        return y, y_pos
+        ctx.mark_non_differentiable(*extras)
+        ctx.set_materialize_grads(False)             # no zero tensors for the (non-existent) gradients of the extras
+        ctx.n_out = 1 + len(extras)
+        return (y, *extras)
 
     @staticmethod
-    def backward(ctx, dy, _d_y_pos=None):
+    def backward(ctx, dy, *_d_extras):
         if dy is None:                                 # (gradients are not materialised: the block's output unused)
-            return (None,) * 18
+            return (None,) * 22
         x, xq_saved, mem, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean, rstd = ctx.saved_tensors
         H, p_attn, p_out, site_attn, site_out = ctx.cfg
         has_pos = xq_saved is not None
@@ -602,21 +747,24 @@ class _XpmBlock(torch.autograd.Function):
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
                _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], x)
         # gradients of the attention core, packed: self: G = [dq | dk | dv]; cross: dq, G = [dk | dv]
+        short = _short_key_bwd(Lk)      # (one kernel that ACCUMULATES dk / dv: zero-filled from the step's arena)
+        new_g = (lambda shape: zeros(shape, device=dev)) if short else (lambda shape: torch.empty(shape, device=dev))
         if self_attn:
-            G = torch.empty((B, Lq, 3 * E), device=dev)
+            G = new_g((B, Lq, 3 * E))
             ldg = 3 * E
             dq_ptr, dk_ptr, dv_ptr = G.data_ptr(), G.data_ptr() + 4 * E, G.data_ptr() + 8 * E
             ld_dq = ldg
         else:
             dq = torch.empty((B, Lq, E), device=dev)
-            G = torch.empty((B, Lk, 2 * E), device=dev)
+            G = new_g((B, Lk, 2 * E))
             ldg = 2 * E
             dq_ptr, dk_ptr, dv_ptr = dq.data_ptr(), G.data_ptr(), G.data_ptr() + 4 * E
             ld_dq = E
         delta = torch.empty((B, H, Lq), device=dev)
         scale = math.sqrt(1.0 / float(D))
         with torch.cuda.device(dev):
-            err = _attn_bwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+            err = (_lib.butd_attention_bwd_short_keys if short else _attn_bwd())(
+                                          B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
                                           _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
                                           delta.data_ptr(), dq_ptr, dk_ptr, dv_ptr, ld_dq, ldg, scale,
                                           p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))
@@ -645,13 +793,19 @@ class _XpmBlock(torch.autograd.Function):
                    _xwgrad(dq, E, xq, d_w_in[:E], d_b_in[:E], Mq, E, E),
                    _xwgrad(G, ldg, mem, d_w_in[E:], d_b_in[E:], Mk, 2 * E, E)], x)
         return (R, d_pos, d_mem, None, d_w_in, d_b_in, d_w_o, d_b_o, d_gamma, d_beta,
-                None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
-def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None):
+def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None,
+          q_pre=None, kv_pre=None, emit=None, ffn=None):
     """LayerNorm(x + Dropout(MHA(x + pos, k, v))), (k, v) = (x + pos, x) or (memory, memory).
-    ``next_pos``: also return ``y + next_pos`` (written by the LayerNorm kernel; no gradient flows through it) for the
-    next block, which takes it as ``xq_pre`` in place of computing ``x + pos`` itself: -> (y, y + next_pos)."""
+    ``next_pos``: also return ``y + next_pos`` (written by the kernel that produced y; no gradient flows through it) for
+    the next block, which takes it as ``xq_pre`` in place of computing ``x + pos`` itself.
+    ``emit``: projections of y / y + next_pos (``q_projection``, ``kv_projections``) computed by the same kernel, to
+    be handed to later blocks as ``q_pre`` / ``kv_pre`` (values only: those blocks own the gradients).
+    ``ffn`` = (ffn Sequential, norm): the FFN block on y in the same kernel.
+    -> y                                   (no extras asked for)
+    -> (y, y + next_pos | None, [emitted...])   otherwise; with ``ffn`` the first element is LayerNorm(y + FFN(y))."""
     training = attn.training
     p_attn = float(attn.dropout) if training else 0.0
     p_out = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
@@ -661,7 +815,32 @@ def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, 
     next_pos = None if next_pos is None else next_pos.detach().contiguous()
     xq_pre = None if (xq_pre is None or pos is None) else xq_pre.detach()
     _check(x, pos, memory)
-    return _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
-                           attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
-                           norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
-                           _next_site(), _next_site(), xq_pre, next_pos)
+    extras_asked = next_pos is not None or emit is not None or ffn is not None
+    chain = _panel_ok(x.shape[-1]) and (ffn is None or _panel_ok(ffn[0][0].out_features))
+    if not chain:       # no chain kernels: the hints that only pay inside one are dropped (round 3's launches)
+        emit, q_pre, kv_pre = None, None, None
+    emit = [(w.detach(), b.detach(), sc, up) for w, b, sc, up in (emit or [])]
+    ffn_pack = None
+    if ffn is not None:
+        seq, norm2 = ffn
+        lin1, _, drop1, lin2, drop2 = seq
+        p1 = float(drop1.p) if drop1.training else 0.0
+        p2 = float(drop2.p) if drop2.training else 0.0
+        ffn_sites = (_next_site(), _next_site())      # (numbered before the block's own: the same on both paths)
+        if chain:
+            ffn_pack = (lin1.weight.detach(), lin1.bias.detach(), lin2.weight.detach(), lin2.bias.detach(),
+                        norm2.weight.detach(), norm2.bias.detach(), float(norm2.eps), p1, p2, *ffn_sites)
+    out = _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
+                          attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
+                          norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
+                          _next_site(), _next_site(), xq_pre, next_pos,
+                          None if q_pre is None else q_pre.detach(),
+                          None if kv_pre is None else tuple(t.detach() for t in kv_pre), emit, ffn_pack)
+    out = list(out) if isinstance(out, tuple) else [out]
+    y = out.pop(0)
+    y_pos = out.pop(0) if next_pos is not None else None
+    emitted = [out.pop(0) for _ in emit]
+    if ffn is not None:
+        y = _FfnBlock.apply(y, lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm2.weight, norm2.bias,
+                            float(norm2.eps), p1, p2, *ffn_sites, tuple(out) if chain else None)
+    return (y, y_pos, emitted) if extras_asked else y

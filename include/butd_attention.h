@@ -119,6 +119,17 @@ int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
                        float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
                        uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
 
+/* Backward of butd_attention_fwd for SHORT KEY SETS (Lk <= butd_attention_bwd_short_keys_max() = 144: the <= 80 text
+ * tokens and the 132 detected boxes of the cross-attention sites, models/encoder_decoder_layers.py:87-122,376-395)
+ * as ONE kernel that computes every score tile once: same arguments and results as butd_attention_bwd, except that
+ * dk and dv are ACCUMULATED into (one atomic add per element and workgroup): the caller zero-fills them.  fp32. */
+int butd_attention_bwd_short_keys_max(void);
+int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                  const float *v, const uint8_t *key_padding_mask, const float *out,
+                                  const float *dout, const float *lse, float *delta, float *dq, float *dk,
+                                  float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
+                                  uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
+
 /* The same two entry points with the matrix steps on the bf16 matrix cores (BASELINE configs[3]: "bf16 attention"):
  * operands rounded to bf16 (nearest even) in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulation; scores'
  * statistics, exponentials, the (o, m, l) state, dropout masks and every tensor in memory are fp32 as above. */

@@ -23,6 +23,12 @@ int butd_graph_replace_memset_nodes(void *graph, int *replaced);
  * graphs (hipGraphNodeTypeGraph) are counted too, and butd_graph_replace_memset_nodes rewrites inside them as well. */
 int butd_graph_node_counts(void *graph, int counts[16]);
 
+/* Profiler-free timeline: a one-wave kernel that writes the device's constant-rate wall clock (s_memrealtime, 100 MHz)
+ * into slots[slot] when the stream reaches it.  Captured into the step's hipGraph at region boundaries it gives the
+ * in-situ duration of each region without rocprofv3 (which serialises the queues of a multi-stream graph);
+ * scratch/step_marks.py.  Not on the product path. */
+int butd_timeline_mark(unsigned long long *slots, int slot, void *stream);
+
 /* hipRuntimeGetVersion / hipDriverGetVersion of the process: recorded next to the memset-node finding (the bug was
  * seen on HIP runtime 7.2, torch 2.10.0+rocm7.0; tests/test_gpu_runtime_probe.py reports whether it is still there). */
 int butd_runtime_versions(int *runtime, int *driver);

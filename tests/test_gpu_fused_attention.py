@@ -338,7 +338,7 @@ def test_chain_of_blocks_with_the_position_sum_from_the_layernorm_kernel(mods):
             if chained:
                 r = ab.block(attn, drop, norm, x=q, pos=pos, memory=memory, xq_pre=qp,
                              next_pos=None if last else pos)
-                q, qp = r if isinstance(r, tuple) else (r, None)
+                q, qp = (r[0], r[1]) if isinstance(r, tuple) else (r, None)
             else:
                 q = ab.block(attn, drop, norm, x=q, pos=pos, memory=memory)
         (q * probe).sum().backward()
@@ -386,3 +386,47 @@ def test_linear_relu_chain_matches_the_stock_modules(mods, lead):
     # anything else than Linear / ReLU alternation goes to the modules themselves
     odd = torch.nn.Sequential(torch.nn.Linear(288, 288), torch.nn.Tanh(), torch.nn.Linear(288, 64)).cuda()
     assert torch.equal(fa.linear_relu_chain(odd, x), odd(x))
+
+
+@pytest.mark.parametrize("B,Lq,Lk,masked,p", [(8, 256, 80, True, 0.1), (8, 256, 132, True, 0.1), (8, 1024, 80, True, 0.1),
+                                              (4, 1024, 132, False, 0.0), (8, 80, 80, True, 0.1), (2, 17, 5, True, 0.0),
+                                              (3, 100, 144, False, 0.1), (2, 200, 33, True, 0.1)])
+def test_short_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p):
+    """butd_attention_bwd_short_keys (one kernel, every score tile computed once, dK / dV accumulated with atomics)
+    against butd_attention_bwd (dQ kernel + dK/dV kernel) on the same saved forward: same dropout masks (same hash),
+    equal to fp32 summation order (1e-5 of the scale); packed / strided gradient rows as the structured block
+    passes them."""
+    _, fa, _, _ = mods
+    from butd_detr_amd import _hiplib
+    lib = _hiplib.load()
+    torch.manual_seed(Lq * 3 + Lk)
+    H, D = 8, 36
+    E = H * D
+    dev = "cuda"
+    q, do = torch.randn(B, Lq, E, device=dev) / 6, torch.randn(B, Lq, E, device=dev)
+    k, v = torch.randn(B, Lk, E, device=dev), torch.randn(B, Lk, E, device=dev)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.uint8, device=dev)
+        for b in range(B):
+            mask[b, Lk - 1 - (b % min(Lk - 1, 7)):] = 1
+    out, lse = torch.empty_like(q), torch.empty(B, H, Lq, device=dev)
+    ctr = fa.rng_counter(torch.device("cuda", 0))
+    ctr.fill_(77)
+    st = torch.cuda.current_stream().cuda_stream
+    mp = mask.data_ptr() if mask is not None else None
+    assert lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
+                                  lse.data_ptr(), p, 5, ctr.data_ptr(), st) == 0
+    res = {}
+    for name, fn in (("two", lib.butd_attention_bwd), ("one", lib.butd_attention_bwd_short_keys)):
+        dq = torch.full((B, Lq, E), float("nan"), device=dev)
+        G = torch.zeros(B, Lk, 2 * E + 4, device=dev)        # dk | dv side by side, rows wider than 2E
+        delta = torch.empty(B, H, Lq, device=dev)
+        assert fn(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(), do.data_ptr(),
+                  lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), G.data_ptr(), G.data_ptr() + 4 * E, E, 2 * E + 4, 0.5,
+                  p, 5, ctr.data_ptr(), st) == 0
+        torch.cuda.synchronize()
+        res[name] = (dq, G[:, :, :E].clone(), G[:, :, E:2 * E].clone(), delta, G[:, :, 2 * E:].clone())
+    for a, bq, name in zip(res["one"], res["two"], ("dq", "dk", "dv", "delta", "padding")):
+        assert torch.isfinite(a).all(), name
+        _close(a, bq, 1e-5 if name != "padding" else 1e-12)
