@@ -144,6 +144,8 @@ CRITERION_SYMBOLS = {
     "butd_soft_token_ce": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _c_float, _P, _P, _P]),
     "butd_contrastive_rows": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P, _P]),
     "butd_seed_objectness": (_c_int, [_c_int] * 5 + [_P] * 10 + [_P]),
+    "butd_loss_combine": (_c_int, [_c_int] + [_P] * 6 + [_c_int] + [_c_float] * 3 + [_P, _P]),
+    "butd_loss_combine_bwd": (_c_int, [_c_int, _P] + [_c_float] * 3 + [_P] * 5 + [_P]),
     "butd_contrastive_cols": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P]),
 }
 
@@ -160,6 +162,12 @@ AUGMENT_SYMBOLS = {
     "butd_augment_boxes": (_c_int, [_c_int, _c_int, _P, _P, _P, _P]),
     "butd_instance_boxes": (_c_int, [_c_int] * 4 + [_P] * 6 + [_P]),
     "butd_object_boxes": (_c_int, [_c_int] * 4 + [_P, _P, ctypes.c_longlong] + [_P] * 8 + [_P]),
+}
+
+ROWWISE_SYMBOLS = {
+    "butd_l2_normalize_fwd": (_c_int, [_c_long, _c_int, _P, _c_float, _P, _P]),
+    "butd_l2_normalize_bwd": (_c_int, [_c_long, _c_int, _P, _P, _c_float, _P, _P]),
+    "butd_three_nn_weights": (_c_int, [_c_long, _P, _P, _P, _P]),
 }
 
 GRAPH_SYMBOLS = {
@@ -179,6 +187,7 @@ ALL_SYMBOLS.update(CRITERION_SYMBOLS)
 ALL_SYMBOLS.update(AUGMENT_SYMBOLS)
 ALL_SYMBOLS.update(GRAPH_SYMBOLS)
 ALL_SYMBOLS.update(PANEL_SYMBOLS)
+ALL_SYMBOLS.update(ROWWISE_SYMBOLS)
 
 _lib = None
 

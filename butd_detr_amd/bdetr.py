@@ -235,7 +235,8 @@ class BeaUTyDETR(nn.Module):
         return end_points
 
     def _normalized_proj(self, x):
-        return F.normalize(self._proj_mlp(self.contrastive_align_projection_image, x), p=2, dim=-1)
+        from .rowwise import l2_normalize       # (F.normalize; one launch each way on the fused backend)
+        return l2_normalize(self._proj_mlp(self.contrastive_align_projection_image, x))
 
     @staticmethod
     def _proj_mlp(seq, x):
@@ -287,13 +288,18 @@ class BeaUTyDETR(nn.Module):
         end_points["text_memory"] = text_feats
         end_points["seed_features"] = points_features
         if self.contrastive_align_loss:
-            end_points["proj_tokens"] = F.normalize(
-                self._proj_mlp(self.contrastive_align_projection_text, text_feats), p=2, dim=-1)
+            from .rowwise import l2_normalize
+            end_points["proj_tokens"] = l2_normalize(self._proj_mlp(self.contrastive_align_projection_text, text_feats))
 
         end_points = self._generate_queries(points_xyz, points_features, end_points, features_pm=vis)
         cluster_feature = end_points["query_points_feature"]     # (B, d, Q)
         cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
-        query = self.decoder_query_proj(cluster_feature).transpose(1, 2).contiguous()
+        if (self._fused(cluster_feature) and self.decoder_query_proj.in_channels % 4 == 0
+                and self.decoder_query_proj.out_channels % 4 == 0):
+            from .fused_attention import conv1x1      # (the 1x1 convolution on position-major rows: bdetr.py:296)
+            query = conv1x1(self.decoder_query_proj, cluster_feature.transpose(1, 2))
+        else:
+            query = self.decoder_query_proj(cluster_feature).transpose(1, 2).contiguous()
         # contrastive projections of the proposal / per-layer queries (bdetr.py:263-268,300-305): the same
         # MLP on seven tensors that nothing downstream of the model reads before the loss -- collected
         # here and projected as ONE stacked batch after the decoder (row-wise op: identical values)

@@ -28,6 +28,7 @@ TU_FLAGS = {
     "ball_query_grid.hip": ["-ffp-contract=off"],
     "criterion_ops.hip": ["-ffp-contract=off"],
     "augment_ops.hip": ["-ffp-contract=off"],
+    "rowwise_ops.hip": ["-ffp-contract=off"],
     "attention_ops.hip": [],
 }
 

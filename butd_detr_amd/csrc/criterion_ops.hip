@@ -458,6 +458,39 @@ __global__ __launch_bounds__(256) void objectness_focal_kernel(int total, int K,
   dlogits[i] = w * alpha_w * (2.0f * pt * dpt * bce + pt * pt * (p - t));
 }
 
+// loss = w_gen * generation + w_sum * (sum ce + w_bbox * sum bbox + sum giou + sum align), NaN if any status word != 0;
+// out = [loss, sum ce, sum bbox, sum giou, sum align]  (losses.py:592-617: the sums over the prefixes + the weighting)
+__global__ void loss_combine_kernel(int P, const float *ce, const float *bbox, const float *giou, const float *align,
+                                    const float *generation, const int *status_words, int nstatus, float w_gen,
+                                    float w_sum, float w_bbox, float *out) {
+  if (threadIdx.x != 0) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  const float *src[4] = {ce, bbox, giou, align};
+  for (int t = 0; t < 4; ++t)
+    if (src[t])
+      for (int i = 0; i < P; ++i) s[t] += src[t][i];
+  const float gen = generation ? generation[0] : 0.f;
+  float loss = w_gen * gen + w_sum * (((s[0] + w_bbox * s[1]) + s[2]) + s[3]);
+  bool bad = false;
+  for (int i = 0; i < nstatus; ++i) bad = bad || status_words[i] != 0;
+  out[0] = bad ? nanf("") : loss;
+  out[1] = s[0]; out[2] = s[1]; out[3] = s[2]; out[4] = s[3];
+}
+
+// gradients of the above for an upstream scalar g: every element of a term gets g * its weight
+__global__ void loss_combine_bwd_kernel(int P, const float *g, float w_gen, float w_sum, float w_bbox, float *d_ce,
+                                        float *d_bbox, float *d_giou, float *d_align, float *d_generation) {
+  const int i = threadIdx.x;
+  const float gv = g[0];
+  if (i < P) {
+    if (d_ce) d_ce[i] = gv * w_sum;
+    if (d_bbox) d_bbox[i] = gv * w_sum * w_bbox;
+    if (d_giou) d_giou[i] = gv * w_sum;
+    if (d_align) d_align[i] = gv * w_sum;
+  }
+  if (i == 0 && d_generation) d_generation[0] = gv * w_gen;
+}
+
 inline int status() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -544,6 +577,23 @@ int butd_seed_objectness(int B, int K, int G, int N, int topk, const float *seed
   const int total = B * K;
   hipLaunchKernelGGL(objectness_focal_kernel, dim3((total + 255) / 256), dim3(256), 0, s, total, K, N, seed_inds,
                      point_instance_label, logits, label, elem_loss, dlogits);
+  return status();
+}
+
+int butd_loss_combine(int P, const float *loss_ce, const float *loss_bbox, const float *loss_giou,
+                      const float *loss_align, const float *generation, const int *status_words, int nstatus,
+                      float w_gen, float w_sum, float w_bbox, float *out5, butd_stream_t stream) {
+  if (P <= 0 || P > 64 || !loss_bbox || !out5) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, P, loss_ce, loss_bbox, loss_giou,
+                     loss_align, generation, status_words, status_words ? nstatus : 0, w_gen, w_sum, w_bbox, out5);
+  return status();
+}
+
+int butd_loss_combine_bwd(int P, const float *g, float w_gen, float w_sum, float w_bbox, float *d_ce, float *d_bbox,
+                          float *d_giou, float *d_align, float *d_generation, butd_stream_t stream) {
+  if (P <= 0 || P > 64 || !g) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, P, g, w_gen, w_sum, w_bbox,
+                     d_ce, d_bbox, d_giou, d_align, d_generation);
   return status();
 }
 

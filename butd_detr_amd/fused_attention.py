@@ -142,6 +142,7 @@ def _attn_bwd():
 
 
 _short_keys = [os.environ.get("BUTD_ATTN_SHORT_KEYS", "1") != "0"]
+_short_keys_all = [os.environ.get("BUTD_ATTN_SHORT_KEYS", "1") == "all"]
 _SHORT_KEYS_MAX = int(_lib.butd_attention_bwd_short_keys_max())
 
 
@@ -151,10 +152,15 @@ def set_short_keys(flag):
     return prev
 
 
-def _short_key_bwd(Lk):
+def _short_key_bwd(Lq, Lk):
     """The single-pass backward (``butd_attention_bwd_short_keys``: dk / dv accumulated, caller zero-fills) serves this
-    call: short key set, fp32 matrix steps."""
-    return _short_keys[0] and not _compute_bf16[0] and Lk <= _SHORT_KEYS_MAX
+    call.  Measured (profiles/r04_attention_short_keys.txt, 8 x 8 heads): it wins where a workgroup walks several
+    query tiles over one staged key set -- 1024 x 80: 88 us vs 115 us for the two kernels -- and loses where its dK / dV
+    atomics are not amortised: 256 x 80: 58 vs 40 us, 256 x 132: 91 vs 47, 1024 x 132: 135 vs 123 (float atomics cost
+    ~25 ns per thousand on this part).  BUTD_ATTN_SHORT_KEYS=all forces it wherever it applies (tests)."""
+    if not _short_keys[0] or _compute_bf16[0] or Lk > _SHORT_KEYS_MAX:
+        return False
+    return _short_keys_all[0] or (Lq >= 512 and Lk <= 80)
 
 
 def get_compute_dtype():
@@ -326,7 +332,7 @@ class _AttentionBlock(torch.autograd.Function):
         d_att = torch.empty((B, Lq, E), device=dev)
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
                _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], xq)
-        short = _short_key_bwd(Lk)
+        short = _short_key_bwd(Lq, Lk)
         dq = torch.empty((B, Lq, E), device=dev)
         dk = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
         dv = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
@@ -527,6 +533,16 @@ def linear(lin, x):
     x = x.contiguous()
     _check(x)
     return _LinearF32.apply(x, lin.weight, lin.bias)
+
+
+def conv1x1(conv, x_pm):
+    """``nn.Conv1d(kernel_size=1)`` applied to position-major rows ``x_pm`` (..., C_in) -> (..., C_out): the same
+    product as ``conv(x.transpose(1, 2)).transpose(1, 2)`` on the grouped GEMM (weight and bias gradient from one
+    split-K product), fp32 operands."""
+    w = conv.weight.view(conv.out_channels, conv.in_channels)
+    x_pm = x_pm.contiguous()
+    _check(x_pm)
+    return _LinearF32.apply(x_pm, w, conv.bias)
 
 
 def _as_mask(mask):
@@ -747,7 +763,7 @@ class _XpmBlock(torch.autograd.Function):
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
                _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], x)
         # gradients of the attention core, packed: self: G = [dq | dk | dv]; cross: dq, G = [dk | dv]
-        short = _short_key_bwd(Lk)      # (one kernel that ACCUMULATES dk / dv: zero-filled from the step's arena)
+        short = _short_key_bwd(Lq, Lk)      # (one kernel that ACCUMULATES dk / dv: zero-filled from the step's arena)
         new_g = (lambda shape: zeros(shape, device=dev)) if short else (lambda shape: torch.empty(shape, device=dev))
         if self_attn:
             G = new_g((B, Lq, 3 * E))

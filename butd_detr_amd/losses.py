@@ -532,6 +532,41 @@ class SetCriterion(nn.Module):
         return {k: v[0] for k, v in losses.items()}, _match_to_indices(match[0], valid)
 
 
+class _CombineLosses(torch.autograd.Function):
+    """losses.py:592-617: sums over the prefixes + the weighting (+ the NaN of a failed assignment) as one launch
+    forward, one backward (``butd_loss_combine``); the stock expression is ~20 scalar launches each way."""
+
+    @staticmethod
+    def forward(ctx, ce, bbox, giou, align, generation, status, w_gen, w_sum, w_bbox):
+        lib = _hiplib.load()
+        P = bbox.numel()
+        out = torch.empty(5, device=bbox.device)
+        terms = [None if t is None else _f32c(t) for t in (ce, bbox, giou, align, generation)]
+        st = None if status is None else status.detach().contiguous().view(-1).to(torch.int32)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(bbox.device):
+            _hiplib.check(lib.butd_loss_combine(P, ptr(terms[0]), ptr(terms[1]), ptr(terms[2]), ptr(terms[3]),
+                                                ptr(terms[4]), ptr(st), 0 if st is None else st.numel(), w_gen, w_sum,
+                                                w_bbox, out.data_ptr(), _stream(bbox)), "butd_loss_combine")
+        ctx.cfg = (P, w_gen, w_sum, w_bbox, [None if t is None else t.shape for t in (ce, bbox, giou, align, generation)])
+        parts = out.unbind(0)
+        ctx.mark_non_differentiable(*parts[1:])
+        return parts
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        P, w_gen, w_sum, w_bbox, shapes = ctx.cfg
+        lib = _hiplib.load()
+        g = g.contiguous()
+        grads = [None if sh is None else torch.empty(sh, device=g.device) for sh in shapes]
+        ptr = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(g.device):
+            _hiplib.check(lib.butd_loss_combine_bwd(P, g.data_ptr(), w_gen, w_sum, w_bbox, ptr(grads[0]), ptr(grads[1]),
+                                                    ptr(grads[2]), ptr(grads[3]), ptr(grads[4]), _stream(g)),
+                          "butd_loss_combine_bwd")
+        return (*grads, None, None, None, None)
+
+
 def hungarian_prefixes(num_decoder_layers):
     return ["proposal_", "last_"] + [f"{i}head_" for i in range(num_decoder_layers - 1)]
 
@@ -555,6 +590,19 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     for key, per_prefix in losses.items():
         for i, p in enumerate(prefixes):
             end_points[f"{p}_{key}"] = per_prefix[i]
+    status = getattr(set_criterion.matcher, "last_status", None)
+    if _fused(out["pred_boxes"]) and len(prefixes) <= 64:
+        generation = (compute_points_obj_cls_loss_hard_topk(end_points, query_points_obj_topk)
+                      if "seeds_obj_cls_logits" in end_points else None)
+        loss, loss_ce, loss_bbox, loss_giou, loss_align = _CombineLosses.apply(
+            losses.get("loss_ce"), losses["loss_bbox"], losses.get("loss_giou"),
+            losses["loss_contrastive_align"] if "proj_tokens" in end_points else None,
+            generation, status, 8.0, 1.0 / (num_decoder_layers + 1), 5.0)
+        end_points.update({"loss_ce": loss_ce, "loss_bbox": loss_bbox, "loss_giou": loss_giou,
+                           "query_points_generation_loss": generation if generation is not None else loss_ce * 0,
+                           "loss_constrastive_align": loss_align, "loss": loss, "hungarian_match": match,
+                           "hungarian_status": status})
+        return loss, end_points
     zero = out["pred_boxes"].new_zeros(())
     loss_ce = losses["loss_ce"].sum() if "loss_ce" in losses else zero
     loss_bbox = losses["loss_bbox"].sum()
@@ -565,7 +613,6 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
     else:
         generation = zero
     loss = 8 * generation + 1.0 / (num_decoder_layers + 1) * (loss_ce + 5 * loss_bbox + loss_giou + loss_align)
-    status = getattr(set_criterion.matcher, "last_status", None)
     if status is not None:
         # where scipy's linear_sum_assignment would have raised (NaN / -inf costs: matcher.py:105) the device solver
         # sets a status word instead; inside a graph replay nothing can raise, so the failure is made visible the

@@ -98,7 +98,14 @@ class PointnetFPModule(nn.Module):
         self.mlp = SharedMLP(list(mlp), bn=bn)
 
     def forward(self, unknown, known, unknow_feats, known_feats):
-        if known is not None:
+        from . import attention_blocks
+        if known is not None and attention_blocks.get_backend() == "hip" and unknown.is_cuda:
+            # the same weights (same operations, same order) from ONE kernel instead of sqrt / add / reciprocal / sum / div
+            from . import pointnet2_ext, rowwise
+            dist2, idx = pointnet2_ext.three_nn(unknown.contiguous(), known.contiguous())
+            weight = rowwise.three_nn_weights(dist2)
+            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), idx, weight)
+        elif known is not None:
             dist, idx = pointnet2_utils.three_nn(unknown, known)
             dist_recip = 1.0 / (dist + 1e-8)
             weight = dist_recip / torch.sum(dist_recip, dim=2, keepdim=True)
@@ -107,7 +114,6 @@ class PointnetFPModule(nn.Module):
             interpolated = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
         if unknow_feats is not None:
             interpolated = torch.cat([interpolated, unknow_feats], dim=1)
-        from . import attention_blocks
         if attention_blocks.get_backend() == "hip" and interpolated.is_cuda and self._chain_ok():
             # SharedMLP = [1x1 conv -> BatchNorm2d -> ReLU] x n on position-major rows: grouped MFMA GEMMs
             # with the BatchNorm folded into the next operand load (fused_mlp); returned as the (B,C,n)

@@ -82,6 +82,20 @@ int butd_seed_objectness(int B, int K, int G, int N, int topk, const float *seed
                          const float *box_mask, const float *logits, unsigned char *label, float *elem_loss,
                          float *dlogits, butd_stream_t stream);
 
+/* The weighting of compute_hungarian_loss (losses.py:592-617) in one launch: the (P,) per-prefix vectors of the four
+ * terms (any of loss_ce / loss_giou / loss_align may be NULL) are summed and combined,
+ *   out5 = [ w_gen * generation + w_sum * (sum ce + w_bbox * sum bbox + sum giou + sum align), sum ce, sum bbox,
+ *            sum giou, sum align ];
+ * the loss is NaN when any of the nstatus assignment status words (include/butd_lsap.h) is nonzero (scipy would have
+ * raised there; inside a graph replay nothing can).  generation: device scalar or NULL.  P <= 64. */
+int butd_loss_combine(int P, const float *loss_ce, const float *loss_bbox, const float *loss_giou,
+                      const float *loss_align, const float *generation, const int *status_words, int nstatus,
+                      float w_gen, float w_sum, float w_bbox, float *out5, butd_stream_t stream);
+
+/* Its gradient for an upstream device scalar g: d term[i] = g * weight (NULL outputs are skipped). */
+int butd_loss_combine_bwd(int P, const float *g, float w_gen, float w_sum, float w_bbox, float *d_ce, float *d_bbox,
+                          float *d_giou, float *d_align, float *d_generation, butd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

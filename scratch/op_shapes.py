@@ -28,6 +28,12 @@ class Log(TorchDispatchMode):
         if ALL and not name.startswith(SKIP) or name.split(".")[0] in KEEP:
             shp = next((tuple(a.shape) for a in args if isinstance(a, torch.Tensor)), ())
             site = "autograd"
+            try:
+                node = torch._C._current_autograd_node()
+                if node is not None:
+                    site = "autograd:" + node.name()
+            except Exception:
+                pass
             for fr in reversed(traceback.extract_stack(limit=40)):
                 if "/butd_detr_amd/" in fr.filename and "op_shapes" not in fr.filename:
                     site = f"{os.path.basename(fr.filename)}:{fr.lineno}"; break
@@ -48,6 +54,6 @@ bysite = collections.Counter()
 for (ph, name, shp, site), n in log.rows.items(): bysite[(ph, site)] += n
 if ALL:
     print("by site:")
-    for (ph, site), n in sorted(bysite.items(), key=lambda kv: -kv[1])[:45]: print(f"{n:4d} {ph} {site}")
-for (ph, name, shp, site), n in sorted(log.rows.items(), key=lambda kv: -kv[1])[:70]:
+    for (ph, site), n in sorted(bysite.items(), key=lambda kv: -kv[1])[:100]: print(f"{n:4d} {ph} {site}")
+for (ph, name, shp, site), n in sorted(log.rows.items(), key=lambda kv: -kv[1])[:400]:
     print(f"{n:4d} {ph} {name:22s} {str(shp):24s} {site}")

@@ -169,9 +169,9 @@ def test_chain_equals_unchained_path_under_dropout(mods, B, Q, Lk):
     finally:
         ab.set_backend("torch")
     # (sites are numbered by block() before either path launches anything: the masks are the same)
-    _close(outs[True][0], outs[False][0], 1e-4, "y", frac=1e-3)
+    _close(outs[True][0], outs[False][0], 1e-4, "y", frac=1e-2)
     for i, (gc, gu) in enumerate(zip(outs[True][1], outs[False][1])):
-        _close(gc, gu, 2e-4, f"grad {i}", frac=1e-3)
+        _close(gc, gu, 2e-4, f"grad {i}", frac=1e-2)
 
 
 def test_ffn_block_chain_vs_unchained_same_masks(mods):
