@@ -64,6 +64,16 @@ def _embedding_lookup(weight, ids):
     return torch.nn.functional.embedding(ids, weight)
 
 
+_HEAD_STREAMS = {}
+
+
+def _head_stream(device):
+    st = _HEAD_STREAMS.get(device)
+    if st is None:
+        st = _HEAD_STREAMS[device] = torch.cuda.Stream(device)
+    return st
+
+
 class BeaUTyDETR(nn.Module):
     """See module docstring.  ``num_encoder_layers`` (default 3) exposes the depth the reference
     hard-codes at bdetr.py:104."""
@@ -305,8 +315,7 @@ class BeaUTyDETR(nn.Module):
         # here and projected as ONE stacked batch after the decoder (row-wise op: identical values)
         proj_inputs = [("proposal_", query)] if self.contrastive_align_loss else []
 
-        center, size = self.proposal_head(cluster_feature, base_xyz=cluster_xyz,
-                                          end_points=end_points, prefix="proposal_")
+        center, size = self._run_head(self.proposal_head, cluster_feature, cluster_xyz, end_points, "proposal_")
         base_xyz, base_size = center.detach(), size.detach()   # (the reference clones: bdetr.py:275-276; the cat /
             # position embedding below copy them anyway and nothing writes the head outputs in place)
 
@@ -331,8 +340,7 @@ class BeaUTyDETR(nn.Module):
             query, q_head, q_proj = fan_out(query, 3)
             if self.contrastive_align_loss:
                 proj_inputs.append((prefix, q_proj))
-            center, size = head(q_head.transpose(1, 2), base_xyz=cluster_xyz,
-                                end_points=end_points, prefix=prefix, features_pm=q_head)
+            center, size = self._run_head(head, q_head.transpose(1, 2), cluster_xyz, end_points, prefix, features_pm=q_head)
             base_xyz, base_size = center.detach(), size.detach()   # (the reference clones: bdetr.py:275-276; the cat /
             # position embedding below copy them anyway and nothing writes the head outputs in place)
         if proj_inputs:
@@ -340,6 +348,38 @@ class BeaUTyDETR(nn.Module):
             for i, (prefix, _) in enumerate(proj_inputs):
                 end_points[f"{prefix}proj_queries"] = proj[i]
         return end_points
+
+    def _run_head(self, head, features, cluster_xyz, end_points, prefix, features_pm=None):
+        """One prediction head (bdetr.py:306-312).  On the fused backend it runs on a FORKED stream: in the forward pass
+        the next decoder layer needs its boxes, so nothing overlaps there (fork + join back to back) -- but autograd
+        runs a node's backward on the stream of its forward, and the backward of every head depends on the loss
+        alone (the boxes handed to the next layer are detached, bdetr.py:275-276): the seven heads' backward chains
+        (~10 launches of 2048-row kernels each, ~0.15 ms) then run on that stream NEXT TO the decoder layers' backward
+        instead of between them.  MEASURED (round 4, bench configuration): 25.79 ms per step with the fork, 25.61 without --
+        the chip shares two queues of small launches no better than one, as round 3 found for the weight-gradient
+        products -- so it is OFF unless BUTD_HEAD_FORK=1 (kept as the A/B switch of that measurement)."""
+        fork = (features.is_cuda and attention_blocks.get_backend() == "hip" and torch.is_grad_enabled()
+                and os.environ.get("BUTD_HEAD_FORK", "0") == "1")
+        if not fork:
+            return head(features, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix, features_pm=features_pm)
+        main = torch.cuda.current_stream(features.device)
+        side = _head_stream(features.device)
+        before = set(end_points.keys())
+        side.wait_stream(main)
+        features.record_stream(side)
+        cluster_xyz.record_stream(side)
+        if features_pm is not None:
+            features_pm.record_stream(side)
+        with torch.cuda.stream(side):
+            center, size = head(features, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix,
+                                features_pm=features_pm)
+        main.wait_stream(side)
+        for k in set(end_points.keys()) - before:       # produced on the side stream, read by the criterion on main
+            if torch.is_tensor(end_points[k]):
+                end_points[k].record_stream(main)
+        center.record_stream(main)
+        size.record_stream(main)
+        return center, size
 
     # parameters whose gradients are complete only once backward has passed the encoder: everything else
     # (decoder, heads, query generation, contrastive projections) is done when backward reaches the three

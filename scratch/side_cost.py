@@ -1,0 +1,42 @@
+"""round 4: what do the two prefetch branches (next batch's FPS chain on 8 CUs, next batch's RoBERTa pass) cost the main
+stream?  The captured step with the branch bodies replaced by nothing while capturing (their RESULTS stay those of the
+warm-up: timing experiment only, the numbers trained on are stale)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import argparse, torch, bench
+from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, HungarianCriterion, synthetic_batch
+dev = torch.device("cuda", 0)
+args = argparse.Namespace(backend="auto", queries=256, points=50000, tokens=80, encoder_layers=3)
+batches = [synthetic_batch(8, dev, seed=1184 + 50 * i, n_points=50000, tokens=80) for i in range(4)]
+
+
+def run(skip_fps, skip_text, reps=30, prio=None):
+    if prio is not None:
+        st = torch.cuda.Stream(dev, priority=prio)
+        with torch.cuda.stream(st):
+            return run(skip_fps, skip_text, reps)
+    model, _ = bench.build_model(args, dev)
+    step = GraphedTrainStep(model, FlatAdamW(model), criterion=HungarianCriterion())
+    o_s, o_t = step._sample_into_next, step._encode_text_into_next
+    step._sample_into_next = lambda: None if (skip_fps and torch.cuda.is_current_stream_capturing()) else o_s()
+    step._encode_text_into_next = lambda: None if (skip_text and torch.cuda.is_current_stream_capturing()) else o_t()
+    for it in range(5):
+        step(batches[it % 4][0], batches[it % 4][1], next_inputs=batches[(it + 1) % 4][0])
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for it in range(reps):
+        step(batches[it % 4][0], batches[it % 4][1], next_inputs=batches[(it + 1) % 4][0])
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "base"
+if mode == "base":
+    print(f"both on, default stream: {run(False, False):.3f} ms / step")
+elif mode == "hi":
+    print(f"both on, issued on a priority -1 stream: {run(False, False, prio=-1):.3f} ms / step")
+elif mode == "lo":
+    print(f"both on, issued on a NEW priority 0 stream: {run(False, False, prio=0):.3f} ms / step")
+elif mode == "none":
+    print(f"both off: {run(True, True):.3f} ms / step")

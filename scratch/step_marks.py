@@ -83,6 +83,27 @@ hook(m.proposal_head, "proposal_head")
 hook(m.points_obj_cls, "objcls")
 hook(m.pos_embed, "pos_embed")
 hook(m.text_projector, "text_proj")
+hook(m.gsample_module, "gsample")
+hook(m.decoder_query_proj, "query_proj")
+hook(m.contrastive_align_projection_image, "proj_img")
+hook(m.contrastive_align_projection_text, "proj_txt")
+if os.environ.get("FINE", "0") == "1":      # every attention / FFN block of the encoder and decoder
+    from butd_detr_amd import fused_attention as _fa, attention_blocks as _ab
+    counter = [0]
+    _orig_block, _orig_ffn = _fa.block, _fa.ffn_block
+
+    def _wrap(fn, tag):
+        def g(*a, **k):
+            out = fn(*a, **k)
+            if torch.cuda.current_stream(dev) != main_stream[0]:
+                return out
+            counter[0] += 1
+            name = f"{tag}{counter[0]}"
+            mark("fwd>" + name)
+            return first_tensor_map(out, lambda t: _BwdMark.apply(t, name))
+        return g
+    _fa.block = _wrap(_orig_block, "blk")
+    _fa.ffn_block = _wrap(_orig_ffn, "ffn")
 
 crit = HungarianCriterion()
 orig_crit = crit.__call__ if hasattr(crit, "__call__") else None
@@ -94,6 +115,8 @@ orig_fb = step._fwd_bwd
 def fwd_bwd():
     main_stream[0] = torch.cuda.current_stream(dev)
     names.clear()
+    if os.environ.get("FINE", "0") == "1":
+        counter[0] = 0
     mark("step start")
     loss = orig_fb()
     mark("step end (gradients packed)")
