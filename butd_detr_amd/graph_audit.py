@@ -20,12 +20,11 @@ NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "
               12: "memcpy_from_symbol", 13: "memcpy_to_symbol"}
 
 
-# where the memset-node bug was observed (round 3, profiles/r03_hipgraph_memset_nodes.txt: 200 of 200 replays wrong): the
-# ROCm 7.2.0 image with torch 2.10.0+rocm7.0 on MI355X (gfx950); the process runs torch's BUNDLED HIP runtime
-# (hipRuntimeGetVersion 70051831 = 7.0.51831), not /opt/rocm's.  tests/test_gpu_runtime_probe.py replays the reproducer and
-# reports whether the running stack still has it; round 4's runs of that probe on the same versions report 0 of 100 wrong
-# replays (gpurun_out/runtime_probe.json) -- the boxes differ in something the versions do not show (firmware / kernel
-# driver), so the rewrite stays: it is exact and costs nothing when the bug is absent.
+# where the memset-node bug was observed (round 3, profiles/r03_hipgraph_memset_nodes.txt: 200 of 200 replays wrong; round 4,
+# profiles/r04_runtime_probe.json: 100 of 100): the ROCm 7.2.0 image with torch 2.10.0+rocm7.0 on MI355X (gfx950); the
+# process runs torch's BUNDLED HIP runtime (hipRuntimeGetVersion 70051831 = 7.0.51831), not /opt/rocm's.
+# tests/test_gpu_runtime_probe.py replays the reproducer, reports whether the running stack still has the bug and asserts
+# that the rewritten graph is right either way (once a runtime fixes it the rewrite is merely redundant).
 BUG_SEEN_ON = {"image": "ROCm 7.2.0", "hip_runtime_in_process": 70051831, "torch": "2.10.0+rocm7.0", "arch": "gfx950"}
 
 
