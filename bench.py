@@ -61,9 +61,11 @@ def parse():
     ap.add_argument("--roofline-child", action="store_true",
                     help="internal: run only the captured training step (warm-up + steps) and print the grouped GEMM's "
                          "algorithmic work per step; the parent runs this under rocprofv3 --kernel-trace --stats")
-    ap.add_argument("--no-overlap-exchange", dest="overlap_exchange", action="store_false",
-                    help="N > 1: one graph + ONE all-reduce of the whole packed buffer instead of the default two-piece "
-                         "capture whose decoder-side gradient bucket is all-reduced under the encoder / backbone backward")
+    ap.add_argument("--overlap-exchange", dest="overlap_exchange", action="store_true", default=None,
+                    help="N > 1: the two-piece capture whose decoder-side gradient bucket is all-reduced under the encoder / "
+                         "backbone backward, instead of the default one graph + ONE all-reduce of the whole packed buffer "
+                         "(opt-in until a run on >= 2 GPUs has compared the loss trajectories; BUTD_OVERLAP_EXCHANGE=1 "
+                         "does the same)")
     ap.add_argument("--distinct-batches", type=int, default=4,
                     help="the timed steps rotate over this many different synthetic batches (scene geometry decides "
                          "how much the pruned FPS and the ball query do; one batch replayed is its best case)")
