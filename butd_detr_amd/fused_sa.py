@@ -75,7 +75,8 @@ class _SAMlpPool(torch.autograd.Function):
             last = li == 2
             # BatchNorm sums straight from the GEMM epilogue while the row count is moderate (every tile
             # ends in 2 double atomics per column); the last layer's pass also takes the pooling extrema
-            in_gemm_stats = training and not last and P <= 131072
+            # (limit measured in the step, round 4: up to 131 072 rows 25.62 ms, 262 144 rows 25.40, 1 048 576 rows 25.51)
+            in_gemm_stats = training and not last and P <= int(os.environ.get("BUTD_SA_INGEMM_MAX", "262144"))
             thin = li == 0 and Kp == 8      # SA1: xyz + colour -> one HBM pass does the product AND the sums
             if thin:
                 _call("butd_sa_thin_conv", xyz, P, Cl, Kp, X.data_ptr(), Kp, w.data_ptr(), Z.data_ptr(),
