@@ -278,8 +278,8 @@ def attention_roofline(batch, reps=10, bf16=False):
 
 
 def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC profile (profiles/r03_pmc.json, else r02), or None."""
-    for name in ("r03_pmc.json", "r02_pmc.json"):
+    """HBM bytes per launch from the committed PMC profile (profiles/r04_pmc.json, else r03 / r02), or None."""
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name))).get(kernel, {}).get("hbm_bytes_per_launch")
         except Exception:

@@ -51,18 +51,49 @@ class Pointnet2Backbone(nn.Module):
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
         return out
 
-    def forward(self, pointcloud, end_points=None, sample_inds=None):
+    @torch.no_grad()
+    def plan(self, pointcloud):
+        """Everything of the backbone that depends on the COORDINATES alone -- no parameter, no feature: per level the
+        furthest-point samples, the sampled centres and the ball-query neighbour lists (pointnet2_modules.py:225-241,
+        pointnet2_utils.py:346-349), and the three-nearest-neighbour indices + inverse-distance weights of the two
+        feature-propagation modules (pointnet2_modules.py:392-396).  A training loop runs it for batch k+1 on a side
+        stream while batch k trains and hands it to ``forward(..., plan=...)``:
+        {"levels": [(inds (B,np) i32, new_xyz (B,np,3), idx (B,np,ns) i32) x 4], "fp": [(idx (B,n,3) i32, weight (B,n,3)) x 2]}"""
+        from . import pointnet2_ext, rowwise
+        xyz = pointcloud[..., 0:3].contiguous()
+        xyzs, levels = [xyz], []
+        for level in (1, 2, 3, 4):
+            sa = getattr(self, f"sa{level}")
+            inds = pointnet2_utils.furthest_point_sample(xyz, sa.npoint)
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+            idx = pointnet2_utils.ball_query(sa.radius, sa.nsample, xyz, new_xyz)
+            levels.append((inds, new_xyz, idx))
+            xyz = new_xyz
+            xyzs.append(xyz)
+        fp = []
+        for unknown, known in ((xyzs[3], xyzs[4]), (xyzs[2], xyzs[3])):     # fp1: sa3 <- sa4, fp2: sa2 <- sa3 (:139-147)
+            dist2, nn_idx = pointnet2_ext.three_nn(unknown, known)
+            fp.append((nn_idx, rowwise.three_nn_weights(dist2)))
+        return {"levels": levels, "fp": fp}
+
+    def forward(self, pointcloud, end_points=None, sample_inds=None, plan=None):
         """pointcloud (B, N, 3 + input_feature_dim) -> end_points dict.  ``sample_inds``: optional
         precomputed result of ``sample(pointcloud)`` (the modules' own ``inds`` argument,
-        pointnet2_modules.py:210-241)."""
+        pointnet2_modules.py:210-241); ``plan``: optional result of ``plan(pointcloud)`` (samples, centres, neighbour
+        lists, interpolation weights: the levels then start at their grouping)."""
         end_points = end_points if end_points else {}
         xyz, features = self._break_up_pc(pointcloud)
         # point-major hand-over between levels (used by the fused gfx950 SA pipeline, ignored otherwise)
         feats_pm, off = (pointcloud.contiguous(), 3) if features is not None else (None, 0)
         for level in (1, 2, 3, 4):
             sa = getattr(self, f"sa{level}")
-            xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off,
-                                     inds=None if sample_inds is None else sample_inds[level - 1])
+            if plan is not None:
+                p_inds, p_xyz, p_idx = plan["levels"][level - 1]
+                xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off, inds=p_inds,
+                                         new_xyz=p_xyz, ball_idx=p_idx)
+            else:
+                xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off,
+                                         inds=None if sample_inds is None else sample_inds[level - 1])
             feats_pm, off = sa.last_features_pm, 0
             # (a module attribute that holds a tensor with a grad_fn keeps this iteration's autograd graph -- and the
             #  parameters' AccumulateGrad nodes with the stream they were created on -- alive into the next one)
@@ -71,10 +102,11 @@ class Pointnet2Backbone(nn.Module):
                 end_points[f"sa{level}_inds"] = inds
             end_points[f"sa{level}_xyz"] = xyz
             end_points[f"sa{level}_features"] = features
+        nn1, nn2 = plan["fp"] if plan is not None else (None, None)
         features = self.fp1(end_points["sa3_xyz"], end_points["sa4_xyz"],
-                            end_points["sa3_features"], end_points["sa4_features"])
+                            end_points["sa3_features"], end_points["sa4_features"], nn=nn1)
         features = self.fp2(end_points["sa2_xyz"], end_points["sa3_xyz"],
-                            end_points["sa2_features"], features)
+                            end_points["sa2_features"], features, nn=nn2)
         end_points["fp2_features"] = features
         end_points["fp2_xyz"] = end_points["sa2_xyz"]
         num_seed = end_points["fp2_xyz"].shape[1]

@@ -208,7 +208,8 @@ class BeaUTyDETR(nn.Module):
         text_out = {}
         hidden = inputs.get("text_encoder_output")
         if hidden is not None:          # language model already run (prefetched): projector only
-            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
+            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"),
+                                           plan=inputs.get("backbone_plan"))
             self._run_text_tower(tokenized, text_out, hidden)
         elif pc.is_cuda and self.overlap_text_tower and self.text_encoder_is_frozen():
             # only the FROZEN language model is forked (no autograd nodes on the side stream: every node's backward
@@ -221,12 +222,14 @@ class BeaUTyDETR(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 hidden = self.encode_text(tokenized, inputs.get("text"))
-            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
+            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"),
+                                           plan=inputs.get("backbone_plan"))
             main.wait_stream(side)
             hidden.record_stream(main)
             self._run_text_tower(tokenized, text_out, hidden)
         else:
-            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"))
+            end_points = self.backbone_net(pc, end_points={}, sample_inds=inputs.get("backbone_sample_inds"),
+                                           plan=inputs.get("backbone_plan"))
             self._run_text_tower(tokenized, text_out, texts=inputs.get("text"))
         end_points["seed_inds"] = end_points["fp2_inds"]
         end_points["seed_xyz"] = end_points["fp2_xyz"]

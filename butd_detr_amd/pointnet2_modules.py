@@ -51,22 +51,23 @@ class PointnetSAModuleVotes(nn.Module):
             return (feats * rbf.unsqueeze(1)).sum(-1) / float(self.nsample)
         raise ValueError(self.pooling)
 
-    def forward(self, xyz, features=None, inds=None, features_pm=None, feat_offset=0):
+    def forward(self, xyz, features=None, inds=None, features_pm=None, feat_offset=0, new_xyz=None, ball_idx=None):
         """``features_pm`` (optional, not in the reference signature): the same features point-major,
         (B, N, feat_offset + C); lets consecutive levels hand activations over without a transpose.
-        After the call ``self.last_features_pm`` holds this level's output point-major (or None)."""
+        After the call ``self.last_features_pm`` holds this level's output point-major (or None).
+        ``new_xyz`` / ``ball_idx`` (optional, with ``inds``): the sampled centres and the ball-query neighbour lists as
+        ``Pointnet2Backbone.plan`` precomputed them (coordinates only: prefetched for the next batch)."""
         self.last_features_pm = None
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
         else:
             assert inds.shape[1] == self.npoint
-        new_xyz = None
-        if self.npoint is not None:
+        if new_xyz is None and self.npoint is not None:
             new_xyz = pointnet2_utils.gather_operation(
                 xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
         from . import attention_blocks, fused_sa
         if attention_blocks.get_backend() == "hip" and fused_sa.supported(self, xyz, features_pm):
-            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            idx = ball_idx if ball_idx is not None else pointnet2_utils.ball_query(self.radius, self.nsample, xyz, new_xyz)
             if features_pm is None and features is not None:
                 features_pm, feat_offset = features.transpose(1, 2).contiguous(), 0
             new_features, self.last_features_pm = fused_sa.sa_mlp_pool(
@@ -97,9 +98,13 @@ class PointnetFPModule(nn.Module):
         super().__init__()
         self.mlp = SharedMLP(list(mlp), bn=bn)
 
-    def forward(self, unknown, known, unknow_feats, known_feats):
+    def forward(self, unknown, known, unknow_feats, known_feats, nn=None):
+        """``nn`` (optional): (idx (B,n,3) i32, weight (B,n,3)) of the three nearest neighbours as
+        ``Pointnet2Backbone.plan`` precomputed them."""
         from . import attention_blocks
-        if known is not None and attention_blocks.get_backend() == "hip" and unknown.is_cuda:
+        if known is not None and nn is not None:
+            interpolated = pointnet2_utils.three_interpolate(known_feats.contiguous(), nn[0], nn[1])
+        elif known is not None and attention_blocks.get_backend() == "hip" and unknown.is_cuda:
             # the same weights (same operations, same order) from ONE kernel instead of sqrt / add / reciprocal / sum / div
             from . import pointnet2_ext, rowwise
             dist2, idx = pointnet2_ext.three_nn(unknown.contiguous(), known.contiguous())

@@ -585,10 +585,25 @@ class GraphedTrainStep:
         self._slots, self._slot, self._sig = {}, None, None
 
     # -- pieces shared by the eager warm-up and the captured region
+    @staticmethod
+    def _plan_pieces(plan):
+        """The tensors of ``Pointnet2Backbone.plan`` in a fixed order: the four sample lists first (tightly packed:
+        ``inds_cur`` is their concatenation), then centres, neighbour lists, interpolation indices and weights."""
+        levels, fp = plan["levels"], plan["fp"]
+        return ([l[0] for l in levels] + [l[1] for l in levels] + [l[2] for l in levels]
+                + [f[0] for f in fp] + [f[1] for f in fp])
+
+    @staticmethod
+    def _plan_from_pieces(pieces):
+        return {"levels": [(pieces[i], pieces[4 + i], pieces[8 + i]) for i in range(4)],
+                "fp": [(pieces[12 + i], pieces[14 + i]) for i in range(2)]}
+
     def _sample_into_next(self):
+        """Everything of the backbone that depends on the next batch's coordinates alone (FPS chain, sampled centres,
+        ball queries, 3-NN weights: Pointnet2Backbone.plan) into the `next` half of the slot's plan buffer."""
         s = self._slot
-        inds = self._backbone().sample(s.next_pc)
-        torch.cat([i.reshape(-1) for i in inds], out=s.inds_next)
+        for src, dst in zip(self._plan_pieces(self._backbone().plan(s.next_pc)), s.plan_next_views):
+            dst.copy_(src)
 
     def _module(self):
         return self.model.module if hasattr(self.model, "module") else self.model
@@ -615,7 +630,7 @@ class GraphedTrainStep:
         s = self._slot
         if self.prefetch_sampling:
             main = torch.cuda.current_stream()
-            s.inds_cur.copy_(s.inds_next)                    # this batch's samples (prefetched)
+            s.plan_cur.copy_(s.plan_next)                    # this batch's samples / centres / neighbour lists (prefetched)
             s.sample_stream.wait_stream(main)                # fork: next batch's chain on 8 CUs
             with torch.cuda.stream(s.sample_stream):
                 self._sample_into_next()
@@ -761,17 +776,26 @@ class GraphedTrainStep:
         if self.prefetch_sampling:
             pc = inputs["point_clouds"]
             s.next_pc = pc[..., :3].clone()
-            levels = [getattr(self._backbone(), f"sa{l}").npoint for l in (1, 2, 3, 4)]
-            b = pc.shape[0]
-            s.inds_next = torch.empty(b * sum(levels), dtype=torch.int32, device=pc.device)
-            s.inds_cur = torch.empty_like(s.inds_next)
-            views, o = [], 0
-            for n in levels:
-                views.append(s.inds_cur[o:o + b * n].view(b, n))
-                o += b * n
-            s.inputs["backbone_sample_inds"] = views
+            # one flat buffer per half (`next`: written by the prefetch branch, `cur`: read by this step's backbone) for
+            # everything Pointnet2Backbone.plan produces; ONE copy node hands a batch's plan over at the start of its step
+            pieces = self._plan_pieces(self._backbone().plan(s.next_pc))    # (THIS batch: shapes + first contents)
+            offs, o = [], 0
+            for i, t in enumerate(pieces):
+                if i >= 4:
+                    o = (o + 255) // 256 * 256                # (the four sample lists stay contiguous: inds_cur below)
+                offs.append(o)
+                o += t.numel() * t.element_size()
+            s.plan_next = torch.empty(o, dtype=torch.uint8, device=pc.device)
+            s.plan_cur = torch.empty_like(s.plan_next)
+            view = lambda buf: [buf[off:off + t.numel() * t.element_size()].view(t.dtype).view(t.shape)
+                                for off, t in zip(offs, pieces)]
+            s.plan_next_views, cur_views = view(s.plan_next), view(s.plan_cur)
+            s.inputs["backbone_plan"] = self._plan_from_pieces(cur_views)
+            n_inds = sum(t.numel() for t in pieces[:4])
+            s.inds_cur = s.plan_cur[:4 * n_inds].view(torch.int32)    # the concatenated sample lists of the current batch
             s.sample_stream = torch.cuda.Stream()
-            self._sample_into_next()                          # prime with THIS batch
+            for src, dst in zip(pieces, s.plan_next_views):   # prime with THIS batch
+                dst.copy_(src)
             torch.cuda.synchronize()
         if self.prefetch_text:
             s.tok_next = BatchEncoding({k: v.clone() for k, v in tok.items()})

@@ -58,6 +58,32 @@ def test_prefetched_sampling_trains_like_inline_sampling():
         # and the sampled indices the prefetching step consumed for the last batch are that batch's
         want = torch.cat([i.reshape(-1) for i in pre_model.backbone_net.sample(batches[-1][0]["point_clouds"])])
         assert torch.equal(pre._slot.inds_cur, want)
+        # ... and so is the rest of the prefetched plan (centres, neighbour lists, interpolation indices / weights)
+        plan = pre_model.backbone_net.plan(batches[-1][0]["point_clouds"])
+        for got, exp in zip(GraphedTrainStep._plan_pieces(pre._slot.inputs["backbone_plan"]),
+                            GraphedTrainStep._plan_pieces(plan)):
+            assert torch.equal(got, exp)
+    finally:
+        attention_blocks.set_backend("torch")
+
+
+def test_backbone_with_a_precomputed_plan_equals_the_inline_backbone():
+    """Pointnet2Backbone.plan = the coordinate-only part of the backbone (FPS, centres, ball queries, 3-NN weights);
+    forward(plan=...) must produce what forward() produces: same indices, same centres, same features."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.backbone_module import Pointnet2Backbone
+    from butd_detr_amd.synthetic_scenes import uniform_cloud
+    try:
+        attention_blocks.set_backend("hip")
+        torch.manual_seed(3)
+        net = Pointnet2Backbone(input_feature_dim=3).cuda().train()
+        pc = torch.from_numpy(uniform_cloud(seed=9, n_points=8192, batch=2)).cuda()
+        a = net(pc, end_points={})
+        b = net(pc, end_points={}, plan=net.plan(pc))
+        for k in ("sa1_inds", "sa2_inds", "fp2_inds", "sa1_xyz", "sa2_xyz", "sa3_xyz", "sa4_xyz"):
+            assert torch.equal(a[k], b[k]), k
+        for k in ("sa1_features", "sa4_features", "fp2_features"):       # (BatchNorm sums by atomics: rounding)
+            assert float((a[k] - b[k]).abs().max()) <= 1e-5 * float(a[k].abs().max()), k
     finally:
         attention_blocks.set_backend("torch")
 
