@@ -504,7 +504,10 @@ class GraphedTrainStep:
     ``prefetch_sampling``: the furthest-point-sampling chain of the backbone (4 serial launches, ~4.7 ms
     on 8 CUs at 8 x 50k points) depends on the coordinates only, so the graph computes it for the NEXT
     batch on a forked stream while the current batch trains on the other 248 CUs, exactly as a data
-    loader prefetches: ``step(inputs_k, targets_k, next_inputs=inputs_k+1)``.  Every replay still runs
+    loader prefetches: ``step(inputs_k, targets_k, next_inputs=inputs_k+1)``.  Since round 4 the branch computes the
+    whole coordinate-only part of the backbone (``Pointnet2Backbone.plan``: samples, sampled centres, ball-query
+    neighbour lists of the four levels, 3-NN indices + weights of the two propagation modules: ~30 launches /
+    0.3 ms off the main queue); one copy node hands a batch's plan over at the start of its step.  Every replay still runs
     one sampling chain and one model pass; a call whose inputs were not announced by the previous call
     falls back to sampling them on the spot.  ``prefetch_text`` does the same with the FROZEN language
     model (its output depends on the tokens only): batch k+1's RoBERTa pass runs on a forked stream during
