@@ -53,7 +53,11 @@ class GemmProblem(ctypes.Structure):
                 ("b_drop_p", _c_float), ("b_drop_site", _c_u32),
                 ("col_sum", _c_void_p), ("col_sumsq", _c_void_p),
                 ("c_add", _c_int), ("c2", _c_void_p), ("col_slots", _c_int), ("col_slot_stride", _c_long),
-                ("compute_bf16", _c_int), ("c_gate", _c_void_p), ("c_gate_scale", _c_float)]
+                ("compute_bf16", _c_int), ("c_gate", _c_void_p), ("c_gate_scale", _c_float),
+                ("a_bn_sum", _c_void_p), ("a_bn_sumsq", _c_void_p), ("a_bn_gamma", _c_void_p), ("a_bn_beta", _c_void_p),
+                ("a_bn_running_mean", _c_void_p), ("a_bn_running_var", _c_void_p), ("a_bn_nbt", _c_void_p),
+                ("a_bn_out", _c_void_p), ("a_bn_ld", _c_long), ("a_bn_count", _c_long),
+                ("a_bn_eps", _c_float), ("a_bn_momentum", _c_float)]
 
 
 ATTENTION_SYMBOLS = {

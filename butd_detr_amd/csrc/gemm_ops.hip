@@ -281,15 +281,16 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
     // every mode behind run-time branches in one loop body the kernel was ~8 % slower (the path taken
     // was a few hundred instructions scattered over a 30 KB body).
     const bool rt_a_kc = P.lda_k == 1, rt_b_kc = P.ldb_k == 1;
-    const bool rt_fx = P.a_chan_scale != nullptr || P.b_chan_scale != nullptr || a_dropout || b_dropout ||
-                       ones || ((kend - kbeg) % kBK) != 0;
+    const bool rt_fx = P.a_chan_scale != nullptr || P.a_bn_sum != nullptr || P.b_chan_scale != nullptr || a_dropout ||
+                       b_dropout || ones || ((kend - kbeg) % kBK) != 0;
     auto run_fast = [&](auto a_kc_t, auto b_kc_t, auto fx_t) {
       constexpr bool a_kc = decltype(a_kc_t)::value, b_kc = decltype(b_kc_t)::value;
       constexpr bool FX = decltype(fx_t)::value;
       constexpr int kLdTA = TM + 4, kLdTB = TN + 4;   // row stride of a [k][row] image
       static_assert(kBK * kLdTA <= TM * kLd && kBK * kLdTB <= TN * kLd, "[k][row] image must fit the [row][k] buffer");
       const bool f_ones = FX && ones, f_adrop = FX && a_dropout, f_bdrop = FX && b_dropout;
-      const bool a_aff = FX && P.a_chan_scale != nullptr;   // channel = k (varies per slab): staged in LDS
+      const bool a_bn = FX && P.a_bn_sum != nullptr;        // ... computed here from the producer's BatchNorm sums
+      const bool a_aff = FX && (P.a_chan_scale != nullptr || a_bn);   // channel = k (varies per slab): staged in LDS
       const bool b_aff = FX && P.b_chan_scale != nullptr;   // channel = B row: loop-invariant per thread
       const int krange = kend - kbeg;
       // per-thread staging plan: float4 u of operand X sits at (row, k) of the slab; rows outside the
@@ -345,7 +346,41 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
         }
       }
       const long sa = a_kc ? kBK : (long)kBK * P.lda_k, sb = b_kc ? kBK : (long)kBK * P.ldb_k;   // per slab
-      if (a_aff) {
+      if (a_bn) {
+        // BatchNorm bookkeeping of the producing layer (the arithmetic of butd_mlp_bn_finalize): every workgroup
+        // derives scale / shift of its contraction range; the problem's first workgroup also leaves mean / rstd /
+        // scale / shift behind for the backward pass and updates the running statistics -- exactly once
+        const bool writer = wg == batch.blk_begin[pi];
+        const double cnt = (double)P.a_bn_count;
+        for (int k = tid; k < krange; k += kThreads) {
+          const int c = kbeg + k;
+          const double m = P.a_bn_sum[c] / cnt;
+          double v = P.a_bn_sumsq[c] / cnt - m * m;
+          if (v < 0.0) v = 0.0;
+          const float mu = (float)m, var = (float)v;
+          const float rs = 1.0f / sqrtf(var + P.a_bn_eps);
+          const float g = P.a_bn_gamma[c];
+          const float sc = g * rs, sh = P.a_bn_beta[c] - mu * g * rs;
+          Asc[k] = sc;
+          Ash[k] = sh;
+          if (writer) {
+            if (P.a_bn_out) {
+              P.a_bn_out[c] = mu;
+              P.a_bn_out[P.a_bn_ld + c] = rs;
+              P.a_bn_out[2 * P.a_bn_ld + c] = sc;
+              P.a_bn_out[3 * P.a_bn_ld + c] = sh;
+            }
+            if (P.a_bn_running_mean) {
+              const double unbiased = P.a_bn_count > 1 ? v * cnt / (double)(P.a_bn_count - 1) : v;
+              const float mom = P.a_bn_momentum;
+              P.a_bn_running_mean[c] = (1.f - mom) * P.a_bn_running_mean[c] + mom * mu;
+              P.a_bn_running_var[c] = (1.f - mom) * P.a_bn_running_var[c] + mom * (float)unbiased;
+            }
+          }
+        }
+        if (writer && tid == 0 && P.a_bn_nbt) *P.a_bn_nbt += 1;
+        __syncthreads();
+      } else if (a_aff) {
         for (int k = tid; k < krange; k += kThreads) {
           Asc[k] = P.a_chan_scale[kbeg + k];
           Ash[k] = P.a_chan_shift[kbeg + k];
@@ -880,7 +915,7 @@ bool fast_eligible(const butd_gemm_problem &p) {
          (a_kc || (p.M & 3) == 0) && (b_kc || (p.N & 3) == 0) &&   // partial tiles: whole float4 in or out
          ((a_kc ? p.lda_m : p.lda_k) & 3) == 0 && ((b_kc ? p.ldb_n : p.ldb_k) & 3) == 0 &&
          ((((uintptr_t)p.a) | ((uintptr_t)p.b)) & 15) == 0 &&
-         (p.a_chan_scale == nullptr || per <= kAffK);
+         ((p.a_chan_scale == nullptr && p.a_bn_sum == nullptr) || per <= kAffK);
 }
 
 long fill_batch(GemmBatch &batch, const butd_gemm_problem *problems, const int *index, int count,
@@ -1035,6 +1070,10 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
     if ((p.col_sum != nullptr || p.c_add || p.c2 != nullptr || p.c_gate != nullptr) && (p.accumulate || p.ones_col || p.split_k > 1))
       return (int)hipErrorInvalidValue;
     if (p.col_slots > 1 && (p.col_slots & (p.col_slots - 1))) return (int)hipErrorInvalidValue;
+    // (the in-kernel BatchNorm bookkeeping exists on the float4 path only, on unsplit forward products)
+    if (p.a_bn_sum && (!fast_eligible(p) || p.split_k > 1 || !p.a_bn_sumsq || !p.a_bn_gamma || !p.a_bn_beta ||
+                       p.a_bn_count <= 0 || p.a_chan_scale))
+      return (int)hipErrorInvalidValue;
     if (fast_eligible(p)) fast_idx[nf++] = i; else slow_idx[ns++] = i;
   }
   int err = launch_group(problems, fast_idx, nf, true, rng_counter, (hipStream_t)stream);

@@ -21,6 +21,7 @@ from ._hiplib import BnSegment
 from .fused_attention import _gemm, _problem, _stream, rng_counter, _site, zeros
 
 _lib = _hiplib.load()
+_FOLD_BN = [__import__("os").environ.get("BUTD_FOLD_BN", "1") != "0"]     # A/B switch of the in-product BatchNorm bookkeeping
 
 
 def _call(name, ref, *args):
@@ -71,25 +72,39 @@ class _MlpChains(torch.autograd.Function):
         aff = torch.empty((nh, 4, G * Hmax), device=dev)       # per layer: mean, rstd, scale, shift
         sl = lambda l, i: slice(i * Hs[l], (i + 1) * Hs[l])
 
+        # Training: the product that CONSUMES a hidden layer computes that layer's BatchNorm scale / shift from the column
+        # sums itself (butd_gemm_problem.a_bn_*: its first workgroup also writes mean / rstd / scale / shift for the
+        # backward pass and updates the running statistics), so no bookkeeping launch sits between two products
+        # (28 launches per step in the bench configuration).  Needs the float4 staging path (K <= 320, aligned rows).
+        fold = [spec.training and _FOLD_BN[0] and Hs[l] <= 320 and (G * Hs[l]) % 4 == 0 and not (spec.tail and l == nh - 1)
+                for l in range(nh)]
+
         def operand(l, i):
             """Input of layer l (l == nh: the output layer) of chain i: tensor, row stride, prologue."""
             if l == 0:
-                return x, Cin, None, (0.0, 0)
+                return x, Cin, None, (0.0, 0), None
             s = sl(l - 1, i)
-            return (Z[l - 1][:, s], G * Hs[l - 1], (aff[l - 1, 2, s], aff[l - 1, 3, s]),
-                    (p, spec.site0 + (l - 1) * G + i))
+            drop = (p, spec.site0 + (l - 1) * G + i)
+            if fold[l - 1]:
+                rm, rv, nbt = spec.bn_buffers[i][l - 1]
+                bn = (stats[l - 1, 0, s], stats[l - 1, 1, s], hidden[i][l - 1][2], hidden[i][l - 1][3], rm, rv, nbt,
+                      aff[l - 1, 0, s], G * Hmax, P, spec.eps, spec.momentum)
+                return Z[l - 1][:, s], G * Hs[l - 1], None, drop, bn
+            return Z[l - 1][:, s], G * Hs[l - 1], (aff[l - 1, 2, s], aff[l - 1, 3, s]), drop, None
 
         for l in range(nh):
             H, GH = Hs[l], G * Hs[l]
             probs = []
             for i in range(G):
                 w, b = hidden[i][l][0], hidden[i][l][1]
-                a, lda, a_aff, a_drop = operand(l, i)
+                a, lda, a_aff, a_drop, a_bn = operand(l, i)
                 K = Cin if l == 0 else Hs[l - 1]
                 probs.append(_problem(a, w, Z[l][:, sl(l, i)], P, H, K, (lda, 1), (K, 1), GH, bias=b,
-                                      a_affine=a_aff, a_drop=a_drop,
+                                      a_affine=a_aff, a_drop=a_drop, a_bn=a_bn,
                                       col_stats=(stats[l, 0, sl(l, i)], stats[l, 1, sl(l, i)])))
             _gemm(probs, x)
+            if fold[l]:
+                continue                       # (the next product does this layer's bookkeeping)
             segs = (BnSegment * _hiplib.MLP_MAX_SEGMENTS)()
             for i in range(G):
                 rm, rv, nbt = spec.bn_buffers[i][l]
@@ -108,10 +123,10 @@ class _MlpChains(torch.autograd.Function):
             outs, probs = [], []
             for i in range(G):
                 w, b = outp[i]
-                a, lda, a_aff, a_drop = operand(nh, i)
+                a, lda, a_aff, a_drop, a_bn = operand(nh, i)
                 o = torch.empty((P, spec.outs[i]), device=dev)
                 probs.append(_problem(a, w, o, P, spec.outs[i], Hs[-1], (lda, 1), (Hs[-1], 1), spec.outs[i],
-                                      bias=b, a_affine=a_aff, a_drop=a_drop))
+                                      bias=b, a_affine=a_aff, a_drop=a_drop, a_bn=a_bn))
                 outs.append(o)
             _gemm(probs, x)
         ctx.save_for_backward(x, aff, *Z, *params)

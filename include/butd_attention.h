@@ -85,6 +85,21 @@ typedef struct {
    * products on the element-wise staging path).  c_gate has the layout of C (same ldc). */
   const float *c_gate;
   float c_gate_scale;
+  /* Optional: the A operand's per-channel affine computed HERE from the BatchNorm column sums the producing product
+   * left behind (training mode; replaces a_chan_scale / a_chan_shift and the bookkeeping launch between two products of
+   * a Conv1d+BatchNorm chain, include/butd_mlp.h):  for channel k of the contraction
+   *   mean = a_bn_sum[k] / count,  var = max(a_bn_sumsq[k] / count - mean^2, 0),  rstd = 1 / sqrt(var + eps),
+   *   scale = gamma[k] * rstd,  shift = beta[k] - mean * scale,   A(m,k) <- relu(A(m,k) * scale + shift)
+   * -- the arithmetic of butd_mlp_bn_finalize.  The problem's FIRST workgroup also writes mean, rstd, scale, shift to
+   * a_bn_out[0..3][k] (rows a_bn_ld floats apart; saved for the backward pass), updates the running statistics
+   * (momentum, unbiased variance) and increments *a_bn_nbt.  Float4-aligned problems only (K <= 320 per slice). */
+  const double *a_bn_sum, *a_bn_sumsq;
+  const float *a_bn_gamma, *a_bn_beta;
+  float *a_bn_running_mean, *a_bn_running_var;
+  long long *a_bn_nbt;
+  float *a_bn_out;
+  long a_bn_ld, a_bn_count;
+  float a_bn_eps, a_bn_momentum;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).
