@@ -159,6 +159,8 @@ for s in snaps[2:]:
     for i in range(n - 1):
         acc.setdefault(i, []).append(d[i])
 print(f"step start -> update end: {sum(tot) / len(tot):.3f} ms")
+if os.environ.get("MARK_NAMES"):
+    open(os.environ["MARK_NAMES"], "w").write("\n".join(names) + "\n")
 print("  interval (us, mean over replays)      from -> to")
 groups = collections.OrderedDict()
 for i in range(n - 1):
