@@ -254,14 +254,12 @@ __global__ __launch_bounds__(kThreads) void panel_chain_kernel(PanelArgs args, c
     if (NT <= 16) gemm_stage_k<RT, 4>(acc, ring, panel(S.in_buf), S.w, boff, S.K, fr, fg);
     else gemm_stage_k<RT, 5>(acc, ring, panel(S.in_buf), S.w, boff, S.K, fr, fg);
     // (this stage's ring is drained: the next stage's first slabs start their trip now)
-    const int ct_last = wave + 16;   // tile index of j = 4
     float bias_v[5];
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
       const int ct = wave + 4 * j;
       bias_v[j] = (S.bias && ct < NT) ? S.bias[ct * 16 + fr] : 0.f;
     }
-    (void)ct_last;
     if (si + 1 < args.nstages) prefetch_stage(args.st[si + 1]);
 
     const float scale = S.scale;
