@@ -118,20 +118,25 @@ class CrossAttentionLayer(nn.Module):
                         ffn=(self.ffn_lv, self.norm_lv2))[0]
 
     def vision_branch(self, vis_feats, text_in, text_key_padding_mask, pos_feats,
-                      detected_feats=None, detected_mask=None, xq_pre=None, q_pre=None, kv_pre=None):
-        """vision attends to language (keys/values = the layer INPUT text), [to the boxes], FFN"""
+                      detected_feats=None, detected_mask=None, xq_pre=None, q_pre=None, kv_pre=None, next_pos=None):
+        """vision attends to language (keys/values = the layer INPUT text), [to the boxes], FFN.
+        ``next_pos``: -> (out, out + next_pos): the `src + pos` of the next layer's self-attention, from the FFN's
+        LayerNorm kernel (values only; None on the stock path)."""
         # positional features only on the query (:79-80)
         boxes = detected_feats is not None and self.use_butd_enc_attn
         vis_feats, _, em = ab.block(self.cross_vl, self.dropout_vl, self.norm_vl, x=vis_feats, pos=pos_feats,
                                     memory=text_in, key_padding_mask=text_key_padding_mask, xq_pre=xq_pre,
                                     q_pre=q_pre, kv_pre=kv_pre,
                                     emit=[ab.q_projection(self.cross_d, False)] if boxes else None,
-                                    ffn=None if boxes else (self.ffn_vl, self.norm_vl2))
+                                    ffn=None if boxes else (self.ffn_vl, self.norm_vl2),
+                                    next_pos=None if boxes else next_pos)
+        vis_pos = _
         if boxes:
-            vis_feats = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=vis_feats, memory=detected_feats,
-                                 key_padding_mask=detected_mask, q_pre=em[0] if em else None,
-                                 ffn=(self.ffn_vl, self.norm_vl2))[0]
-        return vis_feats
+            vis_feats, vis_pos, _ = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=vis_feats,
+                                             memory=detected_feats, key_padding_mask=detected_mask,
+                                             q_pre=em[0] if em else None, ffn=(self.ffn_vl, self.norm_vl2),
+                                             next_pos=next_pos)
+        return vis_feats if next_pos is None else (vis_feats, vis_pos)
 
     def self_emits(self):
         """What the two self-attention blocks in front of this layer emit for it: (vision side, language side)."""
@@ -158,11 +163,12 @@ class TransformerEncoderLayerNoFFN(nn.Module):
 class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
     """Same, with the positional embedding added to query and key (not value)."""
 
-    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, emit=None):
-        """``emit``: as above; the output + pos is produced too -> (out, out + pos, [projections])."""
+    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, emit=None, xq_pre=None):
+        """``emit``: as above; the output + pos is produced too -> (out, out + pos, [projections]).
+        ``xq_pre``: src + pos as an earlier kernel already wrote it (values only)."""
         assert src_mask is None, "attn_mask is never used on this path"
         return ab.block(self.self_attn, self.dropout1, self.norm1, x=src, pos=pos,
-                        key_padding_mask=src_key_padding_mask, emit=emit,
+                        key_padding_mask=src_key_padding_mask, emit=emit, xq_pre=xq_pre,
                         next_pos=pos if emit is not None else None)
 
 
@@ -196,7 +202,12 @@ class BiEncoderLayer(nn.Module):
                                                use_butd_enc_attn)
 
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
-                end_points={}, detected_feats=None, detected_mask=None):
+                end_points={}, detected_feats=None, detected_mask=None, vis_xq_pre=None, next_pos=None):
+        """The reference's signature (:212-255) plus two optional hints of the layer stack: ``pos_feats`` may be a pair
+        (alias for the self-attention, alias for the cross-attention: one gradient sum for all layers' aliases,
+        fan_out.py); ``vis_xq_pre`` = vis_feats + pos as the previous layer's last kernel wrote it; ``next_pos`` ->
+        a third result, this layer's vis output + next_pos, for the next layer."""
+        pos_self, pos_cross = pos_feats if isinstance(pos_feats, (tuple, list)) else (pos_feats, pos_feats)
         fork = _fork_language(vis_feats)
         if fork:
             main = torch.cuda.current_stream(vis_feats.device)
@@ -224,9 +235,9 @@ class BiEncoderLayer(nn.Module):
                                                                  emit=text_emit)
         vis_self, vis_self_pos, vis_em = vis_feats, None, []
         if self.self_attention_visual is not None:
-            vis_self, vis_self_pos, vis_em = self.self_attention_visual(vis_feats, pos_feats,
+            vis_self, vis_self_pos, vis_em = self.self_attention_visual(vis_feats, pos_self,
                                                                         src_key_padding_mask=padding_mask,
-                                                                        emit=vis_emit)
+                                                                        emit=vis_emit, xq_pre=vis_xq_pre)
         if fork:
             side.wait_stream(main)                  # language <- vision reads vis_self (+ its key / value projections)
             main.wait_stream(side)                  # vision <- language reads text_self (+ ...)
@@ -238,11 +249,13 @@ class BiEncoderLayer(nn.Module):
         q_lv, kv_vl = (text_em[0], tuple(text_em[1:])) if text_em else (None, None)
         with on_side():
             text_out = cross.language_branch(text_self, vis_self, padding_mask, q_pre=q_lv, kv_pre=kv_lv)
-        vis_out = cross.vision_branch(vis_self, text_self, text_padding_mask, pos_feats, detected_feats,
-                                      detected_mask, xq_pre=vis_self_pos, q_pre=q_vl, kv_pre=kv_vl)
+        vis_out = cross.vision_branch(vis_self, text_self, text_padding_mask, pos_cross, detected_feats,
+                                      detected_mask, xq_pre=vis_self_pos, q_pre=q_vl, kv_pre=kv_vl, next_pos=next_pos)
         if fork:
             main.wait_stream(side)                  # join
             text_out.record_stream(main)
+        if next_pos is not None:
+            return vis_out[0], text_out, vis_out[1]
         return vis_out, text_out
 
 
@@ -255,13 +268,23 @@ class BiEncoder(nn.Module):
     def forward(self, vis_feats, pos_feats, padding_mask, text_feats, text_padding_mask,
                 end_points={}, detected_feats=None, detected_mask=None):
         # the position embedding and the box stream feed every layer: one gradient sum each (fan_out.py)
-        pos_l = fan_out(pos_feats, self.num_layers)
+        # (two consumers per layer -- the self-attention and the vision <- language cross-attention: 2 n aliases, ONE sum)
+        # (the one-launch sum takes up to 8 sources: deeper stacks keep one alias per layer)
+        handoff = os.environ.get("BUTD_ENC_POS_HANDOFF", "1") != "0"       # (A/B switch)
+        two = handoff and 2 * self.num_layers <= 8
+        pos_l = fan_out(pos_feats, 2 * self.num_layers if two else self.num_layers)
+        pos_of = (lambda i: (pos_l[2 * i], pos_l[2 * i + 1])) if two else (lambda i: pos_l[i])
         det_l = fan_out(detected_feats, self.num_layers)
+        xq_pre = None
         for i, layer in enumerate(self.layers):
-            vis_feats, text_feats = layer(vis_feats, pos_l[i], padding_mask, text_feats,
-                                          text_padding_mask, end_points,
-                                          detected_feats=det_l[i],
-                                          detected_mask=detected_mask)
+            # every layer but the last also writes `its output + pos` from its last LayerNorm kernel: the next layer's
+            # query / key input (values only: the fused path's by-product, None on the stock path)
+            nxt = pos_feats if (handoff and i + 1 < self.num_layers and pos_feats is not None) else None
+            out = layer(vis_feats, pos_of(i), padding_mask, text_feats,
+                        text_padding_mask, end_points, detected_feats=det_l[i], detected_mask=detected_mask,
+                        vis_xq_pre=xq_pre, next_pos=nxt)
+            vis_feats, text_feats = out[0], out[1]
+            xq_pre = out[2] if len(out) > 2 else None
             if "lv_attention" in end_points:
                 end_points["lv_attention%d" % i] = end_points["lv_attention"]
         return vis_feats, text_feats

@@ -366,7 +366,9 @@ class _AttentionBlock(torch.autograd.Function):
 
 class _FfnBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, p2, site1, site2, pre=None):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, p2, site1, site2, pre=None, next_pos=None):
+        """``next_pos``: also return y + next_pos (values only), written by the LayerNorm kernel: the `src + pos` of the
+        NEXT layer's first block (encoder_decoder_layers.py:179-185)."""
         B, L, E = x.shape
         Fh = w1.shape[0]
         M = B * L
@@ -388,17 +390,27 @@ class _FfnBlock(torch.autograd.Function):
             else:
                 _gemm([_fwd(x, w1, h, M, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
                 _gemm([_fwd(h, w2, o, M, E, Fh, bias=b2)], x)
+                y_pos = torch.empty((B, L, E), device=dev) if next_pos is not None else None
                 with torch.cuda.device(dev):
-                    err = _lib.butd_add_dropout_layernorm_fwd(
+                    err = _lib.butd_add_dropout_layernorm_fwd_pos(
                         M, E, o.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
-                        mean.data_ptr(), rstd.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _stream(x))
-                _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
+                        mean.data_ptr(), rstd.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _ptr(next_pos),
+                        _ptr(y_pos), _stream(x))
+                _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
+                if y_pos is not None:
+                    ctx.save_for_backward(x, w1, w2, gamma, h, o, mean, rstd)
+                    ctx.cfg = (p1, p2, site1, site2)
+                    ctx.mark_non_differentiable(y_pos)
+                    ctx.set_materialize_grads(False)
+                    return y, y_pos
         ctx.save_for_backward(x, w1, w2, gamma, h, o, mean, rstd)
         ctx.cfg = (p1, p2, site1, site2)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _d_y_pos=None):
+        if dy is None:
+            return (None,) * 14
         x, w1, w2, gamma, h, o, mean, rstd = ctx.saved_tensors
         p1, p2, site1, site2 = ctx.cfg
         B, L, E = x.shape
@@ -430,7 +442,7 @@ class _FfnBlock(torch.autograd.Function):
                _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)], x)
         _gemm([_dgrad(d_h, w1, d_x, M, Fh, E, c_add=True),
                _wgrad(d_h, x, d_w1, d_b1, M, Fh, E)], x)
-        return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None, None
+        return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None, None, None
 
 
 class _LinearReluChain(torch.autograd.Function):
@@ -851,17 +863,22 @@ def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, 
         if chain:
             ffn_pack = (lin1.weight.detach(), lin1.bias.detach(), lin2.weight.detach(), lin2.bias.detach(),
                         norm2.weight.detach(), norm2.bias.detach(), float(norm2.eps), p1, p2, *ffn_sites)
+    # with an FFN behind the block `next_pos` belongs to the FFN's output (the layer's output): unchained, the FFN's own
+    # LayerNorm kernel writes y + next_pos; chained, the panel kernel's last stage would (not built: the chain is off)
+    ffn_pos = next_pos if (ffn is not None and not chain) else None
+    blk_pos = None if ffn is not None else next_pos
     out = _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
                           attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
                           norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
-                          _next_site(), _next_site(), xq_pre, next_pos,
+                          _next_site(), _next_site(), xq_pre, blk_pos,
                           None if q_pre is None else q_pre.detach(),
                           None if kv_pre is None else tuple(t.detach() for t in kv_pre), emit, ffn_pack)
     out = list(out) if isinstance(out, tuple) else [out]
     y = out.pop(0)
-    y_pos = out.pop(0) if next_pos is not None else None
+    y_pos = out.pop(0) if blk_pos is not None else None
     emitted = [out.pop(0) for _ in emit]
     if ffn is not None:
-        y = _FfnBlock.apply(y, lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm2.weight, norm2.bias,
-                            float(norm2.eps), p1, p2, *ffn_sites, tuple(out) if chain else None)
+        r = _FfnBlock.apply(y, lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm2.weight, norm2.bias,
+                            float(norm2.eps), p1, p2, *ffn_sites, tuple(out) if chain else None, ffn_pos)
+        y, y_pos = r if isinstance(r, tuple) else (r, None)
     return (y, y_pos, emitted) if extras_asked else y
