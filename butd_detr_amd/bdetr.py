@@ -289,6 +289,7 @@ class BeaUTyDETR(nn.Module):
                 [self.box_embeddings(inputs["det_boxes"]), class_feats.transpose(1, 2)], 1
             ).transpose(1, 2).contiguous()                       # (B, D, d)
 
+        self._stage_hook(inputs, "encoder")
         vis, text_feats = self.cross_encoder(
             vis_feats=points_features.transpose(1, 2).contiguous(),
             pos_feats=self.pos_embed(points_xyz).transpose(1, 2).contiguous(),
@@ -323,6 +324,7 @@ class BeaUTyDETR(nn.Module):
             # position embedding below copy them anyway and nothing writes the head outputs in place)
 
         # the encoder outputs feed all decoder layers: one gradient sum per stream (fan_out.py)
+        self._stage_hook(inputs, "decoder")
         n_dec = len(self.decoder)
         vis_l, text_l = fan_out(vis, n_dec), fan_out(text_feats, n_dec)
         det_l = fan_out(detected_feats if self.butd else None, n_dec)
@@ -351,6 +353,16 @@ class BeaUTyDETR(nn.Module):
             for i, (prefix, _) in enumerate(proj_inputs):
                 end_points[f"{prefix}proj_queries"] = proj[i]
         return end_points
+
+    @staticmethod
+    def _stage_hook(inputs, stage):
+        """Optional callbacks of the caller at stage boundaries of the forward pass (``inputs["_stage_hooks"] =
+        {"encoder": fn, "decoder": fn}``): the captured training step uses them to fork its prefetch branches (the next
+        batch's language model / sampling chain) where the main queue leaves the chip idle instead of at the start of
+        the step (train_step.GraphedTrainStep)."""
+        hooks = inputs.get("_stage_hooks")
+        if hooks and stage in hooks:
+            hooks[stage]()
 
     def _run_head(self, head, features, cluster_xyz, end_points, prefix, features_pm=None):
         """One prediction head (bdetr.py:306-312).  On the fused backend it runs on a FORKED stream: in the forward pass
