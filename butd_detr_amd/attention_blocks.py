@@ -123,7 +123,7 @@ def kv_projections(attn):
 
 
 def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None,
-          q_pre=None, kv_pre=None, emit=None, ffn=None):
+          q_pre=None, kv_pre=None, emit=None, ffn=None, kv_ext=None):
     """The block in the two shapes the model uses it (every call site of
     encoder_decoder_layers.py:87-122,149-155,179-185,356-404):
         memory is None:  self-attention,  query = key = x (+ pos), value = x
@@ -139,7 +139,7 @@ def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=Non
     if _BACKEND == "hip" and x.is_cuda:
         from . import fused_attention
         return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask, xq_pre, next_pos,
-                                     q_pre, kv_pre, emit, ffn)
+                                     q_pre, kv_pre, emit, ffn, kv_ext)
     q = x if pos is None else x + pos
     k, v = (q, x) if memory is None else (memory, memory)
     y = norm(x + dropout(_mha_torch(attn, q, k, v, key_padding_mask)))

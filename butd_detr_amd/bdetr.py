@@ -64,6 +64,16 @@ def _embedding_lookup(weight, ids):
     return torch.nn.functional.embedding(ids, weight)
 
 
+_KV_STREAMS = {}
+
+
+def _kv_stream(device):
+    st = _KV_STREAMS.get(device)
+    if st is None:
+        st = _KV_STREAMS[device] = torch.cuda.Stream(device)
+    return st
+
+
 _HEAD_STREAMS = {}
 
 
@@ -328,6 +338,7 @@ class BeaUTyDETR(nn.Module):
         n_dec = len(self.decoder)
         vis_l, text_l = fan_out(vis, n_dec), fan_out(text_feats, n_dec)
         det_l = fan_out(detected_feats if self.butd else None, n_dec)
+        kv_layers, kv_events = self._decoder_memory_kv(vis_l, text_l, det_l)
         for i, (layer, head) in enumerate(zip(self.decoder, self.prediction_heads)):
             prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
             if self.self_position_embedding == "none":
@@ -338,9 +349,12 @@ class BeaUTyDETR(nn.Module):
                 query_pos = torch.cat([base_xyz, base_size], -1)
             else:
                 raise NotImplementedError
+            if kv_layers is not None:
+                torch.cuda.current_stream(query.device).wait_event(kv_events[i])     # this layer's k, v are ready
             query = layer(query, vis_l[i], text_l[i], query_pos, None, text_padding_mask,
                           detected_feats=det_l[i],
-                          detected_mask=detected_mask if self.butd else None)
+                          detected_mask=detected_mask if self.butd else None,
+                          **({} if kv_layers is None else {"memory_kv": kv_layers[i]}))
             # the layer output feeds the next layer, its head and the contrastive projection
             query, q_head, q_proj = fan_out(query, 3)
             if self.contrastive_align_loss:
@@ -353,6 +367,38 @@ class BeaUTyDETR(nn.Module):
             for i, (prefix, _) in enumerate(proj_inputs):
                 end_points[f"{prefix}proj_queries"] = proj[i]
         return end_points
+
+    def _decoder_memory_kv(self, vis_l, text_l, det_l):
+        """The key / value projections of the decoder's three constant memories for EVERY layer, on a forked stream
+        (fused backend; OFF unless BUTD_DECODER_KV_FORK=1 -- MEASURED, round 4, 3 x 60-step runs each: 25.14 ms with,
+        25.02 ms without: inside a block's grouped launch these products already fill the CUs the query-side products
+        leave idle, and a second queue adds launches without adding overlap; kept as the A/B of that measurement).
+        Nothing of them depends on the query chain, so they run next to it; autograd runs their backward -- the
+        8192-row input- and weight-gradient products of the vision memory, and the deferred query-projection weight
+        gradients -- on that stream as well (fused_attention.memory_kv).  -> ([(KVHolder, [(k, v), ...]) per layer],
+        [event per layer]) or (None, None)."""
+        ref = vis_l[0]
+        if not (self._fused(ref) and os.environ.get("BUTD_DECODER_KV_FORK", "0") == "1"):
+            return None, None
+        from .fused_attention import memory_kv
+        main = torch.cuda.current_stream(ref.device)
+        side = _kv_stream(ref.device)
+        side.wait_stream(main)
+        layers, events = [], []
+        with torch.cuda.stream(side):
+            for i, layer in enumerate(self.decoder):
+                mems = [text_l[i]] + ([det_l[i]] if self.butd else []) + [vis_l[i]]
+                for m in mems:
+                    m.record_stream(side)
+                holder, kv = memory_kv(layer.cross_attentions(with_boxes=self.butd), mems)
+                for k, v in kv:
+                    k.record_stream(main)
+                    v.record_stream(main)
+                layers.append((holder, kv))
+                ev = torch.cuda.Event()
+                ev.record(side)
+                events.append(ev)
+        return layers, events
 
     @staticmethod
     def _stage_hook(inputs, stage):

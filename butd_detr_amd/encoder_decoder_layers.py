@@ -323,9 +323,15 @@ class BiDecoderLayer(nn.Module):
         else:
             self.self_posembed = None
 
+    def cross_attentions(self, with_boxes=True):
+        """The cross-attention modules in the order of ``memory_kv``'s slots: language, [boxes], vision."""
+        return [self.cross_l] + ([self.cross_d] if with_boxes else []) + [self.cross_v]
+
     def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask,
-                text_key_padding_mask, detected_feats=None, detected_mask=None):
-        """query (B,Q,d), vis (B,V,d), lang (B,L,d), query_pos (B,Q,3|6) -> (B,Q,d)."""
+                text_key_padding_mask, detected_feats=None, detected_mask=None, memory_kv=None):
+        """query (B,Q,d), vis (B,V,d), lang (B,L,d), query_pos (B,Q,3|6) -> (B,Q,d).
+        ``memory_kv`` (optional, fused backend): (KVHolder, [(k, v) per cross-attention in ``cross_attentions()``
+        order]) -- the memories' key / value projections as ``fused_attention.memory_kv`` produced them."""
         if self.self_posembed is not None:
             query_pos = self.self_posembed(query_pos).transpose(1, 2).contiguous()
         else:
@@ -342,13 +348,17 @@ class BiDecoderLayer(nn.Module):
         query, qp, em = ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s,
                                  key_padding_mask=padding_mask, next_pos=nxt,
                                  emit=[ab.q_projection(self.cross_l, has_pos)])
+        ext = (lambda i: None) if memory_kv is None else \
+            (lambda i: (memory_kv[1][i][0], memory_kv[1][i][1], memory_kv[0], i))
         query, qp, em = ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l, xq_pre=qp,
                                  q_pre=first(em), memory=lang_feats, key_padding_mask=text_key_padding_mask,
-                                 next_pos=nxt, emit=[ab.q_projection(self.cross_d if boxes else self.cross_v, has_pos)])
+                                 next_pos=nxt, emit=[ab.q_projection(self.cross_d if boxes else self.cross_v, has_pos)],
+                                 kv_ext=ext(0))
         if boxes:
             query, qp, em = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d, xq_pre=qp,
                                      q_pre=first(em), memory=detected_feats, key_padding_mask=detected_mask,
-                                     next_pos=nxt, emit=[ab.q_projection(self.cross_v, has_pos)])
+                                     next_pos=nxt, emit=[ab.q_projection(self.cross_v, has_pos)], kv_ext=ext(1))
         query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v, xq_pre=qp, q_pre=first(em),
-                         memory=vis_feats, key_padding_mask=None, ffn=(self.ffn, self.norm2))[0]
+                         memory=vis_feats, key_padding_mask=None, ffn=(self.ffn, self.norm2),
+                         kv_ext=ext(2 if boxes else 1))[0]
         return query.contiguous()

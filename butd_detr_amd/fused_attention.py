@@ -829,9 +829,190 @@ class _XpmBlock(torch.autograd.Function):
                 None, None, None, None, None, None, None, None, None, None, None, None)
 
 
+# -------------------------------------------------------------------------------------------------
+# Decoder: the key / value projections of the constant memories (language, boxes, vision) on a FORKED stream.
+# A decoder layer's three cross-attention blocks (encoder_decoder_layers.py:376-404) project the SAME three memories in
+# every layer; nothing of that depends on the query chain.  ``MemoryKV`` computes a layer's six projections as one
+# grouped launch -- the model issues all layers' launches on a side stream while the main stream runs the query chain
+# (bdetr.BeaUTyDETR._decoder_memory_kv) -- and owns the WHOLE gradient of the three in-projection weights: autograd runs
+# its backward on that side stream too, so the 8192-row products d_mem = [dk|dv] W_kv, dW_kv = [dk|dv]^T mem and the
+# query-side weight gradients dW_q = dq^T (x + pos) leave the main queue, whose blocks keep only the product the next
+# block waits for (d(x + pos) = dq W_q).  ``_XkvBlock`` is the cross-attention block that takes k, v as differentiable
+# inputs and hands (dq, x + pos) to the holder for the deferred weight gradient.
+# -------------------------------------------------------------------------------------------------
+class KVHolder:
+    """Hand-over between the cross-attention blocks of one decoder layer and its MemoryKV node: slot i = block i's
+    (dq, x + pos) for the deferred query-projection weight gradient."""
+
+    def __init__(self, n):
+        self.q = [None] * n
+
+
+class _MemoryKV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, n, *args):
+        """args = mem_0 .. mem_{n-1}, w_in_0, b_in_0, ..., w_in_{n-1}, b_in_{n-1} -> k_0, v_0, ..., k_{n-1}, v_{n-1}."""
+        mems, wb = args[:n], args[n:]
+        probs, outs = [], []
+        for i, mem in enumerate(mems):
+            w, b = wb[2 * i], wb[2 * i + 1]
+            B, Lk, E = mem.shape
+            k = torch.empty((B, Lk, E), device=mem.device)
+            v = torch.empty((B, Lk, E), device=mem.device)
+            probs += [_fwd(mem, w[E:2 * E], k, B * Lk, E, E, bias=b[E:2 * E]),
+                      _fwd(mem, w[2 * E:], v, B * Lk, E, E, bias=b[2 * E:])]
+            outs += [k, v]
+        for i in range(0, len(probs), 8):
+            _gemm(probs[i:i + 8], mems[0])
+        ctx.save_for_backward(*mems, *wb[0::2])
+        ctx.holder, ctx.n = holder, n
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        n, holder = ctx.n, ctx.holder
+        mems, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        dev = mems[0].device
+        probs, d_mems, d_wb = [], [], []
+        for i, (mem, w) in enumerate(zip(mems, ws)):
+            B, Lk, E = mem.shape
+            Mk = B * Lk
+            slab = zeros(3 * E * E + 3 * E, device=dev)
+            d_w, d_b = slab[:3 * E * E].view(3 * E, E), slab[3 * E * E:]
+            d_wb += [d_w, d_b]
+            dk, dv = grads[2 * i], grads[2 * i + 1]
+            if dk is None or dv is None:          # (the block's output went unused)
+                d_mems.append(None)
+            else:
+                # [dk | dv] as the blocks leave it: two column halves of one (B, Lk, 2E) matrix -- read in place
+                packed = (dk.dim() == 3 and dk.stride() == dv.stride() and dk.stride(2) == 1 and dk.stride(1) == 2 * E
+                          and dk.stride(0) == Lk * 2 * E and dv.data_ptr() == dk.data_ptr() + 4 * E)
+                G = dk if packed else torch.cat([dk, dv], dim=-1).contiguous()
+                d_mem = torch.empty((B, Lk, E), device=dev)
+                d_mems.append(d_mem)
+                probs += [_problem(G, w[E:], d_mem, Mk, E, 2 * E, (2 * E, 1), (1, E), E),
+                          _xwgrad(G, 2 * E, mem, d_w[E:], d_b[E:], Mk, 2 * E, E)]
+            stash = holder.q[i]
+            if stash is not None:
+                dq, xq = stash
+                holder.q[i] = None
+                Mq = dq.shape[0] * dq.shape[1]
+                probs.append(_xwgrad(dq, E, xq, d_w[:E], d_b[:E], Mq, E, E))
+        for i in range(0, len(probs), 8):
+            _gemm(probs[i:i + 8], mems[0])
+        return (None, None, *d_mems, *d_wb)
+
+
+def memory_kv(attns, mems):
+    """[(attention module, memory (B, Lk, E))] of one decoder layer -> (KVHolder, [(k, v), ...]): one grouped launch."""
+    holder = KVHolder(len(attns))
+    mems = [m.contiguous() for m in mems]
+    _check(*mems)
+    wb = []
+    for a in attns:
+        wb += [a.in_proj_weight, a.in_proj_bias]
+    out = _MemoryKV.apply(holder, len(attns), *mems, *wb)
+    return holder, [(out[2 * i], out[2 * i + 1]) for i in range(len(attns))]
+
+
+class _XkvBlock(torch.autograd.Function):
+    """LayerNorm(x + Dropout(MHA(x + pos, k, v))) with k, v given (MemoryKV): the gradients of k, v are returned, the
+    in-projection's weight gradient is MemoryKV's."""
+
+    @staticmethod
+    def forward(ctx, x, pos, k, v, mask, w_in, b_in, w_o, b_o, gamma, beta, num_heads, eps, p_attn, p_out,
+                site_attn, site_out, xq_pre, next_pos, holder, slot):
+        B, Lq, E = x.shape
+        Lk = k.shape[1]
+        H, D = num_heads, E // num_heads
+        dev = x.device
+        Mq = B * Lq
+        scale = math.sqrt(1.0 / float(D))
+        xq = x if pos is None else (xq_pre if xq_pre is not None else x + pos)
+        q = torch.empty((B, Lq, E), device=dev)
+        _gemm([_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale)], x)
+        att = torch.empty((B, Lq, E), device=dev)
+        lse = torch.empty((B, H, Lq), device=dev)
+        with torch.cuda.device(dev):
+            err = _attn_fwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask), att.data_ptr(),
+                              lse.data_ptr(), p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_attention_fwd")
+        proj = torch.empty((B, Lq, E), device=dev)
+        _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
+        y = torch.empty((B, Lq, E), device=dev)
+        mean = torch.empty((Mq,), device=dev)
+        rstd = torch.empty((Mq,), device=dev)
+        y_pos = torch.empty((B, Lq, E), device=dev) if next_pos is not None else None
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_fwd_pos(
+                Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr(), p_out, site_out, rng_counter(dev).data_ptr(), _ptr(next_pos),
+                _ptr(y_pos), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
+        ctx.save_for_backward(x, xq if pos is not None else None, k, v, mask, w_in, w_o, gamma, q, att, lse, proj,
+                              mean, rstd)
+        ctx.cfg = (H, p_attn, p_out, site_attn, site_out, holder, slot)
+        if y_pos is None:
+            return y
+        ctx.mark_non_differentiable(y_pos)
+        ctx.set_materialize_grads(False)
+        return y, y_pos
+
+    @staticmethod
+    def backward(ctx, dy, _d_y_pos=None):
+        if dy is None:
+            return (None,) * 21
+        x, xq_saved, k, v, mask, w_in, w_o, gamma, q, att, lse, proj, mean, rstd = ctx.saved_tensors
+        H, p_attn, p_out, site_attn, site_out, holder, slot = ctx.cfg
+        has_pos = xq_saved is not None
+        xq = xq_saved if has_pos else x
+        B, Lq, E = x.shape
+        Lk = k.shape[1]
+        D = E // H
+        Mq = B * Lq
+        dev = x.device
+        dy = dy.contiguous()
+        slab = zeros(E * E + E + 2 * E, device=dev)
+        d_w_o, d_b_o = slab[:E * E].view(E, E), slab[E * E:E * E + E]
+        d_gamma, d_beta = slab[E * E + E:E * E + 2 * E], slab[E * E + 2 * E:]
+        R = torch.empty((B, Lq, E), device=dev)
+        d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else R
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_bwd(
+                Mq, E, dy.data_ptr(), proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                rstd.data_ptr(), d_proj.data_ptr(), R.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(), p_out,
+                site_out, rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        d_att = torch.empty((B, Lq, E), device=dev)
+        _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E), _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], x)
+        short = _short_key_bwd(Lq, Lk)
+        dq = torch.empty((B, Lq, E), device=dev)
+        G = zeros((B, Lk, 2 * E), device=dev) if short else torch.empty((B, Lk, 2 * E), device=dev)
+        delta = torch.empty((B, H, Lq), device=dev)
+        scale = math.sqrt(1.0 / float(D))
+        with torch.cuda.device(dev):
+            err = (_lib.butd_attention_bwd_short_keys if short else _attn_bwd())(
+                B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask), att.data_ptr(),
+                d_att.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), G.data_ptr(),
+                G.data_ptr() + 4 * E, E, 2 * E, scale, p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_attention_bwd")
+        d_pos = None
+        if has_pos:       # d(x + pos) = dq W_q goes to pos AND is added into the residual-path gradient
+            d_pos = torch.empty((B, Lq, E), device=dev)
+            _gemm([_problem(dq, w_in, d_pos, Mq, E, E, (E, 1), (1, E), E, c2=R)], x)
+        else:
+            _gemm([_problem(dq, w_in, R, Mq, E, E, (E, 1), (1, E), E, c_add=True)], x)
+        holder.q[slot] = (dq, xq)       # MemoryKV's backward (side stream) turns it into dW_q
+        return (R, d_pos, G[:, :, :E], G[:, :, E:], None, None, None, d_w_o, d_b_o, d_gamma, d_beta,
+                None, None, None, None, None, None, None, None, None, None)
+
+
 def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None,
-          q_pre=None, kv_pre=None, emit=None, ffn=None):
+          q_pre=None, kv_pre=None, emit=None, ffn=None, kv_ext=None):
     """LayerNorm(x + Dropout(MHA(x + pos, k, v))), (k, v) = (x + pos, x) or (memory, memory).
+    ``kv_ext`` = (k, v, KVHolder, slot): the memory's key / value projections as a ``memory_kv`` node produced them
+    (differentiable: their gradients go back to that node, which also owns the in-projection's weight gradient).
     ``next_pos``: also return ``y + next_pos`` (written by the kernel that produced y; no gradient flows through it) for
     the next block, which takes it as ``xq_pre`` in place of computing ``x + pos`` itself.
     ``emit``: projections of y / y + next_pos (``q_projection``, ``kv_projections``) computed by the same kernel, to
@@ -848,6 +1029,16 @@ def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, 
     next_pos = None if next_pos is None else next_pos.detach().contiguous()
     xq_pre = None if (xq_pre is None or pos is None) else xq_pre.detach()
     _check(x, pos, memory)
+    if kv_ext is not None:
+        k_ext, v_ext, holder, slot = kv_ext
+        y = _XkvBlock.apply(x, pos, k_ext, v_ext, _as_mask(key_padding_mask), attn.in_proj_weight.detach(),
+                            attn.in_proj_bias.detach(), attn.out_proj.weight, attn.out_proj.bias, norm.weight,
+                            norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out, _next_site(), _next_site(),
+                            xq_pre, None if ffn is not None else next_pos, holder, slot)
+        y, y_pos = y if isinstance(y, tuple) else (y, None)
+        if ffn is not None:
+            y = ffn_block(ffn[0], ffn[1], y)
+        return (y, y_pos, []) if (next_pos is not None or emit is not None or ffn is not None) else y
     extras_asked = next_pos is not None or emit is not None or ffn is not None
     chain = _panel_ok(x.shape[-1]) and (ffn is None or _panel_ok(ffn[0][0].out_features))
     if not chain:       # no chain kernels: the hints that only pay inside one are dropped (round 3's launches)
