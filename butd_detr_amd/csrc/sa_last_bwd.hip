@@ -1,0 +1,416 @@
+// sa_last_bwd.hip -- backward of a set-abstraction level's LAST shared-MLP layer + max-pool in training mode without
+// ever forming its dense gradient (include/butd_sa.h, butd_sa_last_bwd).
+//
+// Reference arithmetic: pointnet2_modules.py:243-257 (SharedMLP -> F.max_pool2d over nsample), pytorch_utils.py:11-36
+// (Conv2d -> BatchNorm2d(batch statistics) -> ReLU).  With H = relu(bn2(Z2)) (P x C2, recomputed from Z2), Z3 = H W3^T,
+// zhat = (Z3 - mu) rstd, s = gamma rstd, and g = the pooled gradient scattered to each (group, channel)'s arg-max row
+// (one non-zero per group and channel), the BatchNorm backward is
+//     dZ3 = s (g - m1 - zhat m2),      m1 = sum(g) / P,  m2 = sum(g zhat) / P        (dense only through m1, m2)
+// and both products that consume dZ3 are linear in its three terms:
+//     dH  = dZ3 W3      =  [sparse: row r gets sum_{c: argmax(group, c) = r} g s_c W3[c,:]]  -  H A  +  d
+//                          A = W3^T diag(s m2 rstd) W3  (C2 x C2),   d = W3^T (s m2 rstd mu - s m1)
+//     dW3 = dZ3^T H     =  s (T - m1 S^T - m2 rstd (W3 Gram - mu S^T))
+//                          T[c,:] = sum_groups g H[argmax row,:],  S = column sums of H,  Gram = H^T H  (C2 x C2)
+// So the level's 10^5..10^6-row tensors are touched as: Z2 read (twice), the layer-2 gradient written and re-read once
+// -- instead of Z3 read, dZ3 written and read twice, Z2 read, dH read and re-read (3.25 GB -> 1.34 GB at SA1, B = 8),
+// and the matrix work halves (2 P C2^2 + 2 P C2^2 flops instead of 4 P C2 C3).  The ReLU gate of layer 2 and the sums
+// its BatchNorm backward needs are taken in the same pass (they were butd_sa_mask_stats).
+//
+//   sa_last_coeffs_kernel   A (negated), d                                   (tiny, double accumulation)
+//   sa_last_mfma_kernel     O = H (-A) + d  -> dH buffer;  Gram partial per workgroup      (fp32 MFMA 16x16x4)
+//   sa_last_sparse_kernel   O += sparse rows; gate; layer-2 sums; T, S partials per workgroup; writes the gated gradient
+//   sa_last_reduce_kernel   partials -> double totals (deterministic: no atomics anywhere on this path)
+//   sa_last_dw_kernel       dW3 and the layer-2 sums
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/butd_sa.h"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 256;
+constexpr int kRows = 64;   // rows per block of the two streaming kernels (a multiple of every nsample: 16, 32, 64)
+
+__device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ coefficients
+// grid C2 x block C2: thread (j, k).  An[j][k] = -sum_c W3[c][j] u_c W3[c][k];  block 0 also d[k] = sum_c W3[c][k] v_c
+template <int C3>
+__global__ void sa_last_coeffs_kernel(int C2, long P, const float *__restrict__ W3, const float *__restrict__ scale3,
+                                      const float *__restrict__ mean3, const float *__restrict__ rstd3,
+                                      const double *__restrict__ S1, const double *__restrict__ S2,
+                                      float *__restrict__ An, float *__restrict__ dvec) {
+  __shared__ double u[C3], v[C3];
+  const double invP = 1.0 / (double)P;
+  for (int c = threadIdx.x; c < C3; c += blockDim.x) {
+    const double s = (double)scale3[c], m1 = S1[c] * invP, m2 = S2[c] * invP, rs = (double)rstd3[c];
+    u[c] = s * m2 * rs;
+    v[c] = u[c] * (double)mean3[c] - s * m1;
+  }
+  __syncthreads();
+  const int j = blockIdx.x, k = threadIdx.x;
+  double a = 0.0, d = 0.0;
+  for (int c = 0; c < C3; ++c) {
+    const double wk = (double)W3[(long)c * C2 + k];
+    a += (double)W3[(long)c * C2 + j] * u[c] * wk;
+    d += wk * v[c];
+  }
+  An[(long)j * C2 + k] = (float)(-a);
+  if (j == 0) dvec[k] = (float)d;
+}
+
+// ------------------------------------------------------------------------------------------- O = H An + d, Gram
+// Persistent workgroups of 4 waves over 64-row blocks.  LDS: the H tile [64][C2 + 36] (row stride = 36 mod 64 banks: the
+// 16-row x 16-byte operand reads of the O product are conflict-free).  O^T tile (16 output columns x 16 rows) = An-rows
+// (A operand, in REGISTERS for the whole kernel: the wave owns C2/4 output columns) x H^T (B operand: lane (row, kq)
+// reads 4 consecutive channels = the k indices of 4 consecutive matrix instructions).  Gram rows owned per wave likewise;
+// its operands are single-float reads of H[4s + kq][column].
+template <int C2>
+__global__ __launch_bounds__(kThreads) void sa_last_mfma_kernel(
+    long P, long nblk, const float *__restrict__ Z2, const float *__restrict__ sc2, const float *__restrict__ sh2,
+    const float *__restrict__ An, const float *__restrict__ dvec, float *__restrict__ O, float *__restrict__ ws) {
+  constexpr int ST = C2 + 36;
+  constexpr int NTO = C2 / 64;   // output-column tiles of 16 per wave
+  constexpr int KG = C2 / 16;    // contraction groups of 16 channels
+  constexpr int GM = C2 / 64;    // Gram row tiles per wave
+  constexpr int GN = C2 / 16;    // Gram column tiles
+  constexpr int QN = C2 / 4;     // float4 chunks per row
+  constexpr int RP = kThreads / QN;   // rows per load pass
+  constexpr int NP = kRows / RP;      // load passes per block
+  __shared__ float Ht[kRows * ST];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
+  const int n0 = wave * (C2 / 4);
+  f4 areg[NTO][KG];
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+      areg[t][g] = *reinterpret_cast<const f4 *>(An + (long)(n0 + 16 * t + lm) * C2 + 16 * g + 4 * lq);
+  f4 dinit[NTO];
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) dinit[t] = *reinterpret_cast<const f4 *>(dvec + n0 + 16 * t + 4 * lq);
+  f4 gacc[GM][GN];
+#pragma unroll
+  for (int m = 0; m < GM; ++m)
+#pragma unroll
+    for (int n = 0; n < GN; ++n) gacc[m][n] = f4{0.f, 0.f, 0.f, 0.f};
+  const int q = tid % QN, rsub = tid / QN;
+  const f4 sc = *reinterpret_cast<const f4 *>(sc2 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh2 + 4 * q);
+  f4 znext[NP];
+  long blk = blockIdx.x;
+  auto load_block = [&](long b) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long p = b * kRows + rsub + ps * RP;
+      znext[ps] = p < P ? *reinterpret_cast<const f4 *>(Z2 + p * C2 + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  if (blk < nblk) load_block(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const bool in = blk * kRows + r < P;
+      f4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = in ? fmaxf(sc[e] * znext[ps][e] + sh[e], 0.f) : 0.f;
+      *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+    }
+    __syncthreads();
+    if (blk + gridDim.x < nblk) load_block(blk + gridDim.x);   // in flight under the matrix work below
+    // ---- O^T tiles
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f4 oacc[NTO];
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) oacc[t] = dinit[t];
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const f4 hv = *reinterpret_cast<const f4 *>(Ht + (16 * rt + lm) * ST + 16 * g + 4 * lq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < NTO; ++t) oacc[t] = mfma4(areg[t][g][i], hv[i], oacc[t]);
+      }
+      const long p = blk * kRows + 16 * rt + lm;
+      if (p < P) {
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) *reinterpret_cast<f4 *>(O + p * C2 + n0 + 16 * t + 4 * lq) = oacc[t];
+      }
+    }
+    // ---- Gram += H^T H over the block's rows
+#pragma unroll 4
+    for (int s = 0; s < kRows / 4; ++s) {
+      const float *hrow = Ht + (4 * s + lq) * ST + lm;
+      float a[GM], b[GN];
+#pragma unroll
+      for (int m = 0; m < GM; ++m) a[m] = hrow[n0 + 16 * m];
+#pragma unroll
+      for (int n = 0; n < GN; ++n) b[n] = hrow[16 * n];
+#pragma unroll
+      for (int m = 0; m < GM; ++m)
+#pragma unroll
+        for (int n = 0; n < GN; ++n) gacc[m][n] = mfma4(a[m], b[n], gacc[m][n]);
+    }
+    __syncthreads();
+  }
+  float *out = ws + (long)blockIdx.x * C2 * C2;
+#pragma unroll
+  for (int m = 0; m < GM; ++m)
+#pragma unroll
+    for (int n = 0; n < GN; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) out[(long)(n0 + 16 * m + 4 * lq + i) * C2 + 16 * n + lm] = gacc[m][n][i];
+}
+
+// --------------------------------------------------------------------- sparse rows, gate, layer-2 sums, T and S
+// Same block decomposition.  LDS: the O tile and the H tile [64][C2 + 4], the block's (group, channel) records.  A wave
+// owns C3/4 channels: its W3 rows and its T accumulators live in registers (lane = column, C2/64 columns per lane); for
+// every non-zero (group, channel) it adds g s W3[c,:] to the arg-max row of the O tile (LDS float atomics: other waves
+// may hit the same row) and g H[row,:] to T[c,:].  Then the element-wise pass: gate by H > 0, the two BatchNorm sums of
+// layer 2 and the column sums of H per thread, the gated gradient to memory.  Partials leave per workgroup.
+template <int C2, int C3>
+__global__ __launch_bounds__(kThreads) void sa_last_sparse_kernel(
+    long P, long nblk, int ns, long G, float *__restrict__ O, const float *__restrict__ Z2,
+    const float *__restrict__ sc2, const float *__restrict__ sh2, const float *__restrict__ mean2,
+    const float *__restrict__ rstd2, const float *__restrict__ W3, const float *__restrict__ d_out,
+    const float *__restrict__ zsel, const uint8_t *__restrict__ asel, const float *__restrict__ sc3,
+    const float *__restrict__ sh3, float *__restrict__ ws, long ws_stride) {
+  constexpr int ST = C2 + 4;
+  constexpr int CPW = C3 / 4;
+  constexpr int KL = C2 / 64;
+  constexpr int QN = C2 / 4;
+  constexpr int RP = kThreads / QN;
+  constexpr int NP = kRows / RP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Os = lds;                   // [64][ST]
+  float *Hs = Os + kRows * ST;       // [64][ST]
+  float *g_sh = Hs + kRows * ST;     // [4][C3] pooled gradient where the pooled activation is > 0, else 0
+  int *row_sh = reinterpret_cast<int *>(g_sh + 4 * C3);   // [4][C3] arg-max row inside the block
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int q = tid % QN, rsub = tid / QN;
+  const int nc = kRows / ns;         // groups per block
+  float w3r[CPW][KL], tacc[CPW][KL], s3r[CPW];
+#pragma unroll
+  for (int ci = 0; ci < CPW; ++ci) {
+    const int c = wave * CPW + ci;
+    s3r[ci] = sc3[c];
+#pragma unroll
+    for (int kk = 0; kk < KL; ++kk) {
+      w3r[ci][kk] = W3[(long)c * C2 + lane + 64 * kk];
+      tacc[ci][kk] = 0.f;
+    }
+  }
+  const f4 sc = *reinterpret_cast<const f4 *>(sc2 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh2 + 4 * q);
+  const f4 mu = *reinterpret_cast<const f4 *>(mean2 + 4 * q), rs = *reinterpret_cast<const f4 *>(rstd2 + 4 * q);
+  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, scol = {0.f, 0.f, 0.f, 0.f};
+  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    f4 zk[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const long p = blk * kRows + r;
+      f4 h = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+      zk[ps] = f4{0.f, 0.f, 0.f, 0.f};
+      if (p < P) {
+        zk[ps] = *reinterpret_cast<const f4 *>(Z2 + p * C2 + 4 * q);
+        o = *reinterpret_cast<const f4 *>(O + p * C2 + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = fmaxf(sc[e] * zk[ps][e] + sh[e], 0.f);
+      }
+      *reinterpret_cast<f4 *>(Hs + r * ST + 4 * q) = h;
+      *reinterpret_cast<f4 *>(Os + r * ST + 4 * q) = o;
+    }
+    for (int e = tid; e < nc * C3; e += kThreads) {
+      const int gi = e / C3, c = e - gi * C3;
+      const long g = blk * nc + gi;
+      float gv = 0.f;
+      int row = 0;
+      if (g < G) {
+        const float z = zsel[g * C3 + c];
+        if (sc3[c] * z + sh3[c] > 0.f) gv = d_out[g * C3 + c];
+        row = gi * ns + (int)asel[g * C3 + c];
+      }
+      g_sh[e] = gv;
+      row_sh[e] = row;
+    }
+    __syncthreads();
+    for (int gi = 0; gi < nc; ++gi) {
+#pragma unroll
+      for (int ci = 0; ci < CPW; ++ci) {
+        const int c = wave * CPW + ci;
+        const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g_sh[gi * C3 + c])));
+        if (gv != 0.f) {
+          const int row = __builtin_amdgcn_readfirstlane(row_sh[gi * C3 + c]);
+          const float gs = gv * s3r[ci];
+#pragma unroll
+          for (int kk = 0; kk < KL; ++kk) {
+            const int k = lane + 64 * kk;
+            atomicAdd(Os + row * ST + k, gs * w3r[ci][kk]);
+            tacc[ci][kk] += gv * Hs[row * ST + k];
+          }
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const long p = blk * kRows + r;
+      if (p < P) {
+        const f4 o = *reinterpret_cast<const f4 *>(Os + r * ST + 4 * q);
+        const f4 h = *reinterpret_cast<const f4 *>(Hs + r * ST + 4 * q);
+        f4 g2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g2[e] = h[e] > 0.f ? o[e] : 0.f;
+          s1[e] += g2[e];
+          s2[e] += g2[e] * (zk[ps][e] - mu[e]) * rs[e];
+          scol[e] += h[e];
+        }
+        *reinterpret_cast<f4 *>(O + p * C2 + 4 * q) = g2;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partials of this workgroup: T (C3 x C2), then s1, s2, S (C2 each)
+  float *out = ws + (long)blockIdx.x * ws_stride;
+#pragma unroll
+  for (int ci = 0; ci < CPW; ++ci)
+#pragma unroll
+    for (int kk = 0; kk < KL; ++kk) out[(long)(wave * CPW + ci) * C2 + lane + 64 * kk] = tacc[ci][kk];
+  float *red = Os;    // [3][RP][C2]
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[(0 * RP + rsub) * C2 + 4 * q + e] = s1[e];
+    red[(1 * RP + rsub) * C2 + 4 * q + e] = s2[e];
+    red[(2 * RP + rsub) * C2 + 4 * q + e] = scol[e];
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * C2; e += kThreads) {
+    const int which = e / C2, col = e - which * C2;
+    float a = 0.f;
+    for (int t = 0; t < RP; ++t) a += red[(which * RP + t) * C2 + col];
+    out[(long)C3 * C2 + e] = a;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------- partials -> totals
+// tot[n] = sum over parts of part[w][n] (double), for two groups of partials laid one after the other in tot
+__global__ void sa_last_reduce_kernel(const float *__restrict__ p1, long n1, int parts1, const float *__restrict__ p2,
+                                      long n2, int parts2, double *__restrict__ tot) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n1) {
+    double a = 0.0;
+    for (int w = 0; w < parts1; ++w) a += (double)p1[(long)w * n1 + i];
+    tot[i] = a;
+  } else if (i < n1 + n2) {
+    const long j = i - n1;
+    double a = 0.0;
+    for (int w = 0; w < parts2; ++w) a += (double)p2[(long)w * n2 + j];
+    tot[i] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------- dW3, sums
+// grid C3 x block C2.  tot = [Gram C2*C2 | T C3*C2 | s1 C2 | s2 C2 | S C2] (double).  The centring uses mu' = W3 S / P
+// (the batch mean of Z3 = H W3^T written through the same sums as Gram: the covariance W3 (Gram - S S^T / P) is then
+// centred exactly).
+__global__ void sa_last_dw_kernel(int C2, int C3, long P, const float *__restrict__ W3, const float *__restrict__ scale3,
+                                  const float *__restrict__ rstd3, const double *__restrict__ S1_3,
+                                  const double *__restrict__ S2_3, const double *__restrict__ tot,
+                                  float *__restrict__ dW3, double *__restrict__ S1_2, double *__restrict__ S2_2) {
+  const int c = blockIdx.x, k = threadIdx.x;
+  const double *gram = tot, *T = tot + (long)C2 * C2, *s1 = T + (long)C3 * C2, *s2 = s1 + C2, *S = s2 + C2;
+  const double invP = 1.0 / (double)P;
+  double wg = 0.0, ws = 0.0;
+  for (int j = 0; j < C2; ++j) {
+    const double w = (double)W3[(long)c * C2 + j];
+    wg += w * gram[(long)j * C2 + k];
+    ws += w * S[j];
+  }
+  const double mu = ws * invP, m1 = S1_3[c] * invP, m2 = S2_3[c] * invP;
+  const double v = T[(long)c * C2 + k] - m1 * S[k] - m2 * (double)rstd3[c] * (wg - mu * S[k]);
+  dW3[(long)c * C2 + k] = (float)((double)scale3[c] * v);
+  if (c == 0) {
+    S1_2[k] = s1[k];
+    S2_2[k] = s2[k];
+  }
+}
+
+template <int C2, int C3>
+constexpr size_t sparse_lds() { return (size_t)(2 * kRows * (C2 + 4) + 8 * C3) * sizeof(float); }
+
+hipError_t sparse_attr() {
+  static hipError_t err = []() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<64, 128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<128, 256>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }();
+  return err;
+}
+
+int grid_mfma(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 768 : 512) ? nblk : (C2 == 64 ? 768 : 512)); }
+int grid_sparse(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 512 : 256) ? nblk : (C2 == 64 ? 512 : 256)); }
+
+}  // namespace
+
+extern "C" {
+
+int butd_sa_last_bwd_supported(int ns, int C2, int C3) {
+  return (ns == 16 || ns == 32 || ns == 64) && ((C2 == 64 && C3 == 128) || (C2 == 128 && C3 == 256));
+}
+
+int butd_sa_last_bwd_scratch(long P, int C2, int C3, long *ws_floats, long *ws_doubles) {
+  if (P <= 0 || !ws_floats || !ws_doubles) return (int)hipErrorInvalidValue;
+  const long nblk = (P + kRows - 1) / kRows;
+  const long per_sparse = (long)C3 * C2 + 3 * C2;
+  *ws_floats = (long)C2 * C2 + C2 + (long)grid_mfma(C2, nblk) * C2 * C2 + (long)grid_sparse(C2, nblk) * per_sparse;
+  *ws_doubles = (long)C2 * C2 + per_sparse;
+  return 0;
+}
+
+int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, const float *scale2,
+                     const float *shift2, const float *mean2, const float *rstd2, const float *W3,
+                     const float *d_out_pm, const float *zsel, const uint8_t *asel, const float *scale3,
+                     const float *shift3, const float *mean3, const float *rstd3, const double *S1_3,
+                     const double *S2_3, float *dH2, float *dW3, double *S1_2, double *S2_2, float *ws_f,
+                     double *ws_d, butd_stream_t stream) {
+  const long G = (long)B * np, P = G * ns;
+  if (P <= 0) return 0;
+  if (!butd_sa_last_bwd_supported(ns, C2, C3)) return (int)hipErrorInvalidValue;
+  if (hipError_t e = sparse_attr(); e != hipSuccess) return (int)e;
+  hipStream_t st = (hipStream_t)stream;
+  const long nblk = (P + kRows - 1) / kRows;
+  const int gm = grid_mfma(C2, nblk), gs = grid_sparse(C2, nblk);
+  const long per_sparse = (long)C3 * C2 + 3 * C2;
+  float *An = ws_f, *dvec = An + (long)C2 * C2, *ws_gram = dvec + C2, *ws_sparse = ws_gram + (long)gm * C2 * C2;
+  if (C3 == 128)
+    hipLaunchKernelGGL(sa_last_coeffs_kernel<128>, dim3(C2), dim3(C2), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
+  else
+    hipLaunchKernelGGL(sa_last_coeffs_kernel<256>, dim3(C2), dim3(C2), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
+  if (C2 == 64) {
+    hipLaunchKernelGGL(sa_last_mfma_kernel<64>, dim3(gm), dim3(kThreads), 0, st, P, nblk, Z2, scale2, shift2, An, dvec, dH2, ws_gram);
+    hipLaunchKernelGGL((sa_last_sparse_kernel<64, 128>), dim3(gs), dim3(kThreads), (sparse_lds<64, 128>()), st, P, nblk, ns, G, dH2, Z2, scale2,
+                       shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse);
+  } else {
+    hipLaunchKernelGGL(sa_last_mfma_kernel<128>, dim3(gm), dim3(kThreads), 0, st, P, nblk, Z2, scale2, shift2, An, dvec, dH2, ws_gram);
+    hipLaunchKernelGGL((sa_last_sparse_kernel<128, 256>), dim3(gs), dim3(kThreads), (sparse_lds<128, 256>()), st, P, nblk, ns, G, dH2, Z2, scale2,
+                       shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse);
+  }
+  const long n1 = (long)C2 * C2, n2 = per_sparse;
+  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((n1 + n2 + 255) / 256)), dim3(256), 0, st, ws_gram, n1, gm,
+                     ws_sparse, n2, gs, ws_d);
+  hipLaunchKernelGGL(sa_last_dw_kernel, dim3(C3), dim3(C2), 0, st, C2, C3, P, W3, scale3, rstd3, S1_3, S2_3, ws_d, dW3,
+                     S1_2, S2_2);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -30,6 +30,34 @@ def _call(name, ref, *args):
     _hiplib.check(err, name)
 
 
+# Training-mode backward of the last layer + max-pool by linearity (include/butd_sa.h, butd_sa_last_bwd): no dense dZ3,
+# half the matrix work, 3.25 -> 1.34 GB at SA1.  BUTD_SA_LAST_BWD=0 keeps the dense path (A/B switch, and the path of
+# widths / nsample the kernel has no instance for).
+_LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
+_scratch_sizes = {}
+
+
+def set_last_layer_linear(flag):
+    prev = _LAST_LIN[0]
+    _LAST_LIN[0] = bool(flag)
+    return prev
+
+
+def _last_lin_ok(training, ns, C2, C3):
+    return bool(training and _LAST_LIN[0] and _lib.butd_sa_last_bwd_supported(int(ns), int(C2), int(C3)))
+
+
+def _last_scratch(P, C2, C3):
+    key = (P, C2, C3)
+    if key not in _scratch_sizes:
+        import ctypes
+        nf, nd = ctypes.c_long(0), ctypes.c_long(0)
+        _hiplib.check(_lib.butd_sa_last_bwd_scratch(P, C2, C3, ctypes.byref(nf), ctypes.byref(nd)),
+                      "butd_sa_last_bwd_scratch")
+        _scratch_sizes[key] = (nf.value, nd.value)
+    return _scratch_sizes[key]
+
+
 class _SAMlpPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, feats_pm, new_xyz, idx, radius, normalize, training, momentum,
@@ -110,15 +138,17 @@ class _SAMlpPool(torch.autograd.Function):
         _call("butd_sa_pool_finalize", xyz, B, np_, C3, zmax.data_ptr(), zmin.data_ptr(), amax.data_ptr(),
               amin.data_ptr(), aff[2, 2].data_ptr(), aff[2, 3].data_ptr(), out_cm.data_ptr(),
               out_pm.data_ptr(), zsel.data_ptr(), asel.data_ptr())
-        ctx.save_for_backward(X, Zs[0], Zs[1], Zs[2], idx, aff, zsel, asel, ws[0], ws[1], ws[2], g1, g2, g3)
+        lin = _last_lin_ok(training, ns, C2, C3)    # the backward then never reads Z3: it is not kept
+        ctx.save_for_backward(X, Zs[0], Zs[1], Zs[2][:0] if lin else Zs[2], idx, aff, zsel, asel, ws[0], ws[1], ws[2],
+                              g1, g2, g3)
         ctx.cfg = (B, N, np_, ns, C, bool(training), feats_pm is not None and feats_pm.requires_grad,
-                   w1.shape, w2.shape, w3.shape, Cin)
+                   w1.shape, w2.shape, w3.shape, Cin, lin)
         return out_cm, out_pm
 
     @staticmethod
     def backward(ctx, d_cm, d_pm):
         X, Z1, Z2, Z3, idx, aff, zsel, asel, w1, w2, w3, g1, g2, g3 = ctx.saved_tensors
-        B, N, np_, ns, C, training, need_dfeat, s1, s2, s3, Cin = ctx.cfg
+        B, N, np_, ns, C, training, need_dfeat, s1, s2, s3, Cin, lin = ctx.cfg
         dev = X.device
         P, Kp = X.shape                                 # Kp = Cin rounded up to a multiple of 4
         C1, C2, C3 = w1.shape[0], w2.shape[0], w3.shape[0]
@@ -143,17 +173,28 @@ class _SAMlpPool(torch.autograd.Function):
         _call("butd_sa_pool_bwd_stats", X, B, np_, C3, d_out.data_ptr(), zsel.data_ptr(), scale(2).data_ptr(),
               shift(2).data_ptr(), mean(2).data_ptr(), rstd(2).data_ptr(), S[2, 0].data_ptr(),
               S[2, 1].data_ptr())
-        _call("butd_sa_dz_last", X, B, np_, ns, C3, Z3.data_ptr(), d_out.data_ptr(), zsel.data_ptr(),
-              asel.data_ptr(), g3.data_ptr(), scale(2).data_ptr(), shift(2).data_ptr(), mean(2).data_ptr(),
-              rstd(2).data_ptr(), S[2, 0].data_ptr(), S[2, 1].data_ptr(), tr)
-        dZ3 = Z3                                        # overwritten in place
         dH2 = torch.empty((P, C2), device=dev)
-        _gemm([_wgrad(dZ3, Z2, dW3, None, P, C3, C2, b_affine=(scale(1), shift(1))),
-               _dgrad(dZ3, w3, dH2, P, C3, C2)], X)
-        # ---- layer 2
-        _call("butd_sa_mask_stats", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), scale(1).data_ptr(),
-              shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(),
-              S[1, 1].data_ptr())
+        if lin:
+            # dH2 (gated by layer 2's ReLU), dW3 and layer 2's BatchNorm sums straight from Z2 and the pooled gradient
+            nf, nd = _last_scratch(P, C2, C3)
+            ws_f = torch.empty(nf, device=dev)
+            ws_d = torch.empty(nd, dtype=torch.float64, device=dev)
+            _call("butd_sa_last_bwd", X, B, np_, ns, C2, C3, Z2.data_ptr(), scale(1).data_ptr(), shift(1).data_ptr(),
+                  mean(1).data_ptr(), rstd(1).data_ptr(), w3.data_ptr(), d_out.data_ptr(), zsel.data_ptr(),
+                  asel.data_ptr(), scale(2).data_ptr(), shift(2).data_ptr(), mean(2).data_ptr(), rstd(2).data_ptr(),
+                  S[2, 0].data_ptr(), S[2, 1].data_ptr(), dH2.data_ptr(), dW3.data_ptr(), S[1, 0].data_ptr(),
+                  S[1, 1].data_ptr(), ws_f.data_ptr(), ws_d.data_ptr())
+        else:
+            _call("butd_sa_dz_last", X, B, np_, ns, C3, Z3.data_ptr(), d_out.data_ptr(), zsel.data_ptr(),
+                  asel.data_ptr(), g3.data_ptr(), scale(2).data_ptr(), shift(2).data_ptr(), mean(2).data_ptr(),
+                  rstd(2).data_ptr(), S[2, 0].data_ptr(), S[2, 1].data_ptr(), tr)
+            dZ3 = Z3                                        # overwritten in place
+            _gemm([_wgrad(dZ3, Z2, dW3, None, P, C3, C2, b_affine=(scale(1), shift(1))),
+                   _dgrad(dZ3, w3, dH2, P, C3, C2)], X)
+            # ---- layer 2
+            _call("butd_sa_mask_stats", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), scale(1).data_ptr(),
+                  shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(),
+                  S[1, 1].data_ptr())
         _call("butd_sa_dz_mid", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), g2.data_ptr(), scale(1).data_ptr(),
               shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
         dZ2 = dH2

@@ -80,6 +80,30 @@ int butd_sa_dz_last(int B, int np, int ns, int C, float *Z, const float *d_out_p
                     const float *mean, const float *rstd, const double *S1, const double *S2,
                     int training, butd_stream_t stream);
 
+/* Backward of the LAST shared-MLP layer + max-pool of a level in TRAINING mode, without forming its dense gradient
+ * (csrc/sa_last_bwd.hip; replaces butd_sa_dz_last + the weight- / input-gradient products of that layer +
+ * butd_sa_mask_stats of the layer below; pointnet2_modules.py:243-257, pytorch_utils.py:11-36).  The BatchNorm backward
+ *   dZ3 = s (g - m1 - zhat m2),  s = gamma rstd,  m1 = S1_3 / P,  m2 = S2_3 / P          (butd_sa_pool_bwd_stats)
+ * is dense only through m1 and m2; g has ONE non-zero per (group, channel), at the arg-max row.  By linearity
+ *   dH2 = dZ3 W3   = [row r: sum over the channels whose arg-max is r of g s W3[c,:]] - H2 A + d,  A = W3^T diag(s m2 rstd) W3
+ *   dW3 = dZ3^T H2 = s (T - m1 S^T - m2 rstd (W3 Gram - mu S^T)),  T[c,:] = sum_groups g H2[arg-max row,:],
+ *                                                                   S = column sums of H2,  Gram = H2^T H2
+ * with H2 = relu(scale2 * Z2 + shift2) recomputed from Z2 (P x C2).  Outputs:
+ *   dH2 (P x C2)  the gradient of layer 2's activation ALREADY gated by its ReLU (what butd_sa_dz_mid re-derives),
+ *   dW3 (C3 x C2) written (not accumulated),
+ *   S1_2, S2_2    the two sums of layer 2's BatchNorm backward (what butd_sa_mask_stats produced), written.
+ * Every reduction goes through per-workgroup partials summed in double: no atomics, bit-reproducible.
+ * Supported: ns in {16, 32, 64}, (C2, C3) in {(64, 128), (128, 256)} -- butd_sa_last_bwd_supported; scratch sizes
+ * (floats / doubles, uninitialised) from butd_sa_last_bwd_scratch. */
+int butd_sa_last_bwd_supported(int ns, int C2, int C3);
+int butd_sa_last_bwd_scratch(long P, int C2, int C3, long *ws_floats, long *ws_doubles);
+int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, const float *scale2,
+                     const float *shift2, const float *mean2, const float *rstd2, const float *W3,
+                     const float *d_out_pm, const float *zsel, const uint8_t *asel, const float *scale3,
+                     const float *shift3, const float *mean3, const float *rstd3, const double *S1_3,
+                     const double *S2_3, float *dH2, float *dW3, double *S1_2, double *S2_2, float *ws_f,
+                     double *ws_d, butd_stream_t stream);
+
 /* Hidden layers, part 1 (read-only pass over dH, Z (P x C)): with g = dH * [scale*z+shift > 0],
  * S1[c] += sum_p g, S2[c] += sum_p g*zhat (double, caller zero-fills). */
 int butd_sa_mask_stats(long P, int C, const float *dH, const float *Z, const float *scale,

@@ -105,6 +105,23 @@ if os.environ.get("FINE", "0") == "1":      # every attention / FFN block of the
     _fa.block = _wrap(_orig_block, "blk")
     _fa.ffn_block = _wrap(_orig_ffn, "ffn")
 
+if os.environ.get("ENC", "0") == "1":       # both sides of every encoder layer: marks on WHICHEVER stream runs the piece
+    def hook_any(obj, attr, name):
+        orig = getattr(obj, attr)
+
+        def f(*a, **k):
+            q = "main" if torch.cuda.current_stream(dev) == main_stream[0] else "side"
+            mark(f"E:{name} start [{q}]")
+            out = orig(*a, **k)
+            mark(f"E:{name} end [{q}]")
+            return out
+        setattr(obj, attr, f)
+    for i, l in enumerate(m.cross_encoder.layers):
+        hook_any(l.self_attention_lang, "forward", f"enc{i} text self-attn")
+        hook_any(l.self_attention_visual, "forward", f"enc{i} vis self-attn")
+        hook_any(l.cross_layer, "language_branch", f"enc{i} language branch")
+        hook_any(l.cross_layer, "vision_branch", f"enc{i} vision branch")
+
 crit = HungarianCriterion()
 orig_crit = crit.__call__ if hasattr(crit, "__call__") else None
 opt = FlatAdamW(model)
@@ -161,6 +178,13 @@ for s in snaps[2:]:
 print(f"step start -> update end: {sum(tot) / len(tot):.3f} ms")
 if os.environ.get("MARK_NAMES"):
     open(os.environ["MARK_NAMES"], "w").write("\n".join(names) + "\n")
+if os.environ.get("ENC", "0") == "1":
+    import numpy as np
+    rel = np.mean([(sn[:n].cpu().numpy().astype("int64") - int(sn[0])) * 10e-3 for sn in snaps[2:]], axis=0)
+    print("encoder pieces, absolute time since step start (us), the stream that ran them:")
+    for i in sorted(range(n), key=lambda i: rel[i]):
+        if names[i].startswith("E:") or names[i].startswith("fwd>enc") or names[i] == "fwd>pos_embed":
+            print(f"  {rel[i]:9.1f}   {names[i]}")
 print("  interval (us, mean over replays)      from -> to")
 groups = collections.OrderedDict()
 for i in range(n - 1):

@@ -1,0 +1,132 @@
+"""-m gpu: the last shared-MLP layer + max-pool backward by linearity (include/butd_sa.h butd_sa_last_bwd,
+csrc/sa_last_bwd.hip) vs (i) the dense path it replaces (butd_sa_dz_last + the two products + butd_sa_mask_stats) on the
+same inputs and (ii) a float64 run of the stock module (pointnet2_modules.py:243-257, pytorch_utils.py:11-36).
+fp32 throughout: north_star's tolerance is 1e-3; the two fp32 paths agree to ~1e-5 of each tensor's scale, and the
+linear path is the closer one to float64 (it never rounds a dense dZ3)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _err(a, b):
+    a, b = a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def _stats(a, b):
+    """(entries beyond 1e-3 of the scale, mean error / scale, size, worst): an arg-max or ReLU decision that falls the
+    other way in fp32 than in float64 reroutes a few entries (as in test_gpu_fused_sa.py: 0.1 % allowed)."""
+    a, b = a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy()
+    e = np.abs(a - b) / max(np.abs(b).max(), 1e-30)
+    return int((e > 1e-3).sum()), float(e.mean()), e.size, float(e.max())
+
+
+def _module(cfg, seed):
+    from butd_detr_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(seed)
+    m = PointnetSAModuleVotes(npoint=cfg["npoint"], radius=cfg["radius"], nsample=cfg["nsample"],
+                              mlp=list(cfg["mlp"]), use_xyz=True, normalize_xyz=True).cuda().train()
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.2, 0.2)
+        m.mlp_module.layer2.bn.bn.weight[::7] *= -1.0      # negative scales on the LAST layer: the min-pool branch
+        m.mlp_module.layer1.bn.bn.weight[:3] *= -1.0
+    return m
+
+
+def _run(m, xyz, feats, probe, linear):
+    from butd_detr_amd import attention_blocks, fused_sa
+    prev = fused_sa.set_last_layer_linear(linear)
+    attention_blocks.set_backend("hip")
+    try:
+        for p in m.parameters():
+            p.grad = None
+        f = feats.clone().requires_grad_(True)
+        y = m(xyz, f)[1]
+        assert m.last_features_pm is not None, "fused path not taken"
+        (y * probe).sum().backward()
+        return y.detach().clone(), f.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}
+    finally:
+        attention_blocks.set_backend("torch")
+        fused_sa.set_last_layer_linear(prev)
+
+
+CFGS = [
+    dict(B=2, N=4096, C=3, npoint=512, radius=0.4, nsample=64, mlp=[3, 64, 64, 128]),        # SA1-like
+    dict(B=2, N=2048, C=128, npoint=1024, radius=0.6, nsample=32, mlp=[128, 128, 128, 256]),  # SA2
+    dict(B=3, N=1024, C=256, npoint=512, radius=0.9, nsample=16, mlp=[256, 128, 128, 256]),   # SA3
+    dict(B=1, N=300, C=256, npoint=3, radius=0.9, nsample=16, mlp=[256, 128, 128, 256]),      # 48 rows: a ragged block
+    dict(B=1, N=700, C=3, npoint=5, radius=0.5, nsample=64, mlp=[3, 64, 64, 128]),            # 5 groups
+]
+
+
+@pytest.mark.parametrize("cfg", CFGS)
+def test_linear_last_layer_equals_dense_path(cfg):
+    m = _module(cfg, 3)
+    torch.manual_seed(11)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    y_d, gf_d, gp_d = _run(m, xyz, feats, probe, linear=False)
+    y_l, gf_l, gp_l = _run(m, xyz, feats, probe, linear=True)
+    assert torch.equal(y_d, y_l)                    # the forward is the same code
+    assert _err(gf_l, gf_d) < 5e-5, _err(gf_l, gf_d)
+    for n in gp_d:
+        assert _err(gp_l[n], gp_d[n]) < 5e-5, (n, _err(gp_l[n], gp_d[n]))
+
+
+def test_linear_last_layer_is_bit_reproducible():
+    """No atomics on the path: two runs give identical dW3 / BatchNorm sums of layer 2 (the dense path's split-K
+    accumulation does not)."""
+    cfg = CFGS[1]
+    m = _module(cfg, 5)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    a = _run(m, xyz, feats, probe, linear=True)[2]
+    b = _run(m, xyz, feats, probe, linear=True)[2]
+    for n in a:
+        if "layer2" in n:
+            assert torch.equal(a[n], b[n]), n
+
+
+@pytest.mark.parametrize("cfg", CFGS[:3])
+def test_linear_last_layer_vs_float64_module(cfg):
+    """Against the stock module in float64 on the CPU with the SAME neighbour lists: both fp32 paths inside 1e-3
+    (north_star), the linear one no further from the truth than the dense one (+ rounding slack)."""
+    from butd_detr_amd import attention_blocks, pointnet2_utils
+    m = _module(cfg, 7)
+    torch.manual_seed(13)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    y_d, gf_d, gp_d = _run(m, xyz, feats, probe, linear=False)
+    y_l, gf_l, gp_l = _run(m, xyz, feats, probe, linear=True)
+    # float64 truth: the module's own torch path with index ops taken from the fp32 GPU kernels (bit-exact vs the oracle)
+    inds = pointnet2_utils.furthest_point_sample(xyz, cfg["npoint"])
+    new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    idx = pointnet2_utils.ball_query(cfg["radius"], cfg["nsample"], xyz, new_xyz).long().cpu()
+    m.last_features_pm = None        # (a tensor with a grad_fn: not deep-copyable)
+    m64 = copy.deepcopy(m).double().cpu()
+    x64, f64 = xyz.double().cpu(), feats.double().cpu().requires_grad_(True)
+    B, S, K = idx.shape
+    bi = torch.arange(B)[:, None, None]
+    grouped_xyz = (x64[bi, idx] - new_xyz.double().cpu()[:, :, None, :]) / cfg["radius"]       # (B, S, K, 3)
+    grouped_f = f64.transpose(1, 2)[bi, idx]                                                     # (B, S, K, C)
+    g = torch.cat([grouped_xyz, grouped_f], -1).permute(0, 3, 1, 2)                              # (B, 3+C, S, K)
+    y64 = m64.mlp_module(g).max(-1)[0]
+    (y64 * probe.double().cpu()).sum().backward()
+    assert _err(y_l, y64) < 1e-4
+    pairs = [("d_feats", gf_d, gf_l, f64.grad)]
+    pairs += [(n, gp_d[n], gp_l[n], p.grad) for n, p in m64.named_parameters() if "mlp_module" in n and p.grad is not None]
+    assert len(pairs) >= 8
+    for n, dense, lin, truth in pairs:
+        (_, m_d, _, _), (bad, m_l, size, worst) = _stats(dense, truth), _stats(lin, truth)
+        assert bad <= max(2, 1e-3 * size) and worst < 2e-2 and m_l <= 1e-4, (n, bad, size, worst, m_l)
+        assert m_l <= 1.5 * m_d + 1e-6, (n, m_l, m_d)        # typical error: no worse than the dense path
