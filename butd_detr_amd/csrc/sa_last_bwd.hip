@@ -38,29 +38,41 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 }
 
 // ------------------------------------------------------------------------------------------------ coefficients
-// grid C2 x block C2: thread (j, k).  An[j][k] = -sum_c W3[c][j] u_c W3[c][k];  block 0 also d[k] = sum_c W3[c][k] v_c
+// grid (C2/16, C2/16) x 256 threads: a 16 x 16 tile of An = -W3^T diag(u) W3 per block, the two 16-column slices of W3
+// staged in LDS; the blocks of the first tile row also write d = W3^T v for their 16 columns.  Double accumulation.
 template <int C3>
-__global__ void sa_last_coeffs_kernel(int C2, long P, const float *__restrict__ W3, const float *__restrict__ scale3,
-                                      const float *__restrict__ mean3, const float *__restrict__ rstd3,
-                                      const double *__restrict__ S1, const double *__restrict__ S2,
-                                      float *__restrict__ An, float *__restrict__ dvec) {
+__global__ __launch_bounds__(256) void sa_last_coeffs_kernel(int C2, long P, const float *__restrict__ W3,
+                                                             const float *__restrict__ scale3,
+                                                             const float *__restrict__ mean3,
+                                                             const float *__restrict__ rstd3,
+                                                             const double *__restrict__ S1,
+                                                             const double *__restrict__ S2, float *__restrict__ An,
+                                                             float *__restrict__ dvec) {
+  __shared__ float Wj[C3][17], Wk[C3][17];
   __shared__ double u[C3], v[C3];
   const double invP = 1.0 / (double)P;
-  for (int c = threadIdx.x; c < C3; c += blockDim.x) {
+  const int tid = threadIdx.x, j0 = blockIdx.x * 16, k0 = blockIdx.y * 16;
+  for (int c = tid; c < C3; c += 256) {
     const double s = (double)scale3[c], m1 = S1[c] * invP, m2 = S2[c] * invP, rs = (double)rstd3[c];
     u[c] = s * m2 * rs;
     v[c] = u[c] * (double)mean3[c] - s * m1;
   }
+  for (int e = tid; e < C3 * 16; e += 256) {
+    const int c = e >> 4, t = e & 15;
+    Wj[c][t] = W3[(long)c * C2 + j0 + t];
+    Wk[c][t] = W3[(long)c * C2 + k0 + t];
+  }
   __syncthreads();
-  const int j = blockIdx.x, k = threadIdx.x;
+  const int tj = tid >> 4, tk = tid & 15;
   double a = 0.0, d = 0.0;
+#pragma unroll 8
   for (int c = 0; c < C3; ++c) {
-    const double wk = (double)W3[(long)c * C2 + k];
-    a += (double)W3[(long)c * C2 + j] * u[c] * wk;
+    const double wk = (double)Wk[c][tk];
+    a += (double)Wj[c][tj] * u[c] * wk;
     d += wk * v[c];
   }
-  An[(long)j * C2 + k] = (float)(-a);
-  if (j == 0) dvec[k] = (float)d;
+  An[(long)(j0 + tj) * C2 + k0 + tk] = (float)(-a);
+  if (blockIdx.x == 0 && tj == 0) dvec[k0 + tk] = (float)d;
 }
 
 // ------------------------------------------------------------------------------------------- O = H An + d, Gram
@@ -168,109 +180,159 @@ __global__ __launch_bounds__(kThreads) void sa_last_mfma_kernel(
 }
 
 // --------------------------------------------------------------------- sparse rows, gate, layer-2 sums, T and S
-// Same block decomposition.  LDS: the O tile and the H tile [64][C2 + 4], the block's (group, channel) records.  A wave
-// owns C3/4 channels: its W3 rows and its T accumulators live in registers (lane = column, C2/64 columns per lane); for
-// every non-zero (group, channel) it adds g s W3[c,:] to the arg-max row of the O tile (LDS float atomics: other waves
-// may hit the same row) and g H[row,:] to T[c,:].  Then the element-wise pass: gate by H > 0, the two BatchNorm sums of
-// layer 2 and the column sums of H per thread, the gated gradient to memory.  Partials leave per workgroup.
-template <int C2, int C3>
-__global__ __launch_bounds__(kThreads) void sa_last_sparse_kernel(
+// Same block decomposition, NW waves per workgroup.  LDS: the O tile and the RAW Z2 tile [64][C2 + 4].  A wave owns
+// C3/NW channels: its W3 rows and its T accumulators live in registers (lane = column, C2/64 columns per lane).  The
+// (group, channel) records -- pooled gradient where the pooled activation is > 0, arg-max row -- are loaded one per LANE
+// (lane ci = the wave's channel ci) and broadcast with v_readlane: the loop over the wave's channels is branch-free
+// straight-line code, so its LDS operations (one float atomic into the arg-max row of the O tile -- other waves may
+// hit the same row -- and one read of that row's activation for T) are all in flight together.  Then the element-wise
+// pass: gate by H > 0, the two BatchNorm sums of layer 2 and the column sums of H per thread, the gated gradient to
+// memory.  The next block's rows and records are fetched while the current block is processed.
+template <int C2, int C3, int NW>
+__global__ __launch_bounds__(NW * 64) void sa_last_sparse_kernel(
     long P, long nblk, int ns, long G, float *__restrict__ O, const float *__restrict__ Z2,
     const float *__restrict__ sc2, const float *__restrict__ sh2, const float *__restrict__ mean2,
     const float *__restrict__ rstd2, const float *__restrict__ W3, const float *__restrict__ d_out,
     const float *__restrict__ zsel, const uint8_t *__restrict__ asel, const float *__restrict__ sc3,
-    const float *__restrict__ sh3, float *__restrict__ ws, long ws_stride) {
+    const float *__restrict__ sh3, float *__restrict__ ws, long ws_stride, int abl) {
+  constexpr int NT = NW * 64;
   constexpr int ST = C2 + 4;
-  constexpr int CPW = C3 / 4;
+  constexpr int CPW = C3 / NW;       // channels per wave (<= 64: one record per lane)
   constexpr int KL = C2 / 64;
   constexpr int QN = C2 / 4;
-  constexpr int RP = kThreads / QN;
+  constexpr int RP = NT / QN;
   constexpr int NP = kRows / RP;
+  static_assert(CPW <= 64 && kRows % RP == 0, "decomposition");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Os = lds;                   // [64][ST]
-  float *Hs = Os + kRows * ST;       // [64][ST]
-  float *g_sh = Hs + kRows * ST;     // [4][C3] pooled gradient where the pooled activation is > 0, else 0
-  int *row_sh = reinterpret_cast<int *>(g_sh + 4 * C3);   // [4][C3] arg-max row inside the block
+  float *Zs = Os + kRows * ST;       // [64][ST]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int q = tid % QN, rsub = tid / QN;
-  const int nc = kRows / ns;         // groups per block
-  float w3r[CPW][KL], tacc[CPW][KL], s3r[CPW];
+  const int nc = kRows / ns;         // groups per block (1, 2 or 4)
+  const int myc = wave * CPW + (lane % CPW);
+  float w3r[CPW][KL], tacc[CPW][KL];
 #pragma unroll
   for (int ci = 0; ci < CPW; ++ci) {
     const int c = wave * CPW + ci;
-    s3r[ci] = sc3[c];
+    const float s3 = sc3[c];
 #pragma unroll
     for (int kk = 0; kk < KL; ++kk) {
-      w3r[ci][kk] = W3[(long)c * C2 + lane + 64 * kk];
+      w3r[ci][kk] = s3 * W3[(long)c * C2 + lane + 64 * kk];      // s W3[c,:]
       tacc[ci][kk] = 0.f;
     }
   }
+  float sck[KL], shk[KL];
+#pragma unroll
+  for (int kk = 0; kk < KL; ++kk) {
+    sck[kk] = sc2[lane + 64 * kk];
+    shk[kk] = sh2[lane + 64 * kk];
+  }
+  const float my_sc3 = sc3[myc], my_sh3 = sh3[myc];
   const f4 sc = *reinterpret_cast<const f4 *>(sc2 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh2 + 4 * q);
   const f4 mu = *reinterpret_cast<const f4 *>(mean2 + 4 * q), rs = *reinterpret_cast<const f4 *>(rstd2 + 4 * q);
   f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, scol = {0.f, 0.f, 0.f, 0.f};
-  for (long blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-    f4 zk[NP];
+  f4 zn[NP], on[NP];
+  float rec_g[4];
+  int rec_row[4];
+  auto fetch = [&](long b) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long p = b * kRows + rsub + ps * RP;
+      const bool in = p < P;
+      zn[ps] = in ? *reinterpret_cast<const f4 *>(Z2 + p * C2 + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+      on[ps] = in ? *reinterpret_cast<const f4 *>(O + p * C2 + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const long g = b * nc + gi;
+      float gv = 0.f;
+      int row = 0;
+      if (gi < nc && g < G) {
+        const float z = zsel[g * C3 + myc];
+        const float dy = d_out[g * C3 + myc];
+        row = gi * ns + (int)asel[g * C3 + myc];
+        gv = my_sc3 * z + my_sh3 > 0.f ? dy : 0.f;
+      }
+      rec_g[gi] = gv;
+      rec_row[gi] = row;
+    }
+  };
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = rsub + ps * RP;
-      const long p = blk * kRows + r;
-      f4 h = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
-      zk[ps] = f4{0.f, 0.f, 0.f, 0.f};
-      if (p < P) {
-        zk[ps] = *reinterpret_cast<const f4 *>(Z2 + p * C2 + 4 * q);
-        o = *reinterpret_cast<const f4 *>(O + p * C2 + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) h[e] = fmaxf(sc[e] * zk[ps][e] + sh[e], 0.f);
-      }
-      *reinterpret_cast<f4 *>(Hs + r * ST + 4 * q) = h;
-      *reinterpret_cast<f4 *>(Os + r * ST + 4 * q) = o;
+      *reinterpret_cast<f4 *>(Zs + r * ST + 4 * q) = zn[ps];
+      *reinterpret_cast<f4 *>(Os + r * ST + 4 * q) = on[ps];
     }
-    for (int e = tid; e < nc * C3; e += kThreads) {
-      const int gi = e / C3, c = e - gi * C3;
-      const long g = blk * nc + gi;
-      float gv = 0.f;
-      int row = 0;
-      if (g < G) {
-        const float z = zsel[g * C3 + c];
-        if (sc3[c] * z + sh3[c] > 0.f) gv = d_out[g * C3 + c];
-        row = gi * ns + (int)asel[g * C3 + c];
-      }
-      g_sh[e] = gv;
-      row_sh[e] = row;
+    float cg[4];
+    int cr[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      cg[gi] = rec_g[gi];
+      cr[gi] = rec_row[gi];
     }
     __syncthreads();
-    for (int gi = 0; gi < nc; ++gi) {
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);          // in flight under the work below
+    // ---- T[c,:] += g H[arg-max row,:]   (reads only; branch-free)
 #pragma unroll
-      for (int ci = 0; ci < CPW; ++ci) {
-        const int c = wave * CPW + ci;
-        const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g_sh[gi * C3 + c])));
-        if (gv != 0.f) {
-          const int row = __builtin_amdgcn_readfirstlane(row_sh[gi * C3 + c]);
-          const float gs = gv * s3r[ci];
+    for (int gi = 0; gi < 4; ++gi) {
+      if (gi < nc && !(abl & 2)) {
 #pragma unroll
-          for (int kk = 0; kk < KL; ++kk) {
-            const int k = lane + 64 * kk;
-            atomicAdd(Os + row * ST + k, gs * w3r[ci][kk]);
-            tacc[ci][kk] += gv * Hs[row * ST + k];
-          }
+        for (int ci = 0; ci < CPW; ++ci) {
+          const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cg[gi]), ci));
+          const int ro = __builtin_amdgcn_readlane(cr[gi], ci) * ST;
+#pragma unroll
+          for (int kk = 0; kk < KL; ++kk)
+            tacc[ci][kk] += gv * fmaxf(sck[kk] * Zs[ro + lane + 64 * kk] + shk[kk], 0.f);
         }
       }
     }
-    __syncthreads();
+    // ---- O[arg-max row,:] += g s W3[c,:].  Waves own channels, so two waves may target the same row; LDS float
+    // atomics serialise per lane on this part (measured: 0.55 ms of the 0.94 ms this kernel took at SA1 with them).
+    // Instead the rows are cut into NW slots and the update runs in NW phases: in phase p wave w applies its records
+    // whose row lies in slot (w + p) mod NW -- disjoint rows per wave within a phase, plain read-add-write, and the
+    // LDS queue of a wave is in order, so two of its records on one row are applied one after the other.
+    for (int ph = 0; ph < NW && !(abl & 1); ++ph) {
+      const int slot = (wave + ph) % NW;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        if (gi < nc) {
+          const unsigned long long m = __ballot((cr[gi] & 63) / (kRows / NW) == slot && cg[gi] != 0.f);
+          if (m != 0ull) {
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci) {
+              if ((m >> ci) & 1ull) {
+                const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cg[gi]), ci));
+                const int ro = __builtin_amdgcn_readlane(cr[gi], ci) * ST;
+#pragma unroll
+                for (int kk = 0; kk < KL; ++kk) {
+                  float *a = Os + ro + lane + 64 * kk;
+                  *a = *a + gv * w3r[ci][kk];
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = rsub + ps * RP;
       const long p = blk * kRows + r;
-      if (p < P) {
+      if (p < P && !(abl & 8)) {
         const f4 o = *reinterpret_cast<const f4 *>(Os + r * ST + 4 * q);
-        const f4 h = *reinterpret_cast<const f4 *>(Hs + r * ST + 4 * q);
+        const f4 z = *reinterpret_cast<const f4 *>(Zs + r * ST + 4 * q);
         f4 g2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          g2[e] = h[e] > 0.f ? o[e] : 0.f;
+          const float h = fmaxf(sc[e] * z[e] + sh[e], 0.f);
+          g2[e] = h > 0.f ? o[e] : 0.f;
           s1[e] += g2[e];
-          s2[e] += g2[e] * (zk[ps][e] - mu[e]) * rs[e];
-          scol[e] += h[e];
+          s2[e] += g2[e] * (z[e] - mu[e]) * rs[e];
+          scol[e] += h;
         }
         *reinterpret_cast<f4 *>(O + p * C2 + 4 * q) = g2;
       }
@@ -292,7 +354,7 @@ __global__ __launch_bounds__(kThreads) void sa_last_sparse_kernel(
     red[(2 * RP + rsub) * C2 + 4 * q + e] = scol[e];
   }
   __syncthreads();
-  for (int e = tid; e < 3 * C2; e += kThreads) {
+  for (int e = tid; e < 3 * C2; e += NT) {
     const int which = e / C2, col = e - which * C2;
     float a = 0.f;
     for (int t = 0; t < RP; ++t) a += red[(which * RP + t) * C2 + col];
@@ -301,19 +363,39 @@ __global__ __launch_bounds__(kThreads) void sa_last_sparse_kernel(
 }
 
 // ----------------------------------------------------------------------------------------------- partials -> totals
-// tot[n] = sum over parts of part[w][n] (double), for two groups of partials laid one after the other in tot
-__global__ void sa_last_reduce_kernel(const float *__restrict__ p1, long n1, int parts1, const float *__restrict__ p2,
-                                      long n2, int parts2, double *__restrict__ tot) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// tot[n] = sum over parts of part[w][n] (double), for two groups of partials laid one after the other in tot.  A block
+// = 16 elements x 16 part-lanes: a thread sums every 16th partial, the 16 sums fold in LDS in a fixed order.
+__global__ __launch_bounds__(256) void sa_last_reduce_kernel(const float *__restrict__ p1, long n1, int parts1,
+                                                             const float *__restrict__ p2, long n2, int parts2,
+                                                             double *__restrict__ tot) {
+  __shared__ double red[16][17];
+  const long i = (long)blockIdx.x * 16 + (threadIdx.x & 15);
+  const int pl = threadIdx.x >> 4;
+  const float *src = nullptr;
+  long n = 0, j = 0;
+  int parts = 0;
   if (i < n1) {
-    double a = 0.0;
-    for (int w = 0; w < parts1; ++w) a += (double)p1[(long)w * n1 + i];
-    tot[i] = a;
+    src = p1; n = n1; j = i; parts = parts1;
   } else if (i < n1 + n2) {
-    const long j = i - n1;
-    double a = 0.0;
-    for (int w = 0; w < parts2; ++w) a += (double)p2[(long)w * n2 + j];
-    tot[i] = a;
+    src = p2; n = n2; j = i - n1; parts = parts2;
+  }
+  double a = 0.0;
+  if (src) {
+    int w = pl;
+    for (; w + 48 < parts; w += 64) {
+      const float v0 = src[(long)w * n + j], v1 = src[(long)(w + 16) * n + j], v2 = src[(long)(w + 32) * n + j],
+                  v3 = src[(long)(w + 48) * n + j];
+      a += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+    }
+    for (; w < parts; w += 16) a += (double)src[(long)w * n + j];
+  }
+  red[pl][threadIdx.x & 15] = a;
+  __syncthreads();
+  if (threadIdx.x < 16 && src) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += red[k][threadIdx.x];
+    tot[i] = t;
   }
 }
 
@@ -329,6 +411,7 @@ __global__ void sa_last_dw_kernel(int C2, int C3, long P, const float *__restric
   const double *gram = tot, *T = tot + (long)C2 * C2, *s1 = T + (long)C3 * C2, *s2 = s1 + C2, *S = s2 + C2;
   const double invP = 1.0 / (double)P;
   double wg = 0.0, ws = 0.0;
+#pragma unroll 16
   for (int j = 0; j < C2; ++j) {
     const double w = (double)W3[(long)c * C2 + j];
     wg += w * gram[(long)j * C2 + k];
@@ -344,25 +427,28 @@ __global__ void sa_last_dw_kernel(int C2, int C3, long P, const float *__restric
 }
 
 template <int C2, int C3>
-constexpr size_t sparse_lds() { return (size_t)(2 * kRows * (C2 + 4) + 8 * C3) * sizeof(float); }
+constexpr size_t sparse_lds() { return (size_t)(2 * kRows * (C2 + 4)) * sizeof(float); }
 
 hipError_t sparse_attr() {
   static hipError_t err = []() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<64, 128>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<64, 128, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<128, 256>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<128, 256, 8>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }();
   return err;
 }
 
+int g_abl = 0;
 int grid_mfma(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 768 : 512) ? nblk : (C2 == 64 ? 768 : 512)); }
 int grid_sparse(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 512 : 256) ? nblk : (C2 == 64 ? 512 : 256)); }
 
 }  // namespace
 
 extern "C" {
+
+int butd_sa_last_bwd_set_ablation(int a) { g_abl = a; return 0; }   /* tuning hook (timing experiments only) */
 
 int butd_sa_last_bwd_supported(int ns, int C2, int C3) {
   return (ns == 16 || ns == 32 || ns == 64) && ((C2 == 64 && C3 == 128) || (C2 == 128 && C3 == 256));
@@ -393,20 +479,20 @@ int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, con
   const long per_sparse = (long)C3 * C2 + 3 * C2;
   float *An = ws_f, *dvec = An + (long)C2 * C2, *ws_gram = dvec + C2, *ws_sparse = ws_gram + (long)gm * C2 * C2;
   if (C3 == 128)
-    hipLaunchKernelGGL(sa_last_coeffs_kernel<128>, dim3(C2), dim3(C2), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
+    hipLaunchKernelGGL(sa_last_coeffs_kernel<128>, dim3(C2 / 16, C2 / 16), dim3(256), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
   else
-    hipLaunchKernelGGL(sa_last_coeffs_kernel<256>, dim3(C2), dim3(C2), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
+    hipLaunchKernelGGL(sa_last_coeffs_kernel<256>, dim3(C2 / 16, C2 / 16), dim3(256), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
   if (C2 == 64) {
     hipLaunchKernelGGL(sa_last_mfma_kernel<64>, dim3(gm), dim3(kThreads), 0, st, P, nblk, Z2, scale2, shift2, An, dvec, dH2, ws_gram);
-    hipLaunchKernelGGL((sa_last_sparse_kernel<64, 128>), dim3(gs), dim3(kThreads), (sparse_lds<64, 128>()), st, P, nblk, ns, G, dH2, Z2, scale2,
-                       shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse);
+    hipLaunchKernelGGL((sa_last_sparse_kernel<64, 128, 4>), dim3(gs), dim3(256), (sparse_lds<64, 128>()), st, P, nblk, ns, G, dH2, Z2, scale2,
+                       shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse, g_abl);
   } else {
     hipLaunchKernelGGL(sa_last_mfma_kernel<128>, dim3(gm), dim3(kThreads), 0, st, P, nblk, Z2, scale2, shift2, An, dvec, dH2, ws_gram);
-    hipLaunchKernelGGL((sa_last_sparse_kernel<128, 256>), dim3(gs), dim3(kThreads), (sparse_lds<128, 256>()), st, P, nblk, ns, G, dH2, Z2, scale2,
-                       shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse);
+    hipLaunchKernelGGL((sa_last_sparse_kernel<128, 256, 8>), dim3(gs), dim3(512), (sparse_lds<128, 256>()), st, P, nblk, ns, G, dH2, Z2, scale2,
+                       shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse, g_abl);
   }
   const long n1 = (long)C2 * C2, n2 = per_sparse;
-  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((n1 + n2 + 255) / 256)), dim3(256), 0, st, ws_gram, n1, gm,
+  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((n1 + n2 + 15) / 16)), dim3(256), 0, st, ws_gram, n1, gm,
                      ws_sparse, n2, gs, ws_d);
   hipLaunchKernelGGL(sa_last_dw_kernel, dim3(C3), dim3(C2), 0, st, C2, C3, P, W3, scale3, rstd3, S1_3, S2_3, ws_d, dW3,
                      S1_2, S2_2);
