@@ -362,6 +362,223 @@ __global__ __launch_bounds__(NW * 64) void sa_last_sparse_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------ the fused pass
+// Both kernels above in ONE pass over Z2 (read once, 268 MB at SA1; the gated gradient written once): per 64-row block
+//   H tile -> LDS;  O = H An + d (matrix cores) -> LDS O tile;  Gram += H^T H (matrix cores);  T += g H[arg-max rows];
+//   O rows += g s W3 (row-slot phases);  gate, layer-2 sums, column sums, store.
+// NW waves: wave w owns 16 output columns of O, 16 rows of Gram (C2 = 16 NW) and C3 / NW channels of W3 / T.
+template <int C2, int C3, int NW>
+__global__ __launch_bounds__(NW * 64) void sa_last_fused_kernel(
+    long P, long nblk, int ns, long G, float *__restrict__ O, const float *__restrict__ Z2,
+    const float *__restrict__ sc2, const float *__restrict__ sh2, const float *__restrict__ mean2,
+    const float *__restrict__ rstd2, const float *__restrict__ W3, const float *__restrict__ An,
+    const float *__restrict__ dvec, const float *__restrict__ d_out, const float *__restrict__ zsel,
+    const uint8_t *__restrict__ asel, const float *__restrict__ sc3, const float *__restrict__ sh3,
+    float *__restrict__ ws_gram, float *__restrict__ ws, long ws_stride) {
+  static_assert(C2 == 16 * NW, "a wave owns 16 columns");
+  constexpr int NT = NW * 64;
+  constexpr int ST = C2 + 36;        // H tile (matrix operand reads, see sa_last_mfma_kernel)
+  constexpr int SO = C2 + 4;         // O tile
+  constexpr int KG = C2 / 16;
+  constexpr int GN = C2 / 16;
+  constexpr int CPW = C3 / NW;
+  constexpr int KL = C2 / 64;
+  constexpr int QN = C2 / 4;
+  constexpr int RP = NT / QN;
+  constexpr int NP = kRows / RP;
+  static_assert(CPW <= 64 && kRows % RP == 0, "decomposition");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Ht = lds;                   // [64][ST]
+  float *Os = Ht + kRows * ST;       // [64][SO]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
+  const int q = tid % QN, rsub = tid / QN;
+  const int n0 = wave * 16;
+  const int nc = kRows / ns;
+  const int myc = wave * CPW + (lane % CPW);
+  f4 areg[KG];
+#pragma unroll
+  for (int g = 0; g < KG; ++g) areg[g] = *reinterpret_cast<const f4 *>(An + (long)(n0 + lm) * C2 + 16 * g + 4 * lq);
+  const f4 dinit = *reinterpret_cast<const f4 *>(dvec + n0 + 4 * lq);
+  f4 gacc[GN];
+#pragma unroll
+  for (int n = 0; n < GN; ++n) gacc[n] = f4{0.f, 0.f, 0.f, 0.f};
+  float w3r[CPW][KL], tacc[CPW][KL];
+#pragma unroll
+  for (int ci = 0; ci < CPW; ++ci) {
+    const int c = wave * CPW + ci;
+    const float s3 = sc3[c];
+#pragma unroll
+    for (int kk = 0; kk < KL; ++kk) {
+      w3r[ci][kk] = s3 * W3[(long)c * C2 + lane + 64 * kk];
+      tacc[ci][kk] = 0.f;
+    }
+  }
+  const float my_sc3 = sc3[myc], my_sh3 = sh3[myc];
+  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, scol = {0.f, 0.f, 0.f, 0.f};
+  f4 zn[NP];
+  float rec_g[4];
+  int rec_row[4];
+  auto fetch = [&](long b) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long p = b * kRows + rsub + ps * RP;
+      zn[ps] = p < P ? *reinterpret_cast<const f4 *>(Z2 + p * C2 + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      const long g = b * nc + gi;
+      float gv = 0.f;
+      int row = 0;
+      if (gi < nc && g < G) {
+        const float z = zsel[g * C3 + myc];
+        const float dy = d_out[g * C3 + myc];
+        row = gi * ns + (int)asel[g * C3 + myc];
+        gv = my_sc3 * z + my_sh3 > 0.f ? dy : 0.f;
+      }
+      rec_g[gi] = gv;
+      rec_row[gi] = row;
+    }
+  };
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+    f4 zk[NP];
+    {
+      const f4 sc = *reinterpret_cast<const f4 *>(sc2 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh2 + 4 * q);
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int r = rsub + ps * RP;
+        const bool in = blk * kRows + r < P;
+        zk[ps] = zn[ps];
+        f4 h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = in ? fmaxf(sc[e] * zn[ps][e] + sh[e], 0.f) : 0.f;
+        *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+      }
+    }
+    float cg[4];
+    int cr[4];
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      cg[gi] = rec_g[gi];
+      cr[gi] = rec_row[gi];
+    }
+    __syncthreads();
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);          // in flight under the work below
+    // ---- O^T tiles (16 columns of this wave x 16 rows) -> LDS
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f4 oacc = dinit;
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const f4 hv = *reinterpret_cast<const f4 *>(Ht + (16 * rt + lm) * ST + 16 * g + 4 * lq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc = mfma4(areg[g][i], hv[i], oacc);
+      }
+      *reinterpret_cast<f4 *>(Os + (16 * rt + lm) * SO + n0 + 4 * lq) = oacc;
+    }
+    // ---- Gram rows of this wave
+#pragma unroll 4
+    for (int s = 0; s < kRows / 4; ++s) {
+      const float *hrow = Ht + (4 * s + lq) * ST + lm;
+      const float a = hrow[n0];
+      float b[GN];
+#pragma unroll
+      for (int n = 0; n < GN; ++n) b[n] = hrow[16 * n];
+#pragma unroll
+      for (int n = 0; n < GN; ++n) gacc[n] = mfma4(a, b[n], gacc[n]);
+    }
+    // ---- T[c,:] += g H[arg-max row,:]
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) {
+      if (gi < nc) {
+#pragma unroll
+        for (int ci = 0; ci < CPW; ++ci) {
+          const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cg[gi]), ci));
+          const int ro = __builtin_amdgcn_readlane(cr[gi], ci) * ST;
+#pragma unroll
+          for (int kk = 0; kk < KL; ++kk) tacc[ci][kk] += gv * Ht[ro + lane + 64 * kk];
+        }
+      }
+    }
+    __syncthreads();                                             // the O tile is complete
+    // ---- O[arg-max row,:] += g s W3[c,:] in NW row-slot phases (see sa_last_sparse_kernel)
+    for (int ph = 0; ph < NW; ++ph) {
+      const int slot = (wave + ph) % NW;
+#pragma unroll
+      for (int gi = 0; gi < 4; ++gi) {
+        if (gi < nc) {
+          const unsigned long long m = __ballot((cr[gi] & 63) / (kRows / NW) == slot && cg[gi] != 0.f);
+          if (m != 0ull) {
+#pragma unroll
+            for (int ci = 0; ci < CPW; ++ci) {
+              if ((m >> ci) & 1ull) {
+                const float gv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cg[gi]), ci));
+                const int ro = __builtin_amdgcn_readlane(cr[gi], ci) * SO;
+#pragma unroll
+                for (int kk = 0; kk < KL; ++kk) {
+                  float *a = Os + ro + lane + 64 * kk;
+                  *a = *a + gv * w3r[ci][kk];
+                }
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    // ---- gate, layer-2 sums, column sums of H, store
+    {
+      const f4 mu = *reinterpret_cast<const f4 *>(mean2 + 4 * q), rs = *reinterpret_cast<const f4 *>(rstd2 + 4 * q);
+#pragma unroll
+      for (int ps = 0; ps < NP; ++ps) {
+        const int r = rsub + ps * RP;
+        const long p = blk * kRows + r;
+        if (p < P) {
+          const f4 o = *reinterpret_cast<const f4 *>(Os + r * SO + 4 * q);
+          const f4 h = *reinterpret_cast<const f4 *>(Ht + r * ST + 4 * q);
+          f4 g2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            g2[e] = h[e] > 0.f ? o[e] : 0.f;
+            s1[e] += g2[e];
+            s2[e] += g2[e] * (zk[ps][e] - mu[e]) * rs[e];
+            scol[e] += h[e];
+          }
+          *reinterpret_cast<f4 *>(O + p * C2 + 4 * q) = g2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partials of this workgroup
+  float *og = ws_gram + (long)blockIdx.x * C2 * C2;
+#pragma unroll
+  for (int n = 0; n < GN; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) og[(long)(n0 + 4 * lq + i) * C2 + 16 * n + lm] = gacc[n][i];
+  float *out = ws + (long)blockIdx.x * ws_stride;
+#pragma unroll
+  for (int ci = 0; ci < CPW; ++ci)
+#pragma unroll
+    for (int kk = 0; kk < KL; ++kk) out[(long)(wave * CPW + ci) * C2 + lane + 64 * kk] = tacc[ci][kk];
+  float *red = Os;    // [3][RP][C2]
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[(0 * RP + rsub) * C2 + 4 * q + e] = s1[e];
+    red[(1 * RP + rsub) * C2 + 4 * q + e] = s2[e];
+    red[(2 * RP + rsub) * C2 + 4 * q + e] = scol[e];
+  }
+  __syncthreads();
+  for (int e = tid; e < 3 * C2; e += NT) {
+    const int which = e / C2, col = e - which * C2;
+    float a = 0.f;
+    for (int t = 0; t < RP; ++t) a += red[(which * RP + t) * C2 + col];
+    out[(long)C3 * C2 + e] = a;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------- partials -> totals
 // tot[n] = sum over parts of part[w][n] (double), for two groups of partials laid one after the other in tot.  A block
 // = 16 elements x 16 part-lanes: a thread sums every 16th partial, the 16 sums fold in LDS in a fixed order.
@@ -426,6 +643,9 @@ __global__ void sa_last_dw_kernel(int C2, int C3, long P, const float *__restric
   }
 }
 
+template <int C2>
+constexpr size_t fused_lds() { return (size_t)(kRows * (C2 + 36) + kRows * (C2 + 4)) * sizeof(float); }
+
 template <int C2, int C3>
 constexpr size_t sparse_lds() { return (size_t)(2 * kRows * (C2 + 4)) * sizeof(float); }
 
@@ -434,7 +654,13 @@ hipError_t sparse_attr() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<64, 128, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<128, 256, 8>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<128, 256, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_fused_kernel<64, 128, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_fused_kernel<128, 256, 8>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }();
   return err;
@@ -477,12 +703,23 @@ int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, con
   const long nblk = (P + kRows - 1) / kRows;
   const int gm = grid_mfma(C2, nblk), gs = grid_sparse(C2, nblk);
   const long per_sparse = (long)C3 * C2 + 3 * C2;
-  float *An = ws_f, *dvec = An + (long)C2 * C2, *ws_gram = dvec + C2, *ws_sparse = ws_gram + (long)gm * C2 * C2;
+  float *An = ws_f, *dvec = An + (long)C2 * C2, *ws_gram = dvec + C2, *ws_sparse = ws_gram + (long)gm * C2 * C2;   // (gm >= gs)
   if (C3 == 128)
     hipLaunchKernelGGL(sa_last_coeffs_kernel<128>, dim3(C2 / 16, C2 / 16), dim3(256), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
   else
     hipLaunchKernelGGL(sa_last_coeffs_kernel<256>, dim3(C2 / 16, C2 / 16), dim3(256), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
-  if (C2 == 64) {
+  const bool fused = !(g_abl & 16) && (C2 == 64 || (g_abl & 32));
+  if (fused) {     // one pass; both partial groups use the sparse grid
+    ws_sparse = ws_gram + (long)gs * C2 * C2;
+    if (C2 == 64)
+      hipLaunchKernelGGL((sa_last_fused_kernel<64, 128, 4>), dim3(gs), dim3(256), (fused_lds<64>()), st, P, nblk, ns, G, dH2,
+                         Z2, scale2, shift2, mean2, rstd2, W3, An, dvec, d_out_pm, zsel, asel, scale3, shift3, ws_gram,
+                         ws_sparse, per_sparse);
+    else
+      hipLaunchKernelGGL((sa_last_fused_kernel<128, 256, 8>), dim3(gs), dim3(512), (fused_lds<128>()), st, P, nblk, ns, G,
+                         dH2, Z2, scale2, shift2, mean2, rstd2, W3, An, dvec, d_out_pm, zsel, asel, scale3, shift3,
+                         ws_gram, ws_sparse, per_sparse);
+  } else if (C2 == 64) {
     hipLaunchKernelGGL(sa_last_mfma_kernel<64>, dim3(gm), dim3(kThreads), 0, st, P, nblk, Z2, scale2, shift2, An, dvec, dH2, ws_gram);
     hipLaunchKernelGGL((sa_last_sparse_kernel<64, 128, 4>), dim3(gs), dim3(256), (sparse_lds<64, 128>()), st, P, nblk, ns, G, dH2, Z2, scale2,
                        shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse, g_abl);
@@ -492,7 +729,7 @@ int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, con
                        shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse, g_abl);
   }
   const long n1 = (long)C2 * C2, n2 = per_sparse;
-  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((n1 + n2 + 15) / 16)), dim3(256), 0, st, ws_gram, n1, gm,
+  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((n1 + n2 + 15) / 16)), dim3(256), 0, st, ws_gram, n1, fused ? gs : gm,
                      ws_sparse, n2, gs, ws_d);
   hipLaunchKernelGGL(sa_last_dw_kernel, dim3(C3), dim3(C2), 0, st, C2, C3, P, W3, scale3, rstd3, S1_3, S2_3, ws_d, dW3,
                      S1_2, S2_2);

@@ -49,4 +49,4 @@ def bench(B, np_, ns, C2, C3, abl):
 
 
 for name, cfg in (("SA1", (8, 2048, 64, 64, 128)), ("SA2", (8, 1024, 32, 128, 256)), ("SA3", (8, 512, 16, 128, 256))):
-    print(name, "  ".join(f"abl={a}: {bench(*cfg, a):7.1f} us" for a in (0, 1, 2, 3, 4, 8, 12, 15)))
+    print(name, "  ".join(f"abl={a}: {bench(*cfg, a):7.1f} us" for a in (0, 16, 32)))
