@@ -22,6 +22,7 @@
 //   sa_last_reduce_kernel   partials -> double totals (deterministic: no atomics anywhere on this path)
 //   sa_last_dw_kernel       dW3 and the layer-2 sums
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include "../../include/butd_sa.h"
@@ -35,6 +36,108 @@ constexpr int kRows = 64;   // rows per block of the two streaming kernels (a mu
 
 __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// --------------------------------------------------------------------------------- forward of the last layer + pool
+// When the backward above is in use nothing reads Z3 = H2 W3^T after the pooling, so the forward need not write it:
+// per 64-row block  H tile -> LDS;  Z3 tile (64 x C3) on the matrix cores -> LDS;  then one thread per channel walks the
+// tile's rows: BatchNorm sums (double accumulators per thread for the whole kernel) and, per group of ns rows, max / min
+// and their FIRST positions (strict compares in row order: butd_sa_colstats' rule).  Replaces the layer's product
+// launch + butd_sa_colstats: reads Z2 once, writes 10 bytes per (group, channel).
+template <int C2, int C3, int NW>
+__global__ __launch_bounds__(NW * 64) void sa_last_fwd_kernel(
+    long P, long nblk, int ns, long G, const float *__restrict__ Z2, const float *__restrict__ sc2,
+    const float *__restrict__ sh2, const float *__restrict__ W3, double *__restrict__ sum,
+    double *__restrict__ sumsq, float *__restrict__ zmax, float *__restrict__ zmin, uint8_t *__restrict__ amax,
+    uint8_t *__restrict__ amin) {
+  constexpr int NT = NW * 64;
+  constexpr int ST = C2 + 36;
+  constexpr int SZ = C3 + 4;
+  constexpr int NTO = C3 / (16 * NW);    // 16-column output tiles per wave
+  constexpr int KG = C2 / 16;
+  constexpr int QN = C2 / 4;
+  constexpr int RP = NT / QN;
+  constexpr int NP = kRows / RP;
+  static_assert(C3 % (16 * NW) == 0 && C3 <= NT && kRows % RP == 0, "decomposition");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Ht = lds;                   // [64][ST]
+  float *Zt = Ht + kRows * ST;       // [64][SZ]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
+  const int q = tid % QN, rsub = tid / QN;
+  const int n0 = wave * (C3 / NW);
+  const int nc = kRows / ns;
+  f4 areg[NTO][KG];
+#pragma unroll
+  for (int t = 0; t < NTO; ++t)
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+      areg[t][g] = *reinterpret_cast<const f4 *>(W3 + (long)(n0 + 16 * t + lm) * C2 + 16 * g + 4 * lq);
+  const f4 sc = *reinterpret_cast<const f4 *>(sc2 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh2 + 4 * q);
+  double dsum = 0.0, dsq = 0.0;
+  f4 zn[NP];
+  auto fetch = [&](long b) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long p = b * kRows + rsub + ps * RP;
+      zn[ps] = p < P ? *reinterpret_cast<const f4 *>(Z2 + p * C2 + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      f4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = fmaxf(sc[e] * zn[ps][e] + sh[e], 0.f);
+      *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+    }
+    __syncthreads();
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f4 oacc[NTO];
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) oacc[t] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const f4 hv = *reinterpret_cast<const f4 *>(Ht + (16 * rt + lm) * ST + 16 * g + 4 * lq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int t = 0; t < NTO; ++t) oacc[t] = mfma4(areg[t][g][i], hv[i], oacc[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < NTO; ++t) *reinterpret_cast<f4 *>(Zt + (16 * rt + lm) * SZ + n0 + 16 * t + 4 * lq) = oacc[t];
+    }
+    __syncthreads();
+    if (tid < C3) {
+      for (int gi = 0; gi < nc; ++gi) {
+        const long g = blk * nc + gi;
+        if (g >= G) break;
+        const float *col = Zt + (gi * ns) * SZ + tid;
+        float mx = -INFINITY, mn = INFINITY;
+        int ax = 0, an = 0;
+        for (int k = 0; k < ns; ++k) {
+          const float v = col[k * SZ];
+          dsum += (double)v;
+          dsq += (double)v * (double)v;
+          if (v > mx) { mx = v; ax = k; }
+          if (v < mn) { mn = v; an = k; }
+        }
+        zmax[g * C3 + tid] = mx;
+        zmin[g * C3 + tid] = mn;
+        amax[g * C3 + tid] = (uint8_t)ax;
+        amin[g * C3 + tid] = (uint8_t)an;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid < C3) {
+    atomicAdd(sum + tid, dsum);
+    atomicAdd(sumsq + tid, dsq);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ coefficients
@@ -657,6 +760,12 @@ hipError_t sparse_attr() {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_sparse_kernel<128, 256, 8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_fwd_kernel<64, 128, 4>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_fwd_kernel<128, 256, 8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_fused_kernel<64, 128, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -667,6 +776,9 @@ hipError_t sparse_attr() {
 }
 
 int g_abl = 0;
+template <int C2, int C3>
+constexpr size_t fwd_lds() { return (size_t)(kRows * (C2 + 36) + kRows * (C3 + 4)) * sizeof(float); }
+
 int grid_mfma(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 768 : 512) ? nblk : (C2 == 64 ? 768 : 512)); }
 int grid_sparse(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 512 : 256) ? nblk : (C2 == 64 ? 512 : 256)); }
 
@@ -678,6 +790,27 @@ int butd_sa_last_bwd_set_ablation(int a) { g_abl = a; return 0; }   /* tuning ho
 
 int butd_sa_last_bwd_supported(int ns, int C2, int C3) {
   return (ns == 16 || ns == 32 || ns == 64) && ((C2 == 64 && C3 == 128) || (C2 == 128 && C3 == 256));
+}
+
+int butd_sa_last_fwd(int B, int np, int ns, int C2, int C3, const float *Z2, const float *scale2,
+                     const float *shift2, const float *W3, double *sum, double *sumsq, float *zmax, float *zmin,
+                     uint8_t *amax, uint8_t *amin, butd_stream_t stream) {
+  const long G = (long)B * np, P = G * ns;
+  if (P <= 0) return 0;
+  if (!butd_sa_last_bwd_supported(ns, C2, C3)) return (int)hipErrorInvalidValue;
+  if (hipError_t e = sparse_attr(); e != hipSuccess) return (int)e;
+  hipStream_t st = (hipStream_t)stream;
+  const long nblk = (P + kRows - 1) / kRows;
+  if (C2 == 64) {
+    const int grid = (int)(nblk < 512 ? nblk : 512);
+    hipLaunchKernelGGL((sa_last_fwd_kernel<64, 128, 4>), dim3(grid), dim3(256), (fwd_lds<64, 128>()), st, P, nblk, ns, G, Z2,
+                       scale2, shift2, W3, sum, sumsq, zmax, zmin, amax, amin);
+  } else {
+    const int grid = (int)(nblk < 256 ? nblk : 256);
+    hipLaunchKernelGGL((sa_last_fwd_kernel<128, 256, 8>), dim3(grid), dim3(512), (fwd_lds<128, 256>()), st, P, nblk, ns, G, Z2,
+                       scale2, shift2, W3, sum, sumsq, zmax, zmin, amax, amin);
+  }
+  return (int)hipGetLastError();
 }
 
 int butd_sa_last_bwd_scratch(long P, int C2, int C3, long *ws_floats, long *ws_doubles) {

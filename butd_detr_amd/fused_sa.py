@@ -34,6 +34,7 @@ def _call(name, ref, *args):
 # half the matrix work, 3.25 -> 1.34 GB at SA1.  BUTD_SA_LAST_BWD=0 keeps the dense path (A/B switch, and the path of
 # widths / nsample the kernel has no instance for).
 _LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
+_LAST_FWD = [os.environ.get("BUTD_SA_LAST_FWD", "1") != "0"]      # ... and the forward that does not write Z3
 _scratch_sizes = {}
 
 
@@ -98,31 +99,39 @@ class _SAMlpPool(torch.autograd.Function):
         Zs, inp, prev_aff = [], X, None
         G = B * np_
         zmax = zmin = amax = amin = None
+        lin = _last_lin_ok(training, ns, C2, C3)    # the backward then never reads Z3: the forward does not write it
         for li, (Cl, w) in enumerate(zip((C1, C2, C3), ws)):
-            Z = torch.empty((P, Cl), device=dev)
             last = li == 2
-            # BatchNorm sums straight from the GEMM epilogue while the row count is moderate (every tile
-            # ends in 2 double atomics per column); the last layer's pass also takes the pooling extrema
-            # (limit measured in the step, round 4: up to 131 072 rows 25.62 ms, 262 144 rows 25.40, 1 048 576 rows 25.51)
-            in_gemm_stats = training and not last and P <= int(os.environ.get("BUTD_SA_INGEMM_MAX", "262144"))
-            thin = li == 0 and Kp == 8      # SA1: xyz + colour -> one HBM pass does the product AND the sums
-            if thin:
-                _call("butd_sa_thin_conv", xyz, P, Cl, Kp, X.data_ptr(), Kp, w.data_ptr(), Z.data_ptr(),
-                      stats[li, 0, 0].data_ptr() if training else None,
-                      stats[li, 0, 1].data_ptr() if training else None)
-                in_gemm_stats = training
-            else:
-                _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff,
-                            col_stats=(stats[li, 0, 0], stats[li, 0, 1]) if in_gemm_stats else None,
-                            col_slots=(SLOTS, 2 * Cm) if in_gemm_stats else (0, 0))], xyz)
             if last:
                 zmax = torch.empty((G, Cl), device=dev)
                 zmin = torch.empty((G, Cl), device=dev)
                 amax = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
                 amin = torch.empty((G, Cl), dtype=torch.uint8, device=dev)
-            if last or (training and not in_gemm_stats):
-                _call("butd_sa_colstats", xyz, P, Cl, Z.data_ptr(), stats[li, 0, 0].data_ptr(),
-                      stats[li, 0, 1].data_ptr(), ns if last else 0, _p(zmax), _p(zmin), _p(amax), _p(amin))
+            if last and lin and _LAST_FWD[0]:
+                # product + BatchNorm sums + pooling extrema in one pass over Z2 (include/butd_sa.h, butd_sa_last_fwd)
+                _call("butd_sa_last_fwd", xyz, B, np_, ns, C2, C3, inp.data_ptr(), prev_aff[0].data_ptr(),
+                      prev_aff[1].data_ptr(), w.data_ptr(), stats[li, 0, 0].data_ptr(), stats[li, 0, 1].data_ptr(),
+                      zmax.data_ptr(), zmin.data_ptr(), amax.data_ptr(), amin.data_ptr())
+                Z, in_gemm_stats = inp[:0], False
+            else:
+                Z = torch.empty((P, Cl), device=dev)
+                # BatchNorm sums straight from the GEMM epilogue while the row count is moderate (every tile
+                # ends in 2 double atomics per column); the last layer's pass also takes the pooling extrema
+                # (limit measured in the step, round 4: up to 131 072 rows 25.62 ms, 262 144 rows 25.40, 1 048 576 rows 25.51)
+                in_gemm_stats = training and not last and P <= int(os.environ.get("BUTD_SA_INGEMM_MAX", "262144"))
+                thin = li == 0 and Kp == 8      # SA1: xyz + colour -> one HBM pass does the product AND the sums
+                if thin:
+                    _call("butd_sa_thin_conv", xyz, P, Cl, Kp, X.data_ptr(), Kp, w.data_ptr(), Z.data_ptr(),
+                          stats[li, 0, 0].data_ptr() if training else None,
+                          stats[li, 0, 1].data_ptr() if training else None)
+                    in_gemm_stats = training
+                else:
+                    _gemm([_fwd(inp, w, Z, P, Cl, w.shape[1], a_affine=prev_aff,
+                                col_stats=(stats[li, 0, 0], stats[li, 0, 1]) if in_gemm_stats else None,
+                                col_slots=(SLOTS, 2 * Cm) if in_gemm_stats else (0, 0))], xyz)
+                if last or (training and not in_gemm_stats):
+                    _call("butd_sa_colstats", xyz, P, Cl, Z.data_ptr(), stats[li, 0, 0].data_ptr(),
+                          stats[li, 0, 1].data_ptr(), ns if last else 0, _p(zmax), _p(zmin), _p(amax), _p(amin))
             g, b, rm, rv, nbt, eps = layers[li]
             _call("butd_sa_bn_finalize", xyz, Cl, P, stats[li, 0, 0].data_ptr(), stats[li, 0, 1].data_ptr(),
                   SLOTS if in_gemm_stats else 1, 2 * Cm, g.data_ptr(), b.data_ptr(), float(eps), float(momentum), int(training), rm.data_ptr(),
@@ -138,8 +147,7 @@ class _SAMlpPool(torch.autograd.Function):
         _call("butd_sa_pool_finalize", xyz, B, np_, C3, zmax.data_ptr(), zmin.data_ptr(), amax.data_ptr(),
               amin.data_ptr(), aff[2, 2].data_ptr(), aff[2, 3].data_ptr(), out_cm.data_ptr(),
               out_pm.data_ptr(), zsel.data_ptr(), asel.data_ptr())
-        lin = _last_lin_ok(training, ns, C2, C3)    # the backward then never reads Z3: it is not kept
-        ctx.save_for_backward(X, Zs[0], Zs[1], Zs[2][:0] if lin else Zs[2], idx, aff, zsel, asel, ws[0], ws[1], ws[2],
+        ctx.save_for_backward(X, Zs[0], Zs[1], Zs[2], idx, aff, zsel, asel, ws[0], ws[1], ws[2],
                               g1, g2, g3)
         ctx.cfg = (B, N, np_, ns, C, bool(training), feats_pm is not None and feats_pm.requires_grad,
                    w1.shape, w2.shape, w3.shape, Cin, lin)

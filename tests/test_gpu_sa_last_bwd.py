@@ -75,10 +75,43 @@ def test_linear_last_layer_equals_dense_path(cfg):
     probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
     y_d, gf_d, gp_d = _run(m, xyz, feats, probe, linear=False)
     y_l, gf_l, gp_l = _run(m, xyz, feats, probe, linear=True)
-    assert torch.equal(y_d, y_l)                    # the forward is the same code
-    assert _err(gf_l, gf_d) < 5e-5, _err(gf_l, gf_d)
-    for n in gp_d:
-        assert _err(gp_l[n], gp_d[n]) < 5e-5, (n, _err(gp_l[n], gp_d[n]))
+    # (the linear path's forward is butd_sa_last_fwd -- Z3 is never written --: same values to fp32 rounding; a pooled
+    #  arg-max between two near-equal candidates may then fall the other way and reroute isolated gradient entries)
+    assert _err(y_l, y_d) < 2e-6, _err(y_l, y_d)
+    for n, a, b in [("d_feats", gf_l, gf_d)] + [(n, gp_l[n], gp_d[n]) for n in gp_d]:
+        bad, mean, size, worst = _stats(a, b)
+        assert bad <= max(2, 1e-3 * size) and mean < 2e-5 and worst < 2e-2, (n, bad, size, mean, worst)
+
+
+@pytest.mark.parametrize("cfg", CFGS[:3])
+def test_forward_without_z3_equals_product_plus_colstats(cfg):
+    """butd_sa_last_fwd vs the layer's product launch + butd_sa_colstats it replaces (same backward): pooled output,
+    BatchNorm running statistics, gradients."""
+    from butd_detr_amd import fused_sa
+    m = _module(cfg, 9)
+    torch.manual_seed(17)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    outs = {}
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    for fwd in (False, True):
+        m.load_state_dict(state)
+        prev = fused_sa._LAST_FWD[0]
+        fused_sa._LAST_FWD[0] = fwd
+        try:
+            outs[fwd] = _run(m, xyz, feats, probe, linear=True) + ({k: v.clone() for k, v in m.state_dict().items()},)
+        finally:
+            fused_sa._LAST_FWD[0] = prev
+    assert _err(outs[True][0], outs[False][0]) < 2e-6
+    for k, v in outs[False][3].items():
+        if "running" in k:
+            assert _err(outs[True][3][k], v) < 1e-6, k
+        if "num_batches" in k:
+            assert int(outs[True][3][k]) == int(v)
+    for n, a, b in [("d_feats", outs[True][1], outs[False][1])] + [(n, outs[True][2][n], outs[False][2][n]) for n in outs[False][2]]:
+        bad, mean, size, worst = _stats(a, b)
+        assert bad <= max(2, 1e-3 * size) and mean < 2e-5 and worst < 2e-2, (n, bad, size, mean, worst)
 
 
 def test_linear_last_layer_is_bit_reproducible():
