@@ -39,41 +39,42 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
 }
 
 // --------------------------------------------------------------------------------- forward of the last layer + pool
-// When the backward above is in use nothing reads Z3 = H2 W3^T after the pooling, so the forward need not write it:
-// per 64-row block  H tile -> LDS;  Z3 tile (64 x C3) on the matrix cores -> LDS;  then one thread per channel walks the
-// tile's rows: BatchNorm sums (double accumulators per thread for the whole kernel) and, per group of ns rows, max / min
-// and their FIRST positions (strict compares in row order: butd_sa_colstats' rule).  Replaces the layer's product
-// launch + butd_sa_colstats: reads Z2 once, writes 10 bytes per (group, channel).
+// When the backward below is in use nothing reads Z3 = H2 W3^T after the pooling, so the forward need not write it:
+// per 64-row block  H tile -> LDS (two buffers: one barrier per block);  Z3 tiles on the matrix cores with the ROWS in
+// the accumulator registers of a lane (D[row = 4 (lane/16) + i][column = lane % 16]): a lane then owns one channel of
+// each of its tiles and folds its rows in registers -- BatchNorm sums (fp32 over the block's 16 rows per lane, then
+// double for the whole kernel) and, per group of ns rows, max / min with their FIRST positions (strict compares in row
+// order, ties across lanes to the smaller position: butd_sa_colstats' rule).  Two xor-shuffles per group finish a
+// channel.  Replaces the layer's product launch + butd_sa_colstats: reads Z2 once, writes 10 bytes per (group, channel).
 template <int C2, int C3, int NW>
 __global__ __launch_bounds__(NW * 64) void sa_last_fwd_kernel(
     long P, long nblk, int ns, long G, const float *__restrict__ Z2, const float *__restrict__ sc2,
     const float *__restrict__ sh2, const float *__restrict__ W3, double *__restrict__ sum,
     double *__restrict__ sumsq, float *__restrict__ zmax, float *__restrict__ zmin, uint8_t *__restrict__ amax,
-    uint8_t *__restrict__ amin) {
+    uint8_t *__restrict__ amin, unsigned int *__restrict__ sched, int chunk) {
   constexpr int NT = NW * 64;
   constexpr int ST = C2 + 36;
-  constexpr int SZ = C3 + 4;
   constexpr int NTO = C3 / (16 * NW);    // 16-column output tiles per wave
   constexpr int KG = C2 / 16;
   constexpr int QN = C2 / 4;
   constexpr int RP = NT / QN;
   constexpr int NP = kRows / RP;
-  static_assert(C3 % (16 * NW) == 0 && C3 <= NT && kRows % RP == 0, "decomposition");
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *Ht = lds;                   // [64][ST]
-  float *Zt = Ht + kRows * ST;       // [64][SZ]
+  static_assert(C3 % (16 * NW) == 0 && kRows % RP == 0, "decomposition");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][64][ST]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
   const int q = tid % QN, rsub = tid / QN;
   const int n0 = wave * (C3 / NW);
-  const int nc = kRows / ns;
-  f4 areg[NTO][KG];
+  const int rtg = ns / 16;               // 16-row tiles per group (1, 2 or 4)
+  f4 wreg[NTO][KG];                      // B operand: W3[column][16 g + 4 lq + i]
 #pragma unroll
   for (int t = 0; t < NTO; ++t)
 #pragma unroll
     for (int g = 0; g < KG; ++g)
-      areg[t][g] = *reinterpret_cast<const f4 *>(W3 + (long)(n0 + 16 * t + lm) * C2 + 16 * g + 4 * lq);
+      wreg[t][g] = *reinterpret_cast<const f4 *>(W3 + (long)(n0 + 16 * t + lm) * C2 + 16 * g + 4 * lq);
   const f4 sc = *reinterpret_cast<const f4 *>(sc2 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh2 + 4 * q);
-  double dsum = 0.0, dsq = 0.0;
+  double dsum[NTO], dsq[NTO];
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) dsum[t] = dsq[t] = 0.0;
   f4 zn[NP];
   auto fetch = [&](long b) {
 #pragma unroll
@@ -82,9 +83,27 @@ __global__ __launch_bounds__(NW * 64) void sa_last_fwd_kernel(
       zn[ps] = p < P ? *reinterpret_cast<const f4 *>(Z2 + p * C2 + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  long blk = blockIdx.x;
-  if (blk < nblk) fetch(blk);
-  for (; blk < nblk; blk += gridDim.x) {
+  // Blocks are handed out by an atomic counter, not by blockIdx: the step runs this kernel next to a side queue that
+  // holds a few CUs for milliseconds (the next batch's sampling chain); a workgroup that is placed late must find the
+  // work already taken instead of owning a fixed share of it (measured: 344 us with fixed shares, 185 us alone).  The
+  // counter hands out chunks of blocks (one fetch per block costs ~15 ns each on ONE address: 16 384 of them were the
+  // kernel's duration at SA1); the chunk after next is fetched while the current one is processed; sched[0] = next
+  // chunk, sched[1] = workgroups done (the last one zeroes both for the next launch).
+  long *s_idx = reinterpret_cast<long *>(lds + 2 * kRows * ST);     // (after the two H buffers; 16-byte aligned)
+  const long nchunk = (nblk + chunk - 1) / chunk;                   // the counter hands out chunks of `chunk` blocks
+  long fetched = 0;
+  const bool dyn = sched != nullptr;       // NULL: fixed shares (blockIdx, + gridDim, ...): grids of several workgroups per CU
+  if (dyn && tid == 0) s_idx[0] = (long)atomicAdd(sched, 2u);        // the first two chunks in one fetch
+  __syncthreads();
+  long cur = dyn ? s_idx[0] : (long)blockIdx.x, nxt = dyn ? cur + 1 : cur + gridDim.x, after = 0;
+  __syncthreads();
+  int j = 0;
+  long blk = cur;                                                    // chunk c = blocks c, c + nchunk, c + 2 nchunk, ...:
+  if (cur < nchunk) fetch(blk);                                      // workgroups stream NEIGHBOURING blocks at any time
+  if (dyn && tid == 0) fetched = (long)atomicAdd(sched, 1u);         // (issued after the loads: they return first)
+  int buf = 0;
+  for (; cur < nchunk; buf ^= 1) {
+    float *Ht = lds + buf * (kRows * ST);
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = rsub + ps * RP;
@@ -93,10 +112,27 @@ __global__ __launch_bounds__(NW * 64) void sa_last_fwd_kernel(
       for (int e = 0; e < 4; ++e) h[e] = fmaxf(sc[e] * zn[ps][e] + sh[e], 0.f);
       *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
     }
-    __syncthreads();
-    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+    if (dyn && j == 0 && tid == 0) s_idx[buf] = fetched;
+    __syncthreads();      // (the other buffer is free again: every wave finished reading it before it got here)
+    if (j == 0) after = dyn ? s_idx[buf] : nxt + gridDim.x;
+    int nj = j + 1;
+    long ncur = cur;
+    if (nj == chunk || cur + nj * nchunk >= nblk) { nj = 0; ncur = nxt; }
+    const long nblkidx = ncur + nj * nchunk;
+    if (ncur < nchunk) fetch(nblkidx);
+    if (dyn && j == 0 && tid == 0) fetched = (long)atomicAdd(sched, 1u);
+    float s32[NTO], q32[NTO], mx[NTO], mn[NTO];
+    int ax[NTO], an[NTO];
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) s32[t] = q32[t] = 0.f;
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
+      if (rt % rtg == 0) {
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) {
+          mx[t] = -INFINITY; mn[t] = INFINITY; ax[t] = an[t] = 0;
+        }
+      }
       f4 oacc[NTO];
 #pragma unroll
       for (int t = 0; t < NTO; ++t) oacc[t] = f4{0.f, 0.f, 0.f, 0.f};
@@ -106,37 +142,66 @@ __global__ __launch_bounds__(NW * 64) void sa_last_fwd_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int t = 0; t < NTO; ++t) oacc[t] = mfma4(areg[t][g][i], hv[i], oacc[t]);
+          for (int t = 0; t < NTO; ++t) oacc[t] = mfma4(hv[i], wreg[t][g][i], oacc[t]);
       }
+      // lane: rows 16 rt + 4 lq + i (i = 0..3) of column n0 + 16 t + lm
+      const bool live = blk * kRows + 16 * rt < P;      // (P is a multiple of ns >= 16: a 16-row tile is all in or all out)
+      const int kbase = (16 * rt) % ns + 4 * lq;        // position inside the group
 #pragma unroll
-      for (int t = 0; t < NTO; ++t) *reinterpret_cast<f4 *>(Zt + (16 * rt + lm) * SZ + n0 + 16 * t + 4 * lq) = oacc[t];
-    }
-    __syncthreads();
-    if (tid < C3) {
-      for (int gi = 0; gi < nc; ++gi) {
-        const long g = blk * nc + gi;
-        if (g >= G) break;
-        const float *col = Zt + (gi * ns) * SZ + tid;
-        float mx = -INFINITY, mn = INFINITY;
-        int ax = 0, an = 0;
-        for (int k = 0; k < ns; ++k) {
-          const float v = col[k * SZ];
-          dsum += (double)v;
-          dsq += (double)v * (double)v;
-          if (v > mx) { mx = v; ax = k; }
-          if (v < mn) { mn = v; an = k; }
+      for (int t = 0; t < NTO; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = live ? oacc[t][i] : 0.f;
+          s32[t] += v;
+          q32[t] += v * v;
+          if (v > mx[t]) { mx[t] = v; ax[t] = kbase + i; }
+          if (v < mn[t]) { mn[t] = v; an[t] = kbase + i; }
         }
-        zmax[g * C3 + tid] = mx;
-        zmin[g * C3 + tid] = mn;
-        amax[g * C3 + tid] = (uint8_t)ax;
-        amin[g * C3 + tid] = (uint8_t)an;
+      if ((rt + 1) % rtg == 0) {       // the group is complete: fold the four row quarters (lanes 16 and 32 apart)
+        const long g = blk * (kRows / ns) + rt / rtg;
+#pragma unroll
+        for (int t = 0; t < NTO; ++t) {
+          float a = mx[t], b2 = mn[t];
+          int ia = ax[t], ib = an[t];
+#pragma unroll
+          for (int d = 16; d <= 32; d <<= 1) {
+            const float oa = __shfl_xor(a, d), ob = __shfl_xor(b2, d);
+            const int oia = __shfl_xor(ia, d), oib = __shfl_xor(ib, d);
+            if (oa > a || (oa == a && oia < ia)) { a = oa; ia = oia; }
+            if (ob < b2 || (ob == b2 && oib < ib)) { b2 = ob; ib = oib; }
+          }
+          if (lq == 0 && g < G && live) {
+            const long o = g * C3 + n0 + 16 * t + lm;
+            zmax[o] = a; zmin[o] = b2; amax[o] = (uint8_t)ia; amin[o] = (uint8_t)ib;
+          }
+        }
       }
     }
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NTO; ++t) {
+      dsum[t] += (double)s32[t];
+      dsq[t] += (double)q32[t];
+    }
+    if (nj == 0) { cur = nxt; nxt = after; }
+    j = nj;
+    blk = nblkidx;
   }
-  if (tid < C3) {
-    atomicAdd(sum + tid, dsum);
-    atomicAdd(sumsq + tid, dsq);
+  if (dyn && tid == 0) {
+    __threadfence();
+    if (atomicAdd(sched + 1, 1u) == gridDim.x - 1) {    // the last workgroup out: every fetch has happened
+      sched[0] = 0u;
+      sched[1] = 0u;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NTO; ++t) {
+    double a = dsum[t], b2 = dsq[t];
+    a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+    b2 += __shfl_xor(b2, 16); b2 += __shfl_xor(b2, 32);
+    if (lq == 0) {
+      atomicAdd(sum + n0 + 16 * t + lm, a);
+      atomicAdd(sumsq + n0 + 16 * t + lm, b2);
+    }
   }
 }
 
@@ -777,7 +842,7 @@ hipError_t sparse_attr() {
 
 int g_abl = 0;
 template <int C2, int C3>
-constexpr size_t fwd_lds() { return (size_t)(kRows * (C2 + 36) + kRows * (C3 + 4)) * sizeof(float); }
+constexpr size_t fwd_lds() { return (size_t)(2 * kRows * (C2 + 36)) * sizeof(float) + 2 * sizeof(long); }
 
 int grid_mfma(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 768 : 512) ? nblk : (C2 == 64 ? 768 : 512)); }
 int grid_sparse(int C2, long nblk) { return (int)(nblk < (C2 == 64 ? 512 : 256) ? nblk : (C2 == 64 ? 512 : 256)); }
@@ -794,21 +859,23 @@ int butd_sa_last_bwd_supported(int ns, int C2, int C3) {
 
 int butd_sa_last_fwd(int B, int np, int ns, int C2, int C3, const float *Z2, const float *scale2,
                      const float *shift2, const float *W3, double *sum, double *sumsq, float *zmax, float *zmin,
-                     uint8_t *amax, uint8_t *amin, butd_stream_t stream) {
+                     uint8_t *amax, uint8_t *amin, unsigned int *sched, butd_stream_t stream) {
   const long G = (long)B * np, P = G * ns;
   if (P <= 0) return 0;
   if (!butd_sa_last_bwd_supported(ns, C2, C3)) return (int)hipErrorInvalidValue;
   if (hipError_t e = sparse_attr(); e != hipSuccess) return (int)e;
   hipStream_t st = (hipStream_t)stream;
   const long nblk = (P + kRows - 1) / kRows;
+  const int chunk = (int)(nblk / 4096 < 1 ? 1 : (nblk / 4096 > 16 ? 16 : nblk / 4096));   // (one workgroup per CU: <= ~4096 counter fetches)
   if (C2 == 64) {
-    const int grid = (int)(nblk < 512 ? nblk : 512);
+    const int grid = (int)(nblk < 768 ? nblk : 768);
+    // (three workgroups per CU: a late one costs 3 %; one counter fetch per 3.6-us block would saturate the counter)
     hipLaunchKernelGGL((sa_last_fwd_kernel<64, 128, 4>), dim3(grid), dim3(256), (fwd_lds<64, 128>()), st, P, nblk, ns, G, Z2,
-                       scale2, shift2, W3, sum, sumsq, zmax, zmin, amax, amin);
+                       scale2, shift2, W3, sum, sumsq, zmax, zmin, amax, amin, (unsigned int *)nullptr, 1);
   } else {
     const int grid = (int)(nblk < 256 ? nblk : 256);
     hipLaunchKernelGGL((sa_last_fwd_kernel<128, 256, 8>), dim3(grid), dim3(512), (fwd_lds<128, 256>()), st, P, nblk, ns, G, Z2,
-                       scale2, shift2, W3, sum, sumsq, zmax, zmin, amax, amin);
+                       scale2, shift2, W3, sum, sumsq, zmax, zmin, amax, amin, sched, chunk);
   }
   return (int)hipGetLastError();
 }

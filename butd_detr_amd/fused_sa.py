@@ -36,6 +36,17 @@ def _call(name, ref, *args):
 _LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
 _LAST_FWD = [os.environ.get("BUTD_SA_LAST_FWD", "1") != "0"]      # ... and the forward that does not write Z3
 _scratch_sizes = {}
+_sched = {}
+
+
+def _sched_words(dev):
+    """Two uint32 per (device, stream) for the kernels that hand their blocks out through a counter (zero between
+    launches: the kernel's last workgroup resets them)."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _sched.get(key)
+    if t is None:
+        t = _sched[key] = torch.zeros(2, dtype=torch.int32, device=dev)      # (not from the step arena: it persists)
+    return t
 
 
 def set_last_layer_linear(flag):
@@ -44,8 +55,12 @@ def set_last_layer_linear(flag):
     return prev
 
 
-def _last_lin_ok(training, ns, C2, C3):
-    return bool(training and _LAST_LIN[0] and _lib.butd_sa_last_bwd_supported(int(ns), int(C2), int(C3)))
+_LAST_MIN_ROWS = [int(os.environ.get("BUTD_SA_LAST_MIN_ROWS", "0"))]
+
+
+def _last_lin_ok(training, ns, C2, C3, P=1 << 30):
+    return bool(training and _LAST_LIN[0] and P >= _LAST_MIN_ROWS[0]
+                and _lib.butd_sa_last_bwd_supported(int(ns), int(C2), int(C3)))
 
 
 def _last_scratch(P, C2, C3):
@@ -99,7 +114,7 @@ class _SAMlpPool(torch.autograd.Function):
         Zs, inp, prev_aff = [], X, None
         G = B * np_
         zmax = zmin = amax = amin = None
-        lin = _last_lin_ok(training, ns, C2, C3)    # the backward then never reads Z3: the forward does not write it
+        lin = _last_lin_ok(training, ns, C2, C3, P)  # the backward then never reads Z3: the forward does not write it
         for li, (Cl, w) in enumerate(zip((C1, C2, C3), ws)):
             last = li == 2
             if last:
@@ -111,7 +126,7 @@ class _SAMlpPool(torch.autograd.Function):
                 # product + BatchNorm sums + pooling extrema in one pass over Z2 (include/butd_sa.h, butd_sa_last_fwd)
                 _call("butd_sa_last_fwd", xyz, B, np_, ns, C2, C3, inp.data_ptr(), prev_aff[0].data_ptr(),
                       prev_aff[1].data_ptr(), w.data_ptr(), stats[li, 0, 0].data_ptr(), stats[li, 0, 1].data_ptr(),
-                      zmax.data_ptr(), zmin.data_ptr(), amax.data_ptr(), amin.data_ptr())
+                      zmax.data_ptr(), zmin.data_ptr(), amax.data_ptr(), amin.data_ptr(), _sched_words(dev).data_ptr())
                 Z, in_gemm_stats = inp[:0], False
             else:
                 Z = torch.empty((P, Cl), device=dev)

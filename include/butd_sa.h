@@ -99,10 +99,12 @@ int butd_sa_last_bwd_supported(int ns, int C2, int C3);
 /* The matching forward: the last layer's product Z3 = relu(scale2 * Z2 + shift2) W3^T, its BatchNorm column sums
  * (sum, sumsq: double, ADDED -- the caller zero-fills) and the per-group extrema of butd_sa_colstats (zmax, zmin: G x C3;
  * amax, amin: G x C3 uint8, first position of the extremum) WITHOUT writing Z3: with butd_sa_last_bwd nothing reads it
- * again.  Same support set. */
+ * again.  Same support set.  sched: two uint32 of device memory, ZERO on entry and left zero (the kernel hands its
+ * 64-row blocks out through them so that workgroups placed late -- other queues may hold CUs -- take no fixed share);
+ * one pair per stream that may run this call concurrently. */
 int butd_sa_last_fwd(int B, int np, int ns, int C2, int C3, const float *Z2, const float *scale2,
                      const float *shift2, const float *W3, double *sum, double *sumsq, float *zmax, float *zmin,
-                     uint8_t *amax, uint8_t *amin, butd_stream_t stream);
+                     uint8_t *amax, uint8_t *amin, unsigned int *sched, butd_stream_t stream);
 int butd_sa_last_bwd_scratch(long P, int C2, int C3, long *ws_floats, long *ws_doubles);
 int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, const float *scale2,
                      const float *shift2, const float *mean2, const float *rstd2, const float *W3,
