@@ -814,6 +814,114 @@ __global__ void sa_last_dw_kernel(int C2, int C3, long P, const float *__restric
 template <int C2>
 constexpr size_t fused_lds() { return (size_t)(kRows * (C2 + 36) + kRows * (C2 + 4)) * sizeof(float); }
 
+// ---------------------------------------------------------------- the FIRST layer when no input gradient is wanted
+// SA1's input features carry no gradient (bdetr.py:151: xyz + colour), so layer 1's backward is its weight gradient
+// alone, and that too is linear in the three terms of the BatchNorm backward:
+//   dW1 = dZ1^T X = s (GX - m1 SX^T - m2 rstd (W1 XX - mu SX^T)),   GX = g^T X,  SX = column sums of X,  XX = X^T X
+// with g = dH1 gated by layer 1's ReLU and X the grouped input (P x 8).  One streaming pass over (dH1, Z1, X) yields
+// S1, S2 (what butd_sa_mask_stats did), GX (C1 x 8), SX, XX as per-workgroup partials; butd_sa_dz_mid's pass over the
+// 10^6-row tensor and the thin weight-gradient product (64 x 8 x 10^6: 113 us) are not run at all.
+constexpr int kFirstChunk = 1024;
+template <int KP>
+__global__ __launch_bounds__(kThreads) void sa_first_stats_kernel(
+    long P, int C, const float *__restrict__ dH, const float *__restrict__ Z, const float *__restrict__ X,
+    const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
+    const float *__restrict__ rstd, float *__restrict__ ws, long ws_stride) {
+  static_assert(KP == 8, "grouped xyz + colour, padded to 8 columns");
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [tpg][C][KP + 2] then the X sums
+  const int c4n = C >> 2, tpg = kThreads / c4n;
+  const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
+  const long row0 = (long)blockIdx.x * kFirstChunk;
+  const long rows = min((long)kFirstChunk, P - row0);
+  const f4 sc = *reinterpret_cast<const f4 *>(scale + 4 * cq), sh = *reinterpret_cast<const f4 *>(shift + 4 * cq);
+  const f4 mu = *reinterpret_cast<const f4 *>(mean + 4 * cq), rs = *reinterpret_cast<const f4 *>(rstd + 4 * cq);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  float gx[4][KP];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < KP; ++k) gx[e][k] = 0.f;
+  float sxr = 0.f, xxr[KP];            // threads cq < KP of every row phase: row cq of X^T X and SX[cq]
+#pragma unroll
+  for (int k = 0; k < KP; ++k) xxr[k] = 0.f;
+  for (long r = sub; r < rows; r += tpg) {
+    const long p = row0 + r;
+    const f4 z = *reinterpret_cast<const f4 *>(Z + p * C + 4 * cq);
+    const f4 d = *reinterpret_cast<const f4 *>(dH + p * C + 4 * cq);
+    const f4 xa = *reinterpret_cast<const f4 *>(X + p * KP), xb = *reinterpret_cast<const f4 *>(X + p * KP + 4);
+    const float x[KP] = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float g = sc[e] * z[e] + sh[e] > 0.f ? d[e] : 0.f;
+      s1[e] += g;
+      s2[e] += g * (z[e] - mu[e]) * rs[e];
+#pragma unroll
+      for (int k = 0; k < KP; ++k) gx[e][k] += g * x[k];
+    }
+    if (cq < KP) {
+      const float xc = cq < 4 ? xa[cq & 3] : xb[cq & 3];
+      sxr += xc;
+#pragma unroll
+      for (int k2 = 0; k2 < KP; ++k2) xxr[k2] += xc * x[k2];
+    }
+  }
+  // fold the tpg row phases in LDS, fixed order
+  constexpr int W = KP + 2;
+  float *red = lds;                                // [tpg][C][W]: gx[0..KP), s1, s2
+  float *redx = lds + (long)tpg * C * W;           // [tpg][KP + KP*KP]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float *o = red + ((long)sub * C + 4 * cq + e) * W;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) o[k] = gx[e][k];
+    o[KP] = s1[e];
+    o[KP + 1] = s2[e];
+  }
+  if (cq < KP) {
+    float *o = redx + (long)sub * (KP + KP * KP);
+    o[cq] = sxr;
+#pragma unroll
+    for (int k2 = 0; k2 < KP; ++k2) o[KP + cq * KP + k2] = xxr[k2];
+  }
+  __syncthreads();
+  float *out = ws + (long)blockIdx.x * ws_stride;  // [C][W] then [KP + KP*KP]
+  for (int i = threadIdx.x; i < C * W; i += kThreads) {
+    float a = 0.f;
+    for (int t = 0; t < tpg; ++t) a += red[(long)t * C * W + i];
+    out[i] = a;
+  }
+  for (int i = threadIdx.x; i < KP + KP * KP; i += kThreads) {
+    float a = 0.f;
+    for (int t = 0; t < tpg; ++t) a += redx[(long)t * (KP + KP * KP) + i];
+    out[C * W + i] = a;
+  }
+}
+
+// grid C x block KP: dW1[c][k]; tot = [C][KP + 2] then SX [KP], XX [KP][KP] (double).  Also hands S1, S2 out.
+template <int KP>
+__global__ void sa_first_dw_kernel(int C, long P, int ldw, const float *__restrict__ W1, const float *__restrict__ scale,
+                                   const float *__restrict__ rstd, const double *__restrict__ tot,
+                                   float *__restrict__ dW1, double *__restrict__ S1, double *__restrict__ S2) {
+  constexpr int W = KP + 2;
+  const int c = blockIdx.x, k = threadIdx.x;
+  const double *row = tot + (long)c * W, *SX = tot + (long)C * W, *XX = SX + KP;
+  const double invP = 1.0 / (double)P;
+  const double m1 = row[KP] * invP, m2 = row[KP + 1] * invP;
+  double wx = 0.0, wsx = 0.0;
+#pragma unroll
+  for (int j = 0; j < KP; ++j) {
+    const double w = (double)W1[(long)c * ldw + j];
+    wx += w * XX[j * KP + k];
+    wsx += w * SX[j];
+  }
+  const double v = row[k] - m1 * SX[k] - m2 * (double)rstd[c] * (wx - wsx * invP * SX[k]);
+  dW1[(long)c * ldw + k] = (float)((double)scale[c] * v);
+  if (k == 0) {
+    S1[c] = row[KP];
+    S2[c] = row[KP + 1];
+  }
+}
+
 template <int C2, int C3>
 constexpr size_t sparse_lds() { return (size_t)(2 * kRows * (C2 + 4)) * sizeof(float); }
 
@@ -877,6 +985,32 @@ int butd_sa_last_fwd(int B, int np, int ns, int C2, int C3, const float *Z2, con
     hipLaunchKernelGGL((sa_last_fwd_kernel<128, 256, 8>), dim3(grid), dim3(512), (fwd_lds<128, 256>()), st, P, nblk, ns, G, Z2,
                        scale2, shift2, W3, sum, sumsq, zmax, zmin, amax, amin, sched, chunk);
   }
+  return (int)hipGetLastError();
+}
+
+int butd_sa_first_bwd_scratch(long P, int C1, int Kp, long *ws_floats, long *ws_doubles) {
+  if (P <= 0 || !ws_floats || !ws_doubles || Kp != 8 || (C1 & 3) || C1 > 256) return (int)hipErrorInvalidValue;
+  const long per = (long)C1 * (Kp + 2) + Kp + Kp * Kp, blocks = (P + kFirstChunk - 1) / kFirstChunk;
+  *ws_floats = blocks * per;
+  *ws_doubles = per;
+  return 0;
+}
+
+int butd_sa_first_bwd(long P, int C1, int Kp, const float *dH1, const float *Z1, const float *X, const float *scale1,
+                      const float *shift1, const float *mean1, const float *rstd1, const float *W1, float *dW1,
+                      double *S1, double *S2, float *ws_f, double *ws_d, butd_stream_t stream) {
+  if (P <= 0) return 0;
+  if (Kp != 8 || (C1 & 3) || C1 > 256 || kThreads % (C1 >> 2)) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  const long per = (long)C1 * (Kp + 2) + Kp + Kp * Kp, blocks = (P + kFirstChunk - 1) / kFirstChunk;
+  const int tpg = kThreads / (C1 >> 2);
+  const size_t lds = ((size_t)tpg * C1 * (Kp + 2) + (size_t)tpg * (Kp + Kp * Kp)) * sizeof(float);
+  if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(sa_first_stats_kernel<8>, dim3((unsigned)blocks), dim3(kThreads), lds, st, P, C1, dH1, Z1, X, scale1,
+                     shift1, mean1, rstd1, ws_f, per);
+  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, st, ws_f, per, (int)blocks,
+                     (const float *)nullptr, 0L, 0, ws_d);
+  hipLaunchKernelGGL(sa_first_dw_kernel<8>, dim3(C1), dim3(Kp), 0, st, C1, P, Kp, W1, scale1, rstd1, ws_d, dW1, S1, S2);
   return (int)hipGetLastError();
 }
 

@@ -35,6 +35,7 @@ def _call(name, ref, *args):
 # widths / nsample the kernel has no instance for).
 _LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
 _LAST_FWD = [os.environ.get("BUTD_SA_LAST_FWD", "1") != "0"]      # ... and the forward that does not write Z3
+_FIRST_LIN = [os.environ.get("BUTD_SA_FIRST_BWD", "1") != "0"]     # ... and the first layer's, where no input gradient is wanted
 _scratch_sizes = {}
 _sched = {}
 
@@ -70,6 +71,17 @@ def _last_scratch(P, C2, C3):
         nf, nd = ctypes.c_long(0), ctypes.c_long(0)
         _hiplib.check(_lib.butd_sa_last_bwd_scratch(P, C2, C3, ctypes.byref(nf), ctypes.byref(nd)),
                       "butd_sa_last_bwd_scratch")
+        _scratch_sizes[key] = (nf.value, nd.value)
+    return _scratch_sizes[key]
+
+
+def _first_scratch(P, C1, Kp):
+    key = ("first", P, C1, Kp)
+    if key not in _scratch_sizes:
+        import ctypes
+        nf, nd = ctypes.c_long(0), ctypes.c_long(0)
+        _hiplib.check(_lib.butd_sa_first_bwd_scratch(P, C1, Kp, ctypes.byref(nf), ctypes.byref(nd)),
+                      "butd_sa_first_bwd_scratch")
         _scratch_sizes[key] = (nf.value, nd.value)
     return _scratch_sizes[key]
 
@@ -225,21 +237,31 @@ class _SAMlpPool(torch.autograd.Function):
         _gemm([_wgrad(dZ2, Z1, dW2, None, P, C2, C1, b_affine=(scale(0), shift(0))),
                _dgrad(dZ2, w2, dH1, P, C2, C1)], X)
         # ---- layer 1
-        _call("butd_sa_mask_stats", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), scale(0).data_ptr(),
-              shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
-              S[0, 1].data_ptr())
-        _call("butd_sa_dz_mid", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), g1.data_ptr(), scale(0).data_ptr(),
-              shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), tr)
-        dZ1 = dH1
+        first_lin = lin and not need_dfeat and Kp == 8 and _FIRST_LIN[0]
         d_feats = None
-        if need_dfeat:
-            dX = torch.empty((P, Kp), device=dev)
-            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp), _dgrad(dZ1, w1, dX, P, C1, Kp)], X)
-            d_feats = zeros((B, N, C), device=dev)
-            _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), Kp, idx.data_ptr(),
-                  d_feats.data_ptr())
+        if first_lin:
+            # no input gradient wanted (SA1): the sums and dW1 from one pass over (dH1, Z1, X) -- no dZ1, no thin product
+            nf, nd = _first_scratch(P, C1, Kp)
+            ws_f = torch.empty(nf, device=dev)
+            ws_d = torch.empty(nd, dtype=torch.float64, device=dev)
+            _call("butd_sa_first_bwd", X, P, C1, Kp, dH1.data_ptr(), Z1.data_ptr(), X.data_ptr(), scale(0).data_ptr(),
+                  shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), w1.data_ptr(), dW1.data_ptr(),
+                  S[0, 0].data_ptr(), S[0, 1].data_ptr(), ws_f.data_ptr(), ws_d.data_ptr())
         else:
-            _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp)], X)
+            _call("butd_sa_mask_stats", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), scale(0).data_ptr(),
+                  shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
+                  S[0, 1].data_ptr())
+            _call("butd_sa_dz_mid", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), g1.data_ptr(), scale(0).data_ptr(),
+                  shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), tr)
+            dZ1 = dH1
+            if need_dfeat:
+                dX = torch.empty((P, Kp), device=dev)
+                _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp), _dgrad(dZ1, w1, dX, P, C1, Kp)], X)
+                d_feats = zeros((B, N, C), device=dev)
+                _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), Kp, idx.data_ptr(),
+                      d_feats.data_ptr())
+            else:
+                _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp)], X)
         dW1 = dW1[:, :Cin]
         Sf = S.float()
         # S1 = sum g, S2 = sum g*zhat with zhat from the statistics the forward used (batch or running):

@@ -113,6 +113,16 @@ int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, con
                      const double *S2_3, float *dH2, float *dW3, double *S1_2, double *S2_2, float *ws_f,
                      double *ws_d, butd_stream_t stream);
 
+/* The FIRST layer's backward when its input needs no gradient (SA1: xyz + colour) and the grouped input has 8 columns,
+ * training mode: one pass over (dH1, Z1, X) gives the BatchNorm sums S1, S2 (what butd_sa_mask_stats gave; WRITTEN) and
+ * dW1 (C1 x 8, row stride 8, written) = dZ1^T X by linearity of the BatchNorm backward -- neither butd_sa_dz_mid nor the
+ * thin weight-gradient product run.  Scratch sizes from butd_sa_first_bwd_scratch.  Per-workgroup partials summed in
+ * double: no atomics. */
+int butd_sa_first_bwd_scratch(long P, int C1, int Kp, long *ws_floats, long *ws_doubles);
+int butd_sa_first_bwd(long P, int C1, int Kp, const float *dH1, const float *Z1, const float *X, const float *scale1,
+                      const float *shift1, const float *mean1, const float *rstd1, const float *W1, float *dW1,
+                      double *S1, double *S2, float *ws_f, double *ws_d, butd_stream_t stream);
+
 /* Hidden layers, part 1 (read-only pass over dH, Z (P x C)): with g = dH * [scale*z+shift > 0],
  * S1[c] += sum_p g, S2[c] += sum_p g*zhat (double, caller zero-fills). */
 int butd_sa_mask_stats(long P, int C, const float *dH, const float *Z, const float *scale,

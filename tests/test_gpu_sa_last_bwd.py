@@ -40,18 +40,19 @@ def _module(cfg, seed):
     return m
 
 
-def _run(m, xyz, feats, probe, linear):
+def _run(m, xyz, feats, probe, linear, input_grad=True):
     from butd_detr_amd import attention_blocks, fused_sa
     prev = fused_sa.set_last_layer_linear(linear)
     attention_blocks.set_backend("hip")
     try:
         for p in m.parameters():
             p.grad = None
-        f = feats.clone().requires_grad_(True)
+        f = feats.clone().requires_grad_(input_grad)
         y = m(xyz, f)[1]
         assert m.last_features_pm is not None, "fused path not taken"
         (y * probe).sum().backward()
-        return y.detach().clone(), f.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters()}
+        return (y.detach().clone(), f.grad.clone() if input_grad else None,
+                {n: p.grad.clone() for n, p in m.named_parameters()})
     finally:
         attention_blocks.set_backend("torch")
         fused_sa.set_last_layer_linear(prev)
@@ -163,3 +164,28 @@ def test_linear_last_layer_vs_float64_module(cfg):
         (_, m_d, _, _), (bad, m_l, size, worst) = _stats(dense, truth), _stats(lin, truth)
         assert bad <= max(2, 1e-3 * size) and worst < 2e-2 and m_l <= 1e-4, (n, bad, size, worst, m_l)
         assert m_l <= 1.5 * m_d + 1e-6, (n, m_l, m_d)        # typical error: no worse than the dense path
+
+
+@pytest.mark.parametrize("cfg", [CFGS[0], CFGS[4], dict(B=8, N=20000, C=3, npoint=2048, radius=0.2, nsample=64, mlp=[3, 64, 64, 128])])
+def test_first_layer_without_input_gradient(cfg):
+    """SA1's features carry no gradient: butd_sa_first_bwd (sums + dW1 from one pass, no dZ1) vs butd_sa_mask_stats +
+    butd_sa_dz_mid + the thin weight-gradient product, and vs the gradients of the run that also asks for d_feats."""
+    from butd_detr_amd import fused_sa
+    m = _module(cfg, 21)
+    torch.manual_seed(23)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    outs = {}
+    for first in (False, True):
+        prev = fused_sa._FIRST_LIN[0]
+        fused_sa._FIRST_LIN[0] = first
+        try:
+            outs[first] = _run(m, xyz, feats, probe, linear=True, input_grad=False)
+        finally:
+            fused_sa._FIRST_LIN[0] = prev
+    ref = _run(m, xyz, feats, probe, linear=True, input_grad=True)
+    assert torch.equal(outs[True][0], outs[False][0])
+    for n in outs[False][2]:
+        assert _err(outs[True][2][n], outs[False][2][n]) < 2e-5, (n, _err(outs[True][2][n], outs[False][2][n]))
+        assert _err(outs[True][2][n], ref[2][n]) < 2e-5, n
