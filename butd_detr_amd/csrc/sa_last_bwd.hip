@@ -747,6 +747,10 @@ __global__ __launch_bounds__(NW * 64) void sa_last_fused_kernel(
   }
 }
 
+// (A one-pass version for the 128-wide levels -- a workgroup per 64-row block AND column half, 244 registers, one
+//  workgroup per CU -- was built and measured: 561 us at SA2 against 434 us for the two kernels above; with a single
+//  workgroup per CU nothing overlaps its eleven barrier-separated phases per block.  profiles/r04_sa_last_layer.txt.)
+
 // ----------------------------------------------------------------------------------------------- partials -> totals
 // tot[n] = sum over parts of part[w][n] (double), for two groups of partials laid one after the other in tot.  A block
 // = 16 elements x 16 part-lanes: a thread sums every 16th partial, the 16 sums fold in LDS in a fixed order.
@@ -941,9 +945,7 @@ hipError_t sparse_attr() {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_fused_kernel<64, 128, 4>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_last_fused_kernel<128, 256, 8>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return e;
   }();
   return err;
 }
@@ -1042,17 +1044,15 @@ int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, con
     hipLaunchKernelGGL(sa_last_coeffs_kernel<128>, dim3(C2 / 16, C2 / 16), dim3(256), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
   else
     hipLaunchKernelGGL(sa_last_coeffs_kernel<256>, dim3(C2 / 16, C2 / 16), dim3(256), 0, st, C2, P, W3, scale3, mean3, rstd3, S1_3, S2_3, An, dvec);
-  const bool fused = !(g_abl & 16) && (C2 == 64 || (g_abl & 32));
+  const long n1 = (long)C2 * C2, n2 = per_sparse;
+  {
+  const bool fused = !(g_abl & 16) && C2 == 64;
+
   if (fused) {     // one pass; both partial groups use the sparse grid
     ws_sparse = ws_gram + (long)gs * C2 * C2;
-    if (C2 == 64)
-      hipLaunchKernelGGL((sa_last_fused_kernel<64, 128, 4>), dim3(gs), dim3(256), (fused_lds<64>()), st, P, nblk, ns, G, dH2,
-                         Z2, scale2, shift2, mean2, rstd2, W3, An, dvec, d_out_pm, zsel, asel, scale3, shift3, ws_gram,
-                         ws_sparse, per_sparse);
-    else
-      hipLaunchKernelGGL((sa_last_fused_kernel<128, 256, 8>), dim3(gs), dim3(512), (fused_lds<128>()), st, P, nblk, ns, G,
-                         dH2, Z2, scale2, shift2, mean2, rstd2, W3, An, dvec, d_out_pm, zsel, asel, scale3, shift3,
-                         ws_gram, ws_sparse, per_sparse);
+    hipLaunchKernelGGL((sa_last_fused_kernel<64, 128, 4>), dim3(gs), dim3(256), (fused_lds<64>()), st, P, nblk, ns, G, dH2,
+                       Z2, scale2, shift2, mean2, rstd2, W3, An, dvec, d_out_pm, zsel, asel, scale3, shift3, ws_gram,
+                       ws_sparse, per_sparse);
   } else if (C2 == 64) {
     hipLaunchKernelGGL(sa_last_mfma_kernel<64>, dim3(gm), dim3(kThreads), 0, st, P, nblk, Z2, scale2, shift2, An, dvec, dH2, ws_gram);
     hipLaunchKernelGGL((sa_last_sparse_kernel<64, 128, 4>), dim3(gs), dim3(256), (sparse_lds<64, 128>()), st, P, nblk, ns, G, dH2, Z2, scale2,
@@ -1062,9 +1062,9 @@ int butd_sa_last_bwd(int B, int np, int ns, int C2, int C3, const float *Z2, con
     hipLaunchKernelGGL((sa_last_sparse_kernel<128, 256, 8>), dim3(gs), dim3(512), (sparse_lds<128, 256>()), st, P, nblk, ns, G, dH2, Z2, scale2,
                        shift2, mean2, rstd2, W3, d_out_pm, zsel, asel, scale3, shift3, ws_sparse, per_sparse, g_abl);
   }
-  const long n1 = (long)C2 * C2, n2 = per_sparse;
   hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((n1 + n2 + 15) / 16)), dim3(256), 0, st, ws_gram, n1, fused ? gs : gm,
                      ws_sparse, n2, gs, ws_d);
+  }
   hipLaunchKernelGGL(sa_last_dw_kernel, dim3(C3), dim3(C2), 0, st, C2, C3, P, W3, scale3, rstd3, S1_3, S2_3, ws_d, dW3,
                      S1_2, S2_2);
   return (int)hipGetLastError();
