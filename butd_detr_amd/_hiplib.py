@@ -115,6 +115,8 @@ SA_SYMBOLS = {
     "butd_sa_last_bwd": (_c_int, [_c_int] * 5 + [_P] * 21 + [_P]),
     "butd_sa_dz_mid": (_c_int, [_c_long, _c_int] + [_P] * 9 + [_c_int, _P]),
     "butd_sa_scatter_rows": (_c_int, [_c_int] * 5 + [_P, _c_int, _P, _P] + [_P]),
+    "butd_sa_inverse_index": (_c_int, [_c_int] * 4 + [_P] * 4 + [_P]),
+    "butd_sa_gather_rows": (_c_int, [_c_int] * 3 + [_P, _c_int, _P, _P, _P] + [_P]),
     "butd_sa_fused_eval": (_c_int, [_c_int] * 5 + [_P, _P, _P, _c_long, _P, _c_float, _c_int] + [_P] * 7 + [_P]),
 }
 

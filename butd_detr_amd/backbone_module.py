@@ -58,8 +58,9 @@ class Pointnet2Backbone(nn.Module):
         pointnet2_utils.py:346-349), and the three-nearest-neighbour indices + inverse-distance weights of the two
         feature-propagation modules (pointnet2_modules.py:392-396).  A training loop runs it for batch k+1 on a side
         stream while batch k trains and hands it to ``forward(..., plan=...)``:
-        {"levels": [(inds (B,np) i32, new_xyz (B,np,3), idx (B,np,ns) i32) x 4], "fp": [(idx (B,n,3) i32, weight (B,n,3)) x 2]}"""
-        from . import pointnet2_ext, rowwise
+        {"levels": [(inds (B,np) i32, new_xyz (B,np,3), idx (B,np,ns) i32, inverse lists (start, list) or None) x 4],
+         "fp": [(idx (B,n,3) i32, weight (B,n,3)) x 2]}"""
+        from . import fused_sa, pointnet2_ext, rowwise
         xyz = pointcloud[..., 0:3].contiguous()
         xyzs, levels = [xyz], []
         for level in (1, 2, 3, 4):
@@ -67,7 +68,9 @@ class Pointnet2Backbone(nn.Module):
             inds = pointnet2_utils.furthest_point_sample(xyz, sa.npoint)
             new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
             idx = pointnet2_utils.ball_query(sa.radius, sa.nsample, xyz, new_xyz)
-            levels.append((inds, new_xyz, idx))
+            # levels 2-4 return a feature gradient: the inverted neighbour lists turn its scatter into a gather
+            inv = fused_sa.inverse_index(idx, xyz.shape[1]) if (level > 1 and idx.is_cuda) else None
+            levels.append((inds, new_xyz, idx, inv))
             xyz = new_xyz
             xyzs.append(xyz)
         fp = []
@@ -88,9 +91,9 @@ class Pointnet2Backbone(nn.Module):
         for level in (1, 2, 3, 4):
             sa = getattr(self, f"sa{level}")
             if plan is not None:
-                p_inds, p_xyz, p_idx = plan["levels"][level - 1]
+                p_inds, p_xyz, p_idx, p_inv = (tuple(plan["levels"][level - 1]) + (None,))[:4]
                 xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off, inds=p_inds,
-                                         new_xyz=p_xyz, ball_idx=p_idx)
+                                         new_xyz=p_xyz, ball_idx=p_idx, ball_inv=p_inv)
             else:
                 xyz, features, inds = sa(xyz, features, features_pm=feats_pm, feat_offset=off,
                                          inds=None if sample_inds is None else sample_inds[level - 1])

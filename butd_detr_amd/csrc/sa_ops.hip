@@ -453,6 +453,92 @@ inline unsigned blocks_for(long total, int cap = 16384) {
 }
 inline bool cols_ok(int C) { return C >= 16 && C <= kThreads && kThreads % C == 0; }
 
+// ----------------------------------------------------------------- feature gradient as a gather (no float atomics)
+// d_feats[b, i, :] = sum over the grouped rows p with idx[p] == i of dX[p, 3:].  The inverse of the neighbour lists (for
+// every point the grouped rows that copy it) is a function of the coordinates alone: built once per batch (count, scan,
+// fill: integer atomics on B*N counters), it turns butd_sa_scatter_rows' 3.3e7 float atomics (SA2, B = 8) into plain
+// row reads.
+__global__ __launch_bounds__(kThreads) void sa_inv_count_kernel(int N, long npns, long P, const int *__restrict__ idx,
+                                                                int *__restrict__ count) {
+  for (long p = (long)blockIdx.x * kThreads + threadIdx.x; p < P; p += (long)gridDim.x * kThreads)
+    atomicAdd(count + (p / npns) * N + idx[p], 1);
+}
+
+// one workgroup per batch element: start[b*N + i] = b*npns + exclusive prefix of count; count is zeroed (the fill's cursor)
+__global__ __launch_bounds__(1024) void sa_inv_scan_kernel(int N, long npns, int *__restrict__ count, int *__restrict__ start,
+                                                           int last_batch) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int per = (N + 1023) / 1024, i0 = t * per, i1 = min(N, i0 + per);
+  int s = 0;
+  for (int i = i0; i < i1; ++i) s += count[(long)b * N + i];
+  part[t] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {           // inclusive scan of the 1024 partial sums
+    const int v = t >= d ? part[t - d] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = (int)((long)b * npns) + (t ? part[t - 1] : 0);
+  for (int i = i0; i < i1; ++i) {
+    const int c = count[(long)b * N + i];
+    start[(long)b * N + i] = run;
+    count[(long)b * N + i] = 0;
+    run += c;
+  }
+  if (b == last_batch && t == 0) start[(long)(b + 1) * N] = (int)((long)(b + 1) * npns);
+}
+
+__global__ __launch_bounds__(kThreads) void sa_inv_fill_kernel(int N, long npns, long P, const int *__restrict__ idx,
+                                                               int *__restrict__ cursor, const int *__restrict__ start,
+                                                               int *__restrict__ list) {
+  for (long p = (long)blockIdx.x * kThreads + threadIdx.x; p < P; p += (long)gridDim.x * kThreads) {
+    const long i = (p / npns) * N + idx[p];
+    list[start[i] + atomicAdd(cursor + i, 1)] = (int)p;
+  }
+}
+
+// thread = one point: its slice sorted ascending (Shell sort in place: slices are ~16 entries, a dense cluster may make one
+// thousands long) -- the lists, and with them the order of the gather's sums, are then the same on every run
+__global__ __launch_bounds__(kThreads) void sa_inv_sort_kernel(long R, const int *__restrict__ start, int *__restrict__ list) {
+  const long r = (long)blockIdx.x * kThreads + threadIdx.x;
+  if (r >= R) return;
+  int *a = list + start[r];
+  const int n = start[r + 1] - start[r];
+  const int gaps[8] = {701, 301, 132, 57, 23, 10, 4, 1};
+  for (int gi = 0; gi < 8; ++gi) {
+    const int gap = gaps[gi];
+    for (int i = gap; i < n; ++i) {
+      const int v = a[i];
+      int j = i;
+      for (; j >= gap && a[j - gap] > v; j -= gap) a[j] = a[j - gap];
+      a[j] = v;
+    }
+  }
+}
+
+// thread = (point row, column); rows_per_block = kThreads / C
+__global__ __launch_bounds__(kThreads) void sa_gather_rows_kernel(long R, int C, const float *__restrict__ dX, int ldx,
+                                                                  const int *__restrict__ start,
+                                                                  const int *__restrict__ list,
+                                                                  float *__restrict__ d_feats) {
+  const int c = threadIdx.x % C;
+  const long r = (long)blockIdx.x * (kThreads / C) + threadIdx.x / C;
+  if (r >= R) return;
+  const int a = start[r], b = start[r + 1];
+  float acc = 0.f;
+  int j = a;
+  for (; j + 3 < b; j += 4) {
+    const int p0 = list[j], p1 = list[j + 1], p2 = list[j + 2], p3 = list[j + 3];
+    const float v0 = dX[(long)p0 * ldx + 3 + c], v1 = dX[(long)p1 * ldx + 3 + c], v2 = dX[(long)p2 * ldx + 3 + c],
+                v3 = dX[(long)p3 * ldx + 3 + c];
+    acc += (v0 + v1) + (v2 + v3);
+  }
+  for (; j < b; ++j) acc += dX[(long)list[j] * ldx + 3 + c];
+  d_feats[r * C + c] = acc;
+}
+
 }  // namespace
 
 extern "C" {
@@ -574,6 +660,31 @@ int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, i
   if (total <= 0) return 0;
   hipLaunchKernelGGL(sa_scatter_rows_kernel, dim3(blocks_for(total, 65536)), dim3(kThreads), 0,
                      (hipStream_t)stream, N, np, ns, C, dX, idx, d_feats_pm, ldx, total);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_inverse_index(int B, int N, int np, int ns, const int *idx, int *count, int *start, int *list,
+                          butd_stream_t stream) {
+  const long npns = (long)np * ns, P = (long)B * npns;
+  if (P <= 0) return 0;
+  if (P >= (1L << 31) || N <= 0) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(sa_inv_count_kernel, dim3(blocks_for(P, 65536)), dim3(kThreads), 0, st, N, npns, P, idx, count);
+  hipLaunchKernelGGL(sa_inv_scan_kernel, dim3(B), dim3(1024), 0, st, N, npns, count, start, B - 1);
+  hipLaunchKernelGGL(sa_inv_fill_kernel, dim3(blocks_for(P, 65536)), dim3(kThreads), 0, st, N, npns, P, idx, count, start, list);
+  const long R = (long)B * N;
+  hipLaunchKernelGGL(sa_inv_sort_kernel, dim3((unsigned)((R + kThreads - 1) / kThreads)), dim3(kThreads), 0, st, R, start, list);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_gather_rows(int B, int N, int C, const float *dX, int ldx, const int *start, const int *list,
+                        float *d_feats_pm, butd_stream_t stream) {
+  const long R = (long)B * N;
+  if (R <= 0 || C <= 0) return 0;
+  if (ldx < 3 + C || C > kThreads || kThreads % C) return (int)hipErrorInvalidValue;
+  const int rpb = kThreads / C;
+  hipLaunchKernelGGL(sa_gather_rows_kernel, dim3((unsigned)((R + rpb - 1) / rpb)), dim3(kThreads), 0, (hipStream_t)stream, R, C,
+                     dX, ldx, start, list, d_feats_pm);
   return (int)hipGetLastError();
 }
 

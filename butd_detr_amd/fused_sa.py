@@ -75,6 +75,21 @@ def _last_scratch(P, C2, C3):
     return _scratch_sizes[key]
 
 
+_GATHER = [os.environ.get("BUTD_SA_GATHER", "1") != "0"]      # feature gradient as a gather over the inverted neighbour lists
+
+
+def inverse_index(idx, N):
+    """(start (B*N + 1,) int32, list (B*np*ns,) int32): for every input point the grouped rows that copy it
+    (include/butd_sa.h, butd_sa_inverse_index).  Coordinates only: Pointnet2Backbone.plan prefetches it."""
+    B, np_, ns = idx.shape
+    dev = idx.device
+    count = torch.zeros(B * N, dtype=torch.int32, device=dev)      # (not the step arena: this also runs on the prefetch stream)
+    start = torch.empty(B * N + 1, dtype=torch.int32, device=dev)
+    lst = torch.empty(B * np_ * ns, dtype=torch.int32, device=dev)
+    _call("butd_sa_inverse_index", idx, B, N, np_, ns, idx.data_ptr(), count.data_ptr(), start.data_ptr(), lst.data_ptr())
+    return start, lst
+
+
 def _first_scratch(P, C1, Kp):
     key = ("first", P, C1, Kp)
     if key not in _scratch_sizes:
@@ -92,7 +107,7 @@ class _SAMlpPool(torch.autograd.Function):
                 w1, g1, b1, rm1, rv1, nbt1, eps1,
                 w2, g2, b2, rm2, rv2, nbt2, eps2,
                 w3, g3, b3, rm3, rv3, nbt3, eps3,
-                feat_ptr_offset, feat_stride):
+                feat_ptr_offset, feat_stride, inv_start=None, inv_list=None):
         B, N, _ = xyz.shape
         np_, ns = idx.shape[1], idx.shape[2]
         C = 0 if feats_pm is None else (feats_pm.shape[-1] - feat_ptr_offset)
@@ -178,6 +193,7 @@ class _SAMlpPool(torch.autograd.Function):
                               g1, g2, g3)
         ctx.cfg = (B, N, np_, ns, C, bool(training), feats_pm is not None and feats_pm.requires_grad,
                    w1.shape, w2.shape, w3.shape, Cin, lin)
+        ctx.inv = (inv_start, inv_list) if inv_start is not None else None
         return out_cm, out_pm
 
     @staticmethod
@@ -257,9 +273,15 @@ class _SAMlpPool(torch.autograd.Function):
             if need_dfeat:
                 dX = torch.empty((P, Kp), device=dev)
                 _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp), _dgrad(dZ1, w1, dX, P, C1, Kp)], X)
-                d_feats = zeros((B, N, C), device=dev)
-                _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), Kp, idx.data_ptr(),
-                      d_feats.data_ptr())
+                if _GATHER[0] and C <= 256 and 256 % C == 0:
+                    start, lst = ctx.inv if ctx.inv is not None else inverse_index(idx, N)
+                    d_feats = torch.empty((B, N, C), device=dev)
+                    _call("butd_sa_gather_rows", X, B, N, C, dX.data_ptr(), Kp, start.data_ptr(), lst.data_ptr(),
+                          d_feats.data_ptr())
+                else:
+                    d_feats = zeros((B, N, C), device=dev)
+                    _call("butd_sa_scatter_rows", X, B, N, np_, ns, C, dX.data_ptr(), Kp, idx.data_ptr(),
+                          d_feats.data_ptr())
             else:
                 _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp)], X)
         dW1 = dW1[:, :Cin]
@@ -272,7 +294,7 @@ class _SAMlpPool(torch.autograd.Function):
                 dW1.reshape(s1), dgs[0], dbs[0], None, None, None, None,
                 dW2.view(s2), dgs[1], dbs[1], None, None, None, None,
                 dW3.view(s3), dgs[2], dbs[2], None, None, None, None,
-                None, None)
+                None, None, None, None)
 
 
 def supported(module, xyz, features_pm):
@@ -338,7 +360,7 @@ def sa_fused_eval(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0):
     return out_cm, out_pm
 
 
-def sa_mlp_pool(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0):
+def sa_mlp_pool(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0, inv=None):
     """-> (new_features (B,C,npoint), new_features_pm (B,npoint,C)).  ``features_pm``: point-major
     (B,N,offset+C) tensor whose last C columns are the per-point features (for SA1 the raw point cloud
     with offset 3)."""
@@ -355,4 +377,4 @@ def sa_mlp_pool(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0):
     stride = 0 if features_pm is None else features_pm.shape[-1]
     return _SAMlpPool.apply(xyz.contiguous(), None if features_pm is None else features_pm.contiguous(),
                             new_xyz.contiguous(), idx, module.radius, module.normalize_xyz, training,
-                            momentum, *args, feat_offset, stride)
+                            momentum, *args, feat_offset, stride, *(inv if inv is not None else (None, None)))

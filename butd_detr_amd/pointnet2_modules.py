@@ -51,12 +51,14 @@ class PointnetSAModuleVotes(nn.Module):
             return (feats * rbf.unsqueeze(1)).sum(-1) / float(self.nsample)
         raise ValueError(self.pooling)
 
-    def forward(self, xyz, features=None, inds=None, features_pm=None, feat_offset=0, new_xyz=None, ball_idx=None):
+    def forward(self, xyz, features=None, inds=None, features_pm=None, feat_offset=0, new_xyz=None, ball_idx=None,
+                ball_inv=None):
         """``features_pm`` (optional, not in the reference signature): the same features point-major,
         (B, N, feat_offset + C); lets consecutive levels hand activations over without a transpose.
         After the call ``self.last_features_pm`` holds this level's output point-major (or None).
         ``new_xyz`` / ``ball_idx`` (optional, with ``inds``): the sampled centres and the ball-query neighbour lists as
-        ``Pointnet2Backbone.plan`` precomputed them (coordinates only: prefetched for the next batch)."""
+        ``Pointnet2Backbone.plan`` precomputed them (coordinates only: prefetched for the next batch); ``ball_inv``: the
+        inverted neighbour lists (fused_sa.inverse_index) for the feature gradient."""
         self.last_features_pm = None
         if inds is None:
             inds = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
@@ -71,7 +73,7 @@ class PointnetSAModuleVotes(nn.Module):
             if features_pm is None and features is not None:
                 features_pm, feat_offset = features.transpose(1, 2).contiguous(), 0
             new_features, self.last_features_pm = fused_sa.sa_mlp_pool(
-                self, xyz, new_xyz, idx, features_pm, feat_offset)
+                self, xyz, new_xyz, idx, features_pm, feat_offset, inv=ball_inv)
             self.last_path = "fused"
             return new_xyz, new_features, inds
         if attention_blocks.get_backend() == "hip" and xyz.is_cuda:

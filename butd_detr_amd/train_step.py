@@ -594,11 +594,13 @@ class GraphedTrainStep:
         ``inds_cur`` is their concatenation), then centres, neighbour lists, interpolation indices and weights."""
         levels, fp = plan["levels"], plan["fp"]
         return ([l[0] for l in levels] + [l[1] for l in levels] + [l[2] for l in levels]
-                + [f[0] for f in fp] + [f[1] for f in fp])
+                + [f[0] for f in fp] + [f[1] for f in fp]
+                + [l[3][0] for l in levels[1:]] + [l[3][1] for l in levels[1:]])      # inverted neighbour lists, levels 2-4
 
     @staticmethod
     def _plan_from_pieces(pieces):
-        return {"levels": [(pieces[i], pieces[4 + i], pieces[8 + i]) for i in range(4)],
+        return {"levels": [(pieces[i], pieces[4 + i], pieces[8 + i], None if i == 0 else (pieces[15 + i], pieces[18 + i]))
+                           for i in range(4)],
                 "fp": [(pieces[12 + i], pieces[14 + i]) for i in range(2)]}
 
     def _sample_into_next(self):

@@ -140,6 +140,17 @@ int butd_sa_dz_mid(long P, int C, float *g, const float *Z, const float *gamma, 
 int butd_sa_scatter_rows(int B, int N, int np, int ns, int C, const float *dX, int ldx, const int *idx,
                          float *d_feats_pm, butd_stream_t stream);
 
+/* The same sum as a GATHER.  butd_sa_inverse_index inverts the neighbour lists idx (B,np,ns) over the level's N input points:
+ * start (B*N + 1 ints; start[b*N + i] .. start[b*N + i + 1] = the slice of `list` for point i of batch b) and list (B*np*ns
+ * ints: grouped row indices p, ascending inside a slice: the result is unique); count (B*N ints) is scratch, ZERO on entry,
+ * the slice lengths on return.  It depends on the coordinates alone: Pointnet2Backbone.plan builds it for the next batch off the critical
+ * path.  butd_sa_gather_rows then writes (not adds) d_feats_pm[b, i, c] = sum over the slice of dX[p, 3 + c]: no float
+ * atomics (butd_sa_scatter_rows issues B*np*ns*C of them: 3.3e7 at SA2, B = 8).  C <= 256 and 256 % C == 0. */
+int butd_sa_inverse_index(int B, int N, int np, int ns, const int *idx, int *count, int *start, int *list,
+                          butd_stream_t stream);
+int butd_sa_gather_rows(int B, int N, int C, const float *dX, int ldx, const int *start, const int *list,
+                        float *d_feats_pm, butd_stream_t stream);
+
 /* The whole set-abstraction level for INFERENCE in one kernel (csrc/sa_fused.hip): ball-query neighbourhoods
  * gathered into LDS tiles, three 1x1 convolutions with folded BatchNorm + ReLU run LDS -> MFMA -> LDS, max-pool
  * over nsample; only the pooled features are written.  Replaces QueryAndGroup + SharedMLP + F.max_pool2d

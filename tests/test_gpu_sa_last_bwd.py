@@ -189,3 +189,36 @@ def test_first_layer_without_input_gradient(cfg):
     for n in outs[False][2]:
         assert _err(outs[True][2][n], outs[False][2][n]) < 2e-5, (n, _err(outs[True][2][n], outs[False][2][n]))
         assert _err(outs[True][2][n], ref[2][n]) < 2e-5, n
+
+
+@pytest.mark.parametrize("cfg", CFGS[1:4])
+def test_feature_gradient_as_gather_equals_scatter(cfg):
+    """butd_sa_inverse_index + butd_sa_gather_rows vs butd_sa_scatter_rows (float atomics), and the inverse lists
+    themselves: every grouped row appears exactly once, in the slice of the point it copies."""
+    from butd_detr_amd import fused_sa, pointnet2_utils
+    m = _module(cfg, 31)
+    torch.manual_seed(37)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    outs = {}
+    for gather in (False, True):
+        prev = fused_sa._GATHER[0]
+        fused_sa._GATHER[0] = gather
+        try:
+            outs[gather] = _run(m, xyz, feats, probe, linear=True)
+        finally:
+            fused_sa._GATHER[0] = prev
+    assert _err(outs[True][1], outs[False][1]) < 1e-5
+    inds = pointnet2_utils.furthest_point_sample(xyz, cfg["npoint"])
+    new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    idx = pointnet2_utils.ball_query(cfg["radius"], cfg["nsample"], xyz, new_xyz)
+    start, lst = fused_sa.inverse_index(idx, cfg["N"])
+    start, lst, flat = start.cpu().numpy(), lst.cpu().numpy(), idx.reshape(cfg["B"], -1).cpu().numpy()
+    P = flat.size
+    assert start[0] == 0 and start[-1] == P and (np.diff(start) >= 0).all()
+    assert np.array_equal(np.sort(lst), np.arange(P))
+    owner = np.repeat(np.arange(cfg["B"] * cfg["N"]), np.diff(start))        # the point each list entry is filed under
+    per = flat.shape[1]
+    assert np.array_equal(owner, (lst // per) * cfg["N"] + flat.reshape(-1)[lst])
+    assert all((np.diff(lst[a:b]) > 0).all() for a, b in zip(start[:-1], start[1:]))      # ascending slices: unique result
