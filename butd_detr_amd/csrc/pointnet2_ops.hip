@@ -162,13 +162,14 @@ constexpr int kBqThreads = 256;
 
 template <int C>
 __global__ __launch_bounds__(kBqThreads) void ball_query_kernel(int n, int m, float radius2,
-                                                               int nsample, int waves_per_scene,
+                                                               int nsample, int waves_per_scene, int total_waves,
                                                                const float *__restrict__ new_xyz,
                                                                const float *__restrict__ xyz,
                                                                int *__restrict__ idx) {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave_in_block = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int gw = blockIdx.x * (kBqThreads / kWave) + wave_in_block;  // wave-uniform
+  if (gw >= total_waves) return;     // the last workgroup's spare waves: they would be centres of a scene past the batch
   const int scene = gw / waves_per_scene;
   const int j0 = (gw - scene * waves_per_scene) * C;
   if (j0 >= m) return;
@@ -513,7 +514,7 @@ int butd_ball_query(int b, int n, int m, float radius, int nsample, const float 
     const long long waves = (long long)wps * b;                                                \
     const int blocks = (int)((waves + (kBqThreads / kWave) - 1) / (kBqThreads / kWave));       \
     hipLaunchKernelGGL((ball_query_kernel<CC>), dim3(blocks), dim3(kBqThreads), 0, s, n, m,    \
-                       radius2, nsample, wps, new_xyz, xyz, idx);                              \
+                       radius2, nsample, wps, (int)waves, new_xyz, xyz, idx);                  \
   }
   switch (C) {
     case 8: BQ_LAUNCH(8) break;

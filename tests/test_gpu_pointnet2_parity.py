@@ -215,3 +215,29 @@ def test_stream_and_graph_capture(ext, oracle):
         a = ext.furthest_point_sampling(d, 128)
     s.synchronize()
     np.testing.assert_array_equal(a.cpu().numpy(), oracle.furthest_point_sampling(pts, 128))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,M", [(1, 700, 5), (3, 333, 7), (1, 64, 1), (5, 100, 3)])
+def test_ball_query_spare_waves_write_nothing(B, N, M):
+    """Round 4: a batch whose (scenes x centre groups) is not a multiple of the 4 waves of a workgroup left spare waves
+    that ran as centres of a scene PAST the batch -- reads of xyz and writes of idx beyond the tensors (found as a GPU
+    memory fault behind a 2 MB allocator block).  The result goes into the middle of a guarded buffer: the guards stay
+    intact and the indices equal the oracle's (ball_query_gpu.cu:14-49)."""
+    from butd_detr_amd import _hiplib
+    from oracle import ext_adapter as orc_ext
+    lib = _hiplib.load()
+    torch.manual_seed(B * 1000 + M)
+    ns, radius = 64, 0.5
+    xyz = torch.rand(B, N, 3, device="cuda") * 2 - 1
+    ctr = xyz[:, :M].contiguous()
+    guard = 4096
+    buf = torch.full((guard + B * M * ns + guard,), -7, dtype=torch.int32, device="cuda")
+    out = buf[guard:guard + B * M * ns]
+    err = lib.butd_ball_query(B, N, M, radius, ns, ctr.data_ptr(), xyz.data_ptr(), out.data_ptr(),
+                              torch.cuda.current_stream().cuda_stream)
+    assert err == 0
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == -7).all()) and bool((buf[guard + B * M * ns:] == -7).all())
+    want = orc_ext.ball_query(ctr.cpu(), xyz.cpu(), radius, ns)
+    assert torch.equal(out.view(B, M, ns).cpu(), want.to(torch.int32))
