@@ -926,6 +926,191 @@ __global__ void sa_first_dw_kernel(int C, long P, int ldw, const float *__restri
   }
 }
 
+// ------------------------------------------- SA1: layer 2 and layer 1 backward in one pass, nothing written per row
+// With no input gradient wanted (SA1) everything below layer 2's gated gradient g2 ends in reductions:
+//   dZ2 = s2 (g2 - m1 - zhat2 m2)          (m1, m2: the sums butd_sa_last_bwd left behind)
+//   dW2 = dZ2^T H1                          (64 x 64, matrix cores)
+//   dH1 = dZ2 W2  ->  g1 = dH1 gated by layer 1's ReLU  ->  S1, S2 of layer 1, GX = g1^T X (64 x 8), SX, XX
+// so one pass over (g2, Z2, Z1, X) per 64-row block -- dZ2 tile and H1 tile in LDS, both products on the matrix cores,
+// the fold of g1 per thread -- replaces butd_sa_dz_mid (writes dZ2), the weight- / input-gradient product pair (reads
+// it twice, writes dH1) and the sa_first_stats pass (reads dH1): 2.45 GB -> 0.84 GB at SA1, B = 8.
+template <int C>
+__global__ __launch_bounds__(256) void sa_mid_first_kernel(
+    long P, long nblk, const float *__restrict__ G2, const float *__restrict__ Z2, const float *__restrict__ Z1,
+    const float *__restrict__ X, const float *__restrict__ gamma2, const float *__restrict__ sc2,
+    const float *__restrict__ sh2, const float *__restrict__ mean2, const float *__restrict__ rstd2,
+    const double *__restrict__ S1_2, const double *__restrict__ S2_2, const float *__restrict__ sc1,
+    const float *__restrict__ sh1, const float *__restrict__ mean1, const float *__restrict__ rstd1,
+    const float *__restrict__ W2, float *__restrict__ ws_w, float *__restrict__ ws, long ws_stride) {
+  static_assert(C == 64, "SA1: 64-wide layers");
+  constexpr int KP = 8, NW = 4;
+  constexpr int ST = C + 36, SO = C + 4, KG = C / 16, GN = C / 16, QN = C / 4, RP = 256 / QN, NP = kRows / RP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Dt = lds;                   // [64][ST]  dZ2
+  float *Ht = Dt + kRows * ST;       // [64][ST]  H1
+  float *Os = Ht + kRows * ST;       // [64][SO]  dH1
+  float *Xs = Os + kRows * SO;       // [64][KP]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
+  const int q = tid % QN, rsub = tid / QN;
+  const int n0 = wave * 16;
+  // dH1^T tile = W2^T (A operand: rows = columns k of W2, contraction over c) x dZ2^T
+  f4 areg[KG];
+#pragma unroll
+  for (int g = 0; g < KG; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[g][i] = W2[(long)(16 * g + 4 * lq + i) * C + n0 + lm];
+  f4 wacc[GN];                       // dW2 rows n0 .. n0 + 16 (channels c of layer 2), all 64 columns
+#pragma unroll
+  for (int n = 0; n < GN; ++n) wacc[n] = f4{0.f, 0.f, 0.f, 0.f};
+  const double invP = 1.0 / (double)P;
+  f4 ga, s2c, h2c, mu2, rs2, a1, a2, s1c, h1c, mu1, rs1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
+    ga[e] = gamma2[c]; s2c[e] = sc2[c]; h2c[e] = sh2[c]; mu2[e] = mean2[c]; rs2[e] = rstd2[c];
+    a1[e] = (float)(S1_2[c] * invP); a2[e] = (float)(S2_2[c] * invP);
+    s1c[e] = sc1[c]; h1c[e] = sh1[c]; mu1[e] = mean1[c]; rs1[e] = rstd1[c];
+  }
+  float gx[4][KP];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < KP; ++k) gx[e][k] = 0.f;
+  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  float sxr = 0.f, xxr[KP];          // threads q < KP: row q of X^T X and SX[q]
+#pragma unroll
+  for (int k = 0; k < KP; ++k) xxr[k] = 0.f;
+  f4 gn[NP], z2n[NP], z1n[NP];
+  float xn = 0.f;                    // thread t < 128: X element (row t / 8 ... two rounds)
+  float xn2 = 0.f;
+  auto fetch = [&](long b) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long p = b * kRows + rsub + ps * RP;
+      const bool in = p < P;
+      gn[ps] = in ? *reinterpret_cast<const f4 *>(G2 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+      z2n[ps] = in ? *reinterpret_cast<const f4 *>(Z2 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+      z1n[ps] = in ? *reinterpret_cast<const f4 *>(Z1 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+    const long e0 = b * kRows * KP + tid, e1 = e0 + 256;          // the block's 64 x 8 inputs: two per thread
+    xn = e0 < P * KP ? X[e0] : 0.f;
+    xn2 = e1 < P * KP ? X[e1] : 0.f;
+  };
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+    f4 zk1[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const bool in = blk * kRows + r < P;
+      zk1[ps] = z1n[ps];
+      f4 d, h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gv = s2c[e] * z2n[ps][e] + h2c[e] > 0.f ? gn[ps][e] : 0.f;      // (idempotent: g2 arrives gated)
+        d[e] = in ? ga[e] * rs2[e] * (gv - a1[e] - (z2n[ps][e] - mu2[e]) * rs2[e] * a2[e]) : 0.f;
+        h[e] = in ? fmaxf(s1c[e] * z1n[ps][e] + h1c[e], 0.f) : 0.f;
+      }
+      *reinterpret_cast<f4 *>(Dt + r * ST + 4 * q) = d;
+      *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+    }
+    Xs[tid] = xn;
+    Xs[tid + 256] = xn2;
+    __syncthreads();
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+    // ---- dH1^T tiles (16 columns of this wave x 16 rows) -> LDS
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const f4 dv = *reinterpret_cast<const f4 *>(Dt + (16 * rt + lm) * ST + 16 * g + 4 * lq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc = mfma4(areg[g][i], dv[i], oacc);
+      }
+      *reinterpret_cast<f4 *>(Os + (16 * rt + lm) * SO + n0 + 4 * lq) = oacc;
+    }
+    // ---- dW2[c = n0 + .., k] += sum_r dZ2[r, c] H1[r, k]
+#pragma unroll 4
+    for (int s = 0; s < kRows / 4; ++s) {
+      const float a = Dt[(4 * s + lq) * ST + n0 + lm];
+      const float *hrow = Ht + (4 * s + lq) * ST + lm;
+      float b[GN];
+#pragma unroll
+      for (int n = 0; n < GN; ++n) b[n] = hrow[16 * n];
+#pragma unroll
+      for (int n = 0; n < GN; ++n) wacc[n] = mfma4(a, b[n], wacc[n]);
+    }
+    __syncthreads();
+    // ---- g1 = dH1 gated; layer-1 sums; GX += g1^T X; SX, XX
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      if (blk * kRows + r < P) {
+        const f4 o = *reinterpret_cast<const f4 *>(Os + r * SO + 4 * q);
+        const f4 xa = *reinterpret_cast<const f4 *>(Xs + r * KP), xb = *reinterpret_cast<const f4 *>(Xs + r * KP + 4);
+        const float x[KP] = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float g = s1c[e] * zk1[ps][e] + h1c[e] > 0.f ? o[e] : 0.f;
+          s1[e] += g;
+          s2[e] += g * (zk1[ps][e] - mu1[e]) * rs1[e];
+#pragma unroll
+          for (int k = 0; k < KP; ++k) gx[e][k] += g * x[k];
+        }
+        if (q < KP) {
+          const float xc = q < 4 ? xa[q & 3] : xb[q & 3];
+          sxr += xc;
+#pragma unroll
+          for (int k2 = 0; k2 < KP; ++k2) xxr[k2] += xc * x[k2];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // ---- partials: dW2 (C x C) per workgroup; then the first-layer block [C][KP + 2] | SX | XX (layout of sa_first_stats)
+  float *ow = ws_w + (long)blockIdx.x * C * C;
+#pragma unroll
+  for (int n = 0; n < GN; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ow[(long)(n0 + 4 * lq + i) * C + 16 * n + lm] = wacc[n][i];
+  constexpr int W = KP + 2;
+  float *red = lds;                                  // [RP][C][W] = 16 * 64 * 10 floats = 40 KB (Dt + Ht hold 51 KB)
+  float *redx = red + (long)RP * C * W;              // [RP][KP + KP*KP]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float *o = red + ((long)rsub * C + 4 * q + e) * W;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) o[k] = gx[e][k];
+    o[KP] = s1[e];
+    o[KP + 1] = s2[e];
+  }
+  if (q < KP) {
+    float *o = redx + (long)rsub * (KP + KP * KP);
+    o[q] = sxr;
+#pragma unroll
+    for (int k2 = 0; k2 < KP; ++k2) o[KP + q * KP + k2] = xxr[k2];
+  }
+  __syncthreads();
+  float *out = ws + (long)blockIdx.x * ws_stride;
+  for (int i = tid; i < C * W; i += 256) {
+    float a = 0.f;
+    for (int t = 0; t < RP; ++t) a += red[(long)t * C * W + i];
+    out[i] = a;
+  }
+  for (int i = tid; i < KP + KP * KP; i += 256) {
+    float a = 0.f;
+    for (int t = 0; t < RP; ++t) a += redx[(long)t * (KP + KP * KP) + i];
+    out[C * W + i] = a;
+  }
+}
+
+__global__ void sa_d2f_kernel(const double *__restrict__ src, float *__restrict__ dst, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+
 template <int C2, int C3>
 constexpr size_t sparse_lds() { return (size_t)(2 * kRows * (C2 + 4)) * sizeof(float); }
 
@@ -1013,6 +1198,40 @@ int butd_sa_first_bwd(long P, int C1, int Kp, const float *dH1, const float *Z1,
   hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((per + 15) / 16)), dim3(256), 0, st, ws_f, per, (int)blocks,
                      (const float *)nullptr, 0L, 0, ws_d);
   hipLaunchKernelGGL(sa_first_dw_kernel<8>, dim3(C1), dim3(Kp), 0, st, C1, P, Kp, W1, scale1, rstd1, ws_d, dW1, S1, S2);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_mid_first_bwd_scratch(long P, int C, int Kp, long *ws_floats, long *ws_doubles) {
+  if (P <= 0 || !ws_floats || !ws_doubles || Kp != 8 || C != 64) return (int)hipErrorInvalidValue;
+  const long per = (long)C * (Kp + 2) + Kp + Kp * Kp;
+  *ws_floats = 512L * ((long)C * C + per);
+  *ws_doubles = (long)C * C + per;
+  return 0;
+}
+
+int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z2, const float *Z1, const float *X,
+                          const float *gamma2, const float *scale2, const float *shift2, const float *mean2,
+                          const float *rstd2, const double *S1_2, const double *S2_2, const float *scale1,
+                          const float *shift1, const float *mean1, const float *rstd1, const float *W2, const float *W1,
+                          float *dW2, float *dW1, double *S1_1, double *S2_1, float *ws_f, double *ws_d,
+                          butd_stream_t stream) {
+  if (P <= 0) return 0;
+  if (Kp != 8 || C != 64) return (int)hipErrorInvalidValue;
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mid_first_kernel<64>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return (int)attr;
+  hipStream_t st = (hipStream_t)stream;
+  const long nblk = (P + kRows - 1) / kRows;
+  const int grid = (int)(nblk < 512 ? nblk : 512);
+  const long per = (long)C * (Kp + 2) + Kp + Kp * Kp, nw = (long)C * C;
+  float *ws_w = ws_f, *ws_p = ws_f + (long)grid * nw;
+  const size_t lds = (size_t)(2 * kRows * (C + 36) + kRows * (C + 4) + kRows * Kp) * sizeof(float);
+  hipLaunchKernelGGL(sa_mid_first_kernel<64>, dim3(grid), dim3(256), lds, st, P, nblk, G2, Z2, Z1, X, gamma2, scale2, shift2,
+                     mean2, rstd2, S1_2, S2_2, scale1, shift1, mean1, rstd1, W2, ws_w, ws_p, per);
+  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((nw + per + 15) / 16)), dim3(256), 0, st, ws_w, nw, grid, ws_p, per,
+                     grid, ws_d);
+  hipLaunchKernelGGL(sa_d2f_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, ws_d, dW2, nw);
+  hipLaunchKernelGGL(sa_first_dw_kernel<8>, dim3(C), dim3(Kp), 0, st, C, P, Kp, W1, scale1, rstd1, ws_d + nw, dW1, S1_1, S2_1);
   return (int)hipGetLastError();
 }
 

@@ -36,6 +36,7 @@ def _call(name, ref, *args):
 _LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
 _LAST_FWD = [os.environ.get("BUTD_SA_LAST_FWD", "1") != "0"]      # ... and the forward that does not write Z3
 _FIRST_LIN = [os.environ.get("BUTD_SA_FIRST_BWD", "1") != "0"]     # ... and the first layer's, where no input gradient is wanted
+_MID_FIRST = [os.environ.get("BUTD_SA_MID_BWD", "1") != "0"]       # ... with layer 2's backward in the same pass (64-wide levels)
 _scratch_sizes = {}
 _sched = {}
 
@@ -88,6 +89,17 @@ def inverse_index(idx, N):
     lst = torch.empty(B * np_ * ns, dtype=torch.int32, device=dev)
     _call("butd_sa_inverse_index", idx, B, N, np_, ns, idx.data_ptr(), count.data_ptr(), start.data_ptr(), lst.data_ptr())
     return start, lst
+
+
+def _mid_scratch(P, C, Kp):
+    key = ("mid", P, C, Kp)
+    if key not in _scratch_sizes:
+        import ctypes
+        nf, nd = ctypes.c_long(0), ctypes.c_long(0)
+        _hiplib.check(_lib.butd_sa_mid_first_bwd_scratch(P, C, Kp, ctypes.byref(nf), ctypes.byref(nd)),
+                      "butd_sa_mid_first_bwd_scratch")
+        _scratch_sizes[key] = (nf.value, nd.value)
+    return _scratch_sizes[key]
 
 
 def _first_scratch(P, C1, Kp):
@@ -246,6 +258,19 @@ class _SAMlpPool(torch.autograd.Function):
             _call("butd_sa_mask_stats", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), scale(1).data_ptr(),
                   shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(),
                   S[1, 1].data_ptr())
+        first_lin = lin and not need_dfeat and Kp == 8 and _FIRST_LIN[0]
+        d_feats = None
+        if first_lin and _MID_FIRST[0] and C1 == 64 and C2 == 64:
+            # layers 2 and 1 in one pass over (g2, Z2, Z1, X): dW2, dW1 and layer 1's sums, nothing written per row
+            nf, nd = _mid_scratch(P, C1, Kp)
+            ws_f = torch.empty(nf, device=dev)
+            ws_d = torch.empty(nd, dtype=torch.float64, device=dev)
+            _call("butd_sa_mid_first_bwd", X, P, C1, Kp, dH2.data_ptr(), Z2.data_ptr(), Z1.data_ptr(), X.data_ptr(),
+                  g2.data_ptr(), scale(1).data_ptr(), shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(),
+                  S[1, 0].data_ptr(), S[1, 1].data_ptr(), scale(0).data_ptr(), shift(0).data_ptr(), mean(0).data_ptr(),
+                  rstd(0).data_ptr(), w2.data_ptr(), w1.data_ptr(), dW2.data_ptr(), dW1.data_ptr(), S[0, 0].data_ptr(),
+                  S[0, 1].data_ptr(), ws_f.data_ptr(), ws_d.data_ptr())
+            return _SAMlpPool._finish(ctx, S, dW1, dW2, dW3, None, (C1, C2, C3), (s1, s2, s3), Cin)
         _call("butd_sa_dz_mid", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), g2.data_ptr(), scale(1).data_ptr(),
               shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
         dZ2 = dH2
@@ -253,8 +278,6 @@ class _SAMlpPool(torch.autograd.Function):
         _gemm([_wgrad(dZ2, Z1, dW2, None, P, C2, C1, b_affine=(scale(0), shift(0))),
                _dgrad(dZ2, w2, dH1, P, C2, C1)], X)
         # ---- layer 1
-        first_lin = lin and not need_dfeat and Kp == 8 and _FIRST_LIN[0]
-        d_feats = None
         if first_lin:
             # no input gradient wanted (SA1): the sums and dW1 from one pass over (dH1, Z1, X) -- no dZ1, no thin product
             nf, nd = _first_scratch(P, C1, Kp)
@@ -284,6 +307,12 @@ class _SAMlpPool(torch.autograd.Function):
                           d_feats.data_ptr())
             else:
                 _gemm([_wgrad(dZ1, X, dW1, None, P, C1, Kp)], X)
+        return _SAMlpPool._finish(ctx, S, dW1, dW2, dW3, d_feats, (C1, C2, C3), (s1, s2, s3), Cin)
+
+    @staticmethod
+    def _finish(ctx, S, dW1, dW2, dW3, d_feats, widths, shapes, Cin):
+        C1, C2, C3 = widths
+        s1, s2, s3 = shapes
         dW1 = dW1[:, :Cin]
         Sf = S.float()
         # S1 = sum g, S2 = sum g*zhat with zhat from the statistics the forward used (batch or running):

@@ -123,6 +123,20 @@ int butd_sa_first_bwd(long P, int C1, int Kp, const float *dH1, const float *Z1,
                       const float *shift1, const float *mean1, const float *rstd1, const float *W1, float *dW1,
                       double *S1, double *S2, float *ws_f, double *ws_d, butd_stream_t stream);
 
+/* SA1 (no input gradient, 64-wide layers, 8 grouped input columns, training mode): layer 2's AND layer 1's backward from
+ * layer 2's gated gradient G2 (what butd_sa_last_bwd wrote) in ONE pass over (G2, Z2, Z1, X), with no per-row output:
+ *   dZ2 = gamma2 rstd2 (g2 - S1_2/P - zhat2 S2_2/P);  dW2 (C x C) = dZ2^T H1;  dH1 = dZ2 W2;  g1 = dH1 gated by layer 1;
+ *   S1_1, S2_1 (written) and dW1 (C x 8) as butd_sa_first_bwd gives them.
+ * Replaces butd_sa_dz_mid + the layer's weight- / input-gradient products + butd_sa_first_bwd (2.45 GB -> 0.84 GB at the
+ * bench size).  Partials per workgroup, summed in double: no atomics. */
+int butd_sa_mid_first_bwd_scratch(long P, int C, int Kp, long *ws_floats, long *ws_doubles);
+int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z2, const float *Z1, const float *X,
+                          const float *gamma2, const float *scale2, const float *shift2, const float *mean2,
+                          const float *rstd2, const double *S1_2, const double *S2_2, const float *scale1,
+                          const float *shift1, const float *mean1, const float *rstd1, const float *W2, const float *W1,
+                          float *dW2, float *dW1, double *S1_1, double *S2_1, float *ws_f, double *ws_d,
+                          butd_stream_t stream);
+
 /* Hidden layers, part 1 (read-only pass over dH, Z (P x C)): with g = dH * [scale*z+shift > 0],
  * S1[c] += sum_p g, S2[c] += sum_p g*zhat (double, caller zero-fills). */
 int butd_sa_mask_stats(long P, int C, const float *dH, const float *Z, const float *scale,

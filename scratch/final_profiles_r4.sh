@@ -24,7 +24,7 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     if r.get("Counter_Name") != "$C": continue
     name = r["Kernel_Name"]
-    key = next((k for k in ("gemm_kernel", "ball_query_kernel", "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "fps_pruned", "bq_grid_query", "lsap_kernel", "ln_bwd_kernel", "sa_colstats", "sa_mask_stats", "sa_dz_mid", "sa_dz_last") if k in name), None)
+    key = next((k for k in ("gemm_kernel", "ball_query_kernel", "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "fps_pruned", "bq_grid_query", "lsap_kernel", "ln_bwd_kernel", "sa_colstats", "sa_mask_stats", "sa_dz_mid", "sa_dz_last", "sa_last_fwd", "sa_last_fused", "sa_last_mfma", "sa_last_sparse", "sa_first_stats", "sa_gather_rows") if k in name), None)
     if key:
         agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
 out = {k: {"launches": c, "avg_$C": v / c} for k, (c, v) in agg.items()}

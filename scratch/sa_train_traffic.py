@@ -25,9 +25,10 @@ new_xyz = torch.gather(src_xyz, 1, inds.long()[..., None].expand(-1, -1, 3)).con
 idx = pointnet2_utils.ball_query(m.radius, m.nsample, src_xyz, new_xyz)
 feats_pm = feats_pm.clone().requires_grad_(level != 1)
 probe = torch.randn(8, np_, m.mlp_module[-1].conv.out_channels, device=dev)
+inv = fused_sa.inverse_index(idx, src_xyz.shape[1]) if level != 1 else None      # (coordinates only: from the prefetched plan in the step)
 def step():
     for p in m.parameters(): p.grad = None
-    out_cm, out_pm = fused_sa.sa_mlp_pool(m, src_xyz, new_xyz, idx, feats_pm, off)
+    out_cm, out_pm = fused_sa.sa_mlp_pool(m, src_xyz, new_xyz, idx, feats_pm, off, inv=inv)
     (out_pm * probe).sum().backward()
 def tg(fn, reps=3):
     fn(); torch.cuda.synchronize()

@@ -177,18 +177,21 @@ def test_first_layer_without_input_gradient(cfg):
     feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
     probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
     outs = {}
-    for first in (False, True):
-        prev = fused_sa._FIRST_LIN[0]
-        fused_sa._FIRST_LIN[0] = first
+    # False: mask_stats + dz_mid + thin product;  True: butd_sa_first_bwd;  "mid": butd_sa_mid_first_bwd (layers 2 AND 1 in
+    # one pass over (g2, Z2, Z1, X): also no dZ2, no dH1)
+    for first, mid in ((False, False), (True, False), (True, True)):
+        prev = fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0]
+        fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0] = first, mid
         try:
-            outs[first] = _run(m, xyz, feats, probe, linear=True, input_grad=False)
+            outs["mid" if mid else first] = _run(m, xyz, feats, probe, linear=True, input_grad=False)
         finally:
-            fused_sa._FIRST_LIN[0] = prev
+            fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0] = prev
     ref = _run(m, xyz, feats, probe, linear=True, input_grad=True)
-    assert torch.equal(outs[True][0], outs[False][0])
+    assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs["mid"][0], outs[False][0])
     for n in outs[False][2]:
-        assert _err(outs[True][2][n], outs[False][2][n]) < 2e-5, (n, _err(outs[True][2][n], outs[False][2][n]))
-        assert _err(outs[True][2][n], ref[2][n]) < 2e-5, n
+        for k in (True, "mid"):
+            assert _err(outs[k][2][n], outs[False][2][n]) < 2e-5, (k, n, _err(outs[k][2][n], outs[False][2][n]))
+            assert _err(outs[k][2][n], ref[2][n]) < 2e-5, (k, n)
 
 
 @pytest.mark.parametrize("cfg", CFGS[1:4])
