@@ -175,7 +175,9 @@ def _rocprof_kernel_stats(argv, kernel, timeout=600):
         if res.returncode != 0 or not files:
             raise RuntimeError(f"rocprofv3 child failed (rc {res.returncode}): {res.stderr[-400:]}")
         calls, total = 0, 0
+        _LAST_CHILD_ROWS.clear()
         for row in csv.DictReader(open(files[0])):
+            _LAST_CHILD_ROWS.append((row["Name"], int(row["Calls"]), int(row["TotalDurationNs"])))
             if kernel in row["Name"]:
                 calls += int(row["Calls"])
                 total += int(row["TotalDurationNs"])
@@ -183,6 +185,47 @@ def _rocprof_kernel_stats(argv, kernel, timeout=600):
         return calls, total, (json.loads(lines[-1]) if lines else {})
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
+
+
+_LAST_CHILD_ROWS = []        # (kernel name, calls, total ns) of the last rocprofv3 child: gemm_roofline's trace, reused below
+
+
+def sa_linear_roofline(args, gemm):
+    """The set-abstraction products that left ``gemm_kernel`` in round 4 (csrc/sa_last_bwd.hip: the last layer + max-pool
+    forward without Z3, its backward by linearity, SA1's layer 2 + layer 1 backward in one pass) -- durations from the SAME
+    child trace as ``roofline``; flops = what these kernels execute on the matrix cores (forward 2 P C2 C3; backward
+    4 P C2^2: H.A and the Gram matrix; SA1's lower pass 4 P C^2), bytes = their algorithmic HBM traffic (Z2 read per pass,
+    the gated gradient written once, SA1's lower pass reads g2, Z2, Z1, X).  Also the matrix-core rate of gemm_kernel and
+    these kernels TOGETHER: the figure comparable with round 3's ``roofline.frac`` (the 10^5..10^6-row products, the most
+    efficient launches of gemm_kernel, are the ones that moved)."""
+    if not _LAST_CHILD_ROWS or not gemm.get("launches_per_step"):
+        return None
+    names = ("sa_last_fwd_kernel", "sa_last_fused_kernel", "sa_last_mfma_kernel", "sa_last_sparse_kernel", "sa_mid_first_kernel")
+    gemm_calls = sum(c for n, c, _ in _LAST_CHILD_ROWS if "gemm_kernel" in n)
+    steps = gemm_calls / gemm["launches_per_step"]            # steps in the child's trace
+    per = {k: sum(t for n, _, t in _LAST_CHILD_ROWS if k in n) / steps * 1e-6 for k in names}     # ms per step
+    ms = sum(per.values())
+    if ms <= 0:
+        return None
+    B, npts = args.batch, args.points
+    levels = [(B * 2048 * 64, 64, 128), (B * 1024 * 32, 128, 256), (B * 512 * 16, 128, 256), (B * 256 * 16, 128, 256)]
+    flops = sum(2.0 * P * c2 * c3 + 4.0 * P * c2 * c2 for P, c2, c3 in levels) + 4.0 * levels[0][0] * 64 * 64
+    bytes_ = sum(4.0 * P * c2 * (1 + 2) for P, c2, _ in levels)           # forward reads Z2; backward reads Z2, writes g2
+    bytes_ += sum(4.0 * P * c2 * 2 for P, c2, _ in levels[1:])            # 128-wide levels: two-kernel backward (O round trip)
+    bytes_ += 4.0 * levels[0][0] * (3 * 64 + 8)                           # SA1 lower pass
+    both_ms = ms + gemm["ms_per_step_in_kernel"]
+    both = (flops + gemm["algorithmic_flops_per_step"]) / (both_ms * 1e-3) / 1e12
+    return {"kernel": "sa_last_fwd / sa_last_fused / sa_last_mfma + sa_last_sparse / sa_mid_first (set-abstraction last layer + "
+                      "max-pool by linearity, SA1 lower layers: the products that left gemm_kernel)",
+            "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TF, 4), "traffic": None,
+            "ms_per_step_in_kernels": round(ms, 3), "ms_per_kernel": {k: round(v, 3) for k, v in per.items()},
+            "matrix_flops_per_step": flops, "algorithmic_bytes_per_step": bytes_,
+            "hbm_gbps_algorithmic": round(bytes_ / (ms * 1e-3) / 1e9, 1),
+            "with_gemm_kernel": {"ms_per_step": round(both_ms, 3), "achieved": round(both, 2),
+                                 "frac": round(both / FP32_MATRIX_PEAK_TF, 4),
+                                 "note": "all fp32 matrix-core product kernels of the step (attention core excluded): "
+                                         "comparable with round 3's roofline.frac"}}
 
 
 def gemm_roofline(args, fallback_step=None):
@@ -617,6 +660,9 @@ def main():
             # rank 0 only from here on: no collective may run (the criterion's box count was all-reduced above)
             out["roofline"] = gemm_roofline(args, lambda: eager_step(model, make_optimizer(model), inputs, local_targets,
                                                                          criterion=criterion))
+            sa_lin = sa_linear_roofline(args, out["roofline"]) if args.dtype == "f32" else None
+            if sa_lin:
+                out["roofline_sa_linear"] = sa_lin
             if not args.no_extras:
                 out["roofline_ball_query"] = ball_query_roofline(inputs)
                 out["roofline_attention"] = attention_roofline(args.batch)
