@@ -38,6 +38,14 @@ __device__ __forceinline__ f4 mfma4(float a, float b, f4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// z1 = X W1^T of one element: THE order of operations of butd_sa_thin_conv and of every kernel here that recomputes it
+__device__ __forceinline__ float z1_dot(const float *__restrict__ x, const float *__restrict__ w) {
+  float a = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a += x[k] * w[k];
+  return a;
+}
+
 // --------------------------------------------------------------------------------- forward of the last layer + pool
 // When the backward below is in use nothing reads Z3 = H2 W3^T after the pooling, so the forward need not write it:
 // per 64-row block  H tile -> LDS (two buffers: one barrier per block);  Z3 tiles on the matrix cores with the ROWS in
@@ -926,6 +934,143 @@ __global__ void sa_first_dw_kernel(int C, long P, int ldw, const float *__restri
   }
 }
 
+// ------------------------------------------------------------- SA1: the first two layers forward without writing Z1
+// Layer 1's input is the grouped (xyz, colour) row X (8 columns).  Z1 = X W1^T is linear in it, so its BatchNorm batch
+// statistics follow from the moments of X alone: sum_c = W1[c] . SX,  sumsq_c = W1[c]^T XX W1[c]  (SX = column sums, XX =
+// X^T X: 8 + 64 numbers, double).  No pass over a 10^6 x 64 tensor is needed to normalise layer 1 -- and Z1 need not
+// exist at all: the second layer's kernel forms z1 -> relu(bn(z1)) from the X tile on the fly (8 multiply-adds per
+// element), multiplies by W2 on the matrix cores, writes Z2 and takes its column sums in the same pass; the backward
+// (sa_mid_first_kernel<RECOMP>) recomputes z1 the same way.  Replaces butd_sa_thin_conv (writes Z1), the layer-2 product
+// launch (reads it) and butd_sa_colstats (reads Z2 back): 1.1 GB -> 0.3 GB at SA1, B = 8.
+__global__ __launch_bounds__(256) void sa_x_moments_kernel(long P, const float *__restrict__ X, double *__restrict__ mom) {
+  // thread = (row lane t / 8, column k = t % 8): SX[k] and row k of XX over its rows; mom = [SX 8 | XX 64], zero on entry
+  __shared__ float red[32][72];
+  const int k = threadIdx.x & 7, rl = threadIdx.x >> 3;
+  float sx = 0.f, xx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (long r = (long)blockIdx.x * 32 + rl; r < P; r += (long)gridDim.x * 32) {
+    const f4 a = *reinterpret_cast<const f4 *>(X + r * 8), b = *reinterpret_cast<const f4 *>(X + r * 8 + 4);
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const float xk = k < 4 ? a[k & 3] : b[k & 3];
+    sx += xk;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xx[j] += xk * x[j];
+  }
+  red[rl][k] = sx;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[rl][8 + k * 8 + j] = xx[j];
+  __syncthreads();
+  if (threadIdx.x < 72) {
+    double a = 0.0;
+    for (int t = 0; t < 32; ++t) a += (double)red[t][threadIdx.x];
+    atomicAdd(mom + threadIdx.x, a);
+  }
+}
+
+__global__ void sa_l1_stats_kernel(int C, const float *__restrict__ W1, const double *__restrict__ mom,
+                                   double *__restrict__ sum, double *__restrict__ sumsq) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int k = 0; k < 8; ++k) {
+    const double wk = (double)W1[c * 8 + k];
+    s += wk * mom[k];
+    for (int j = 0; j < 8; ++j) q += wk * (double)W1[c * 8 + j] * mom[8 + k * 8 + j];
+  }
+  sum[c] = s;
+  sumsq[c] = q;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void sa_l12_fwd_kernel(long P, long nblk, const float *__restrict__ X,
+                                                         const float *__restrict__ W1, const float *__restrict__ sc1,
+                                                         const float *__restrict__ sh1, const float *__restrict__ W2,
+                                                         float *__restrict__ Z2, double *__restrict__ sum,
+                                                         double *__restrict__ sumsq) {
+  static_assert(C == 64, "SA1");
+  constexpr int KP = 8, ST = C + 36, SO = C + 4, KG = C / 16, QN = C / 4, RP = 256 / QN, NP = kRows / RP;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Ht = lds;                   // [64][ST]
+  float *Zs = Ht + kRows * ST;       // [64][SO]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
+  const int q = tid % QN, rsub = tid / QN, n0 = wave * 16;
+  float w1r[4][KP];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+#pragma unroll
+    for (int k = 0; k < KP; ++k) w1r[e][k] = W1[(4 * q + e) * KP + k];
+  const f4 sc = *reinterpret_cast<const f4 *>(sc1 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh1 + 4 * q);
+  f4 areg[KG];                       // A operand of the transposed product: W2 rows = output columns of this wave
+#pragma unroll
+  for (int g = 0; g < KG; ++g) areg[g] = *reinterpret_cast<const f4 *>(W2 + (long)(n0 + lm) * C + 16 * g + 4 * lq);
+  f4 s = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+  f4 xa[NP], xb[NP];
+  auto fetch = [&](long b) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long p = b * kRows + rsub + ps * RP;
+      const bool in = p < P;
+      xa[ps] = in ? *reinterpret_cast<const f4 *>(X + p * KP) : f4{0.f, 0.f, 0.f, 0.f};
+      xb[ps] = in ? *reinterpret_cast<const f4 *>(X + p * KP + 4) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const bool in = blk * kRows + r < P;
+      const float x[KP] = {xa[ps][0], xa[ps][1], xa[ps][2], xa[ps][3], xb[ps][0], xb[ps][1], xb[ps][2], xb[ps][3]};
+      f4 h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) h[e] = in ? fmaxf(sc[e] * z1_dot(x, w1r[e]) + sh[e], 0.f) : 0.f;
+      *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+    }
+    __syncthreads();
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const f4 hv = *reinterpret_cast<const f4 *>(Ht + (16 * rt + lm) * ST + 16 * g + 4 * lq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc = mfma4(areg[g][i], hv[i], oacc);
+      }
+      *reinterpret_cast<f4 *>(Zs + (16 * rt + lm) * SO + n0 + 4 * lq) = oacc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const long p = blk * kRows + r;
+      if (p < P) {
+        const f4 z = *reinterpret_cast<const f4 *>(Zs + r * SO + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[e] += z[e];
+          sq[e] += z[e] * z[e];
+        }
+        *reinterpret_cast<f4 *>(Z2 + p * C + 4 * q) = z;
+      }
+    }
+    __syncthreads();
+  }
+  float *red = lds;                  // [2][RP][C]
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[(0 * RP + rsub) * C + 4 * q + e] = s[e];
+    red[(1 * RP + rsub) * C + 4 * q + e] = sq[e];
+  }
+  __syncthreads();
+  if (tid < 2 * C) {
+    const int which = tid / C, col = tid - which * C;
+    double a = 0.0;
+    for (int t = 0; t < RP; ++t) a += (double)red[(which * RP + t) * C + col];
+    atomicAdd((which ? sumsq : sum) + col, a);
+  }
+}
+
 // ------------------------------------------- SA1: layer 2 and layer 1 backward in one pass, nothing written per row
 // With no input gradient wanted (SA1) everything below layer 2's gated gradient g2 ends in reductions:
 //   dZ2 = s2 (g2 - m1 - zhat2 m2)          (m1, m2: the sums butd_sa_last_bwd left behind)
@@ -934,14 +1079,16 @@ __global__ void sa_first_dw_kernel(int C, long P, int ldw, const float *__restri
 // so one pass over (g2, Z2, Z1, X) per 64-row block -- dZ2 tile and H1 tile in LDS, both products on the matrix cores,
 // the fold of g1 per thread -- replaces butd_sa_dz_mid (writes dZ2), the weight- / input-gradient product pair (reads
 // it twice, writes dH1) and the sa_first_stats pass (reads dH1): 2.45 GB -> 0.84 GB at SA1, B = 8.
-template <int C>
-__global__ __launch_bounds__(256) void sa_mid_first_kernel(
+// RECOMP: Z1 was never written (butd_sa_first_two_fwd): it is recomputed from the X tile and W1 (8 multiply-adds).
+template <int C, bool RECOMP>
+__global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
     long P, long nblk, const float *__restrict__ G2, const float *__restrict__ Z2, const float *__restrict__ Z1,
     const float *__restrict__ X, const float *__restrict__ gamma2, const float *__restrict__ sc2,
     const float *__restrict__ sh2, const float *__restrict__ mean2, const float *__restrict__ rstd2,
     const double *__restrict__ S1_2, const double *__restrict__ S2_2, const float *__restrict__ sc1,
     const float *__restrict__ sh1, const float *__restrict__ mean1, const float *__restrict__ rstd1,
-    const float *__restrict__ W2, float *__restrict__ ws_w, float *__restrict__ ws, long ws_stride) {
+    const float *__restrict__ W2, const float *__restrict__ W1, float *__restrict__ ws_w, float *__restrict__ ws,
+    long ws_stride) {
   static_assert(C == 64, "SA1: 64-wide layers");
   constexpr int KP = 8, NW = 4;
   constexpr int ST = C + 36, SO = C + 4, KG = C / 16, GN = C / 16, QN = C / 4, RP = 256 / QN, NP = kRows / RP;
@@ -950,9 +1097,14 @@ __global__ __launch_bounds__(256) void sa_mid_first_kernel(
   float *Ht = Dt + kRows * ST;       // [64][ST]  H1
   float *Os = Ht + kRows * ST;       // [64][SO]  dH1
   float *Xs = Os + kRows * SO;       // [64][KP]
+  float *W1s = Xs + kRows * KP;      // [C][KP]   (RECOMP)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
   const int q = tid % QN, rsub = tid / QN;
   const int n0 = wave * 16;
+  if (RECOMP) {
+    W1s[tid] = W1[tid];
+    W1s[tid + 256] = W1[tid + 256];
+  }
   // dH1^T tile = W2^T (A operand: rows = columns k of W2, contraction over c) x dZ2^T
   f4 areg[KG];
 #pragma unroll
@@ -990,7 +1142,7 @@ __global__ __launch_bounds__(256) void sa_mid_first_kernel(
       const bool in = p < P;
       gn[ps] = in ? *reinterpret_cast<const f4 *>(G2 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
       z2n[ps] = in ? *reinterpret_cast<const f4 *>(Z2 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
-      z1n[ps] = in ? *reinterpret_cast<const f4 *>(Z1 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+      if (!RECOMP) z1n[ps] = in ? *reinterpret_cast<const f4 *>(Z1 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
     }
     const long e0 = b * kRows * KP + tid, e1 = e0 + 256;          // the block's 64 x 8 inputs: two per thread
     xn = e0 < P * KP ? X[e0] : 0.f;
@@ -1000,23 +1152,29 @@ __global__ __launch_bounds__(256) void sa_mid_first_kernel(
   if (blk < nblk) fetch(blk);
   for (; blk < nblk; blk += gridDim.x) {
     f4 zk1[NP];
+    Xs[tid] = xn;
+    Xs[tid + 256] = xn2;
+    if (RECOMP) __syncthreads();       // the X tile (and, the first time, W1) before z1 is formed from them
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = rsub + ps * RP;
       const bool in = blk * kRows + r < P;
-      zk1[ps] = z1n[ps];
+      if (RECOMP) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zk1[ps][e] = z1_dot(Xs + r * KP, W1s + (4 * q + e) * KP);
+      } else {
+        zk1[ps] = z1n[ps];
+      }
       f4 d, h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float gv = s2c[e] * z2n[ps][e] + h2c[e] > 0.f ? gn[ps][e] : 0.f;      // (idempotent: g2 arrives gated)
         d[e] = in ? ga[e] * rs2[e] * (gv - a1[e] - (z2n[ps][e] - mu2[e]) * rs2[e] * a2[e]) : 0.f;
-        h[e] = in ? fmaxf(s1c[e] * z1n[ps][e] + h1c[e], 0.f) : 0.f;
+        h[e] = in ? fmaxf(s1c[e] * zk1[ps][e] + h1c[e], 0.f) : 0.f;
       }
       *reinterpret_cast<f4 *>(Dt + r * ST + 4 * q) = d;
       *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
     }
-    Xs[tid] = xn;
-    Xs[tid + 256] = xn2;
     __syncthreads();
     if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
     // ---- dH1^T tiles (16 columns of this wave x 16 rows) -> LDS
@@ -1201,6 +1359,29 @@ int butd_sa_first_bwd(long P, int C1, int Kp, const float *dH1, const float *Z1,
   return (int)hipGetLastError();
 }
 
+int butd_sa_first_two_fwd(long P, int C, int Kp, const float *X, const float *W1, const float *W2, double *mom,
+                          double *sum1, double *sumsq1, const float *scale1, const float *shift1, float *Z2, double *sum2,
+                          double *sumsq2, int phase, butd_stream_t stream) {
+  if (P <= 0) return 0;
+  if (Kp != 8 || C != 64) return (int)hipErrorInvalidValue;
+  hipStream_t st = (hipStream_t)stream;
+  if (phase == 0) {            // layer 1's BatchNorm sums from the moments of X (mom: 72 doubles, zero on entry)
+    const long blocks = (P + 31) / 32;
+    hipLaunchKernelGGL(sa_x_moments_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, P, X, mom);
+    hipLaunchKernelGGL(sa_l1_stats_kernel, dim3(1), dim3(64), 0, st, C, W1, mom, sum1, sumsq1);
+  } else {                     // layer 2: Z2 and its column sums (added: zero on entry), z1 formed on the fly
+    static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_l12_fwd_kernel<64>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) return (int)attr;
+    const long nblk = (P + kRows - 1) / kRows;
+    const int grid = (int)(nblk < 768 ? nblk : 768);
+    const size_t lds = (size_t)(kRows * (C + 36) + kRows * (C + 4)) * sizeof(float);
+    hipLaunchKernelGGL(sa_l12_fwd_kernel<64>, dim3(grid), dim3(256), lds, st, P, nblk, X, W1, scale1, shift1, W2, Z2, sum2,
+                       sumsq2);
+  }
+  return (int)hipGetLastError();
+}
+
 int butd_sa_mid_first_bwd_scratch(long P, int C, int Kp, long *ws_floats, long *ws_doubles) {
   if (P <= 0 || !ws_floats || !ws_doubles || Kp != 8 || C != 64) return (int)hipErrorInvalidValue;
   const long per = (long)C * (Kp + 2) + Kp + Kp * Kp;
@@ -1217,17 +1398,26 @@ int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z
                           butd_stream_t stream) {
   if (P <= 0) return 0;
   if (Kp != 8 || C != 64) return (int)hipErrorInvalidValue;
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mid_first_kernel<64>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  static hipError_t attr = []() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mid_first_kernel<64, false>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mid_first_kernel<64, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  }();
   if (attr != hipSuccess) return (int)attr;
   hipStream_t st = (hipStream_t)stream;
   const long nblk = (P + kRows - 1) / kRows;
   const int grid = (int)(nblk < 512 ? nblk : 512);
   const long per = (long)C * (Kp + 2) + Kp + Kp * Kp, nw = (long)C * C;
   float *ws_w = ws_f, *ws_p = ws_f + (long)grid * nw;
-  const size_t lds = (size_t)(2 * kRows * (C + 36) + kRows * (C + 4) + kRows * Kp) * sizeof(float);
-  hipLaunchKernelGGL(sa_mid_first_kernel<64>, dim3(grid), dim3(256), lds, st, P, nblk, G2, Z2, Z1, X, gamma2, scale2, shift2,
-                     mean2, rstd2, S1_2, S2_2, scale1, shift1, mean1, rstd1, W2, ws_w, ws_p, per);
+  const size_t lds = (size_t)(2 * kRows * (C + 36) + kRows * (C + 4) + kRows * Kp + C * Kp) * sizeof(float);
+  if (Z1 != nullptr)
+    hipLaunchKernelGGL((sa_mid_first_kernel<64, false>), dim3(grid), dim3(256), lds, st, P, nblk, G2, Z2, Z1, X, gamma2, scale2,
+                       shift2, mean2, rstd2, S1_2, S2_2, scale1, shift1, mean1, rstd1, W2, W1, ws_w, ws_p, per);
+  else       // Z1 was never written (butd_sa_first_two_fwd): recomputed from X and W1
+    hipLaunchKernelGGL((sa_mid_first_kernel<64, true>), dim3(grid), dim3(256), lds, st, P, nblk, G2, Z2, Z1, X, gamma2, scale2,
+                       shift2, mean2, rstd2, S1_2, S2_2, scale1, shift1, mean1, rstd1, W2, W1, ws_w, ws_p, per);
   hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((nw + per + 15) / 16)), dim3(256), 0, st, ws_w, nw, grid, ws_p, per,
                      grid, ws_d);
   hipLaunchKernelGGL(sa_d2f_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, ws_d, dW2, nw);

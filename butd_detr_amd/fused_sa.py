@@ -37,6 +37,10 @@ _LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
 _LAST_FWD = [os.environ.get("BUTD_SA_LAST_FWD", "1") != "0"]      # ... and the forward that does not write Z3
 _FIRST_LIN = [os.environ.get("BUTD_SA_FIRST_BWD", "1") != "0"]     # ... and the first layer's, where no input gradient is wanted
 _MID_FIRST = [os.environ.get("BUTD_SA_MID_BWD", "1") != "0"]       # ... with layer 2's backward in the same pass (64-wide levels)
+# ... and SA1's forward never writing Z1 (butd_sa_first_two_fwd).  OFF: measured neutral in the step (23.63 vs 23.66 ms): the
+# forward saves ~100 us (thin conv + product + colstats 290 us -> moments + one kernel 190 us) and the backward pays them
+# back (sa_mid_first with z1 recomputed from the LDS X tile: 372 vs 232 us).  profiles/r04_sa_last_layer.txt
+_NO_Z1 = [os.environ.get("BUTD_SA_NO_Z1", "0") == "1"]
 _scratch_sizes = {}
 _sched = {}
 
@@ -154,8 +158,32 @@ class _SAMlpPool(torch.autograd.Function):
         G = B * np_
         zmax = zmin = amax = amin = None
         lin = _last_lin_ok(training, ns, C2, C3, P)  # the backward then never reads Z3: the forward does not write it
+        # SA1 (no input gradient, 8 grouped columns, 64-wide layers): layer 1's BatchNorm sums from the moments of X, z1
+        # formed on the fly by layer 2's kernel and again by the backward (butd_sa_mid_first_bwd): Z1 is never written
+        no_z1 = (lin and Kp == 8 and C1 == 64 and C2 == 64 and _NO_Z1[0] and _MID_FIRST[0] and _FIRST_LIN[0]
+                 and not (feats_pm is not None and feats_pm.requires_grad))
         for li, (Cl, w) in enumerate(zip((C1, C2, C3), ws)):
             last = li == 2
+            if no_z1 and li < 2:
+                if li == 0:
+                    mom = torch.zeros(72, dtype=torch.float64, device=dev)
+                    _call("butd_sa_first_two_fwd", xyz, P, C1, Kp, X.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
+                          mom.data_ptr(), stats[0, 0, 0].data_ptr(), stats[0, 0, 1].data_ptr(), None, None, None, None,
+                          None, 0)
+                    Z = X[:0]
+                else:
+                    Z = torch.empty((P, Cl), device=dev)
+                    _call("butd_sa_first_two_fwd", xyz, P, C1, Kp, X.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(), None,
+                          None, None, aff[0, 2].data_ptr(), aff[0, 3].data_ptr(), Z.data_ptr(),
+                          stats[1, 0, 0].data_ptr(), stats[1, 0, 1].data_ptr(), 1)
+                g, b, rm, rv, nbt, eps = layers[li]
+                _call("butd_sa_bn_finalize", xyz, Cl, P, stats[li, 0, 0].data_ptr(), stats[li, 0, 1].data_ptr(), 1, 2 * Cm,
+                      g.data_ptr(), b.data_ptr(), float(eps), float(momentum), int(training), rm.data_ptr(), rv.data_ptr(),
+                      _p(nbt), aff[li, 0].data_ptr(), aff[li, 1].data_ptr(), aff[li, 2].data_ptr(), aff[li, 3].data_ptr())
+                prev_aff = (aff[li, 2], aff[li, 3])
+                Zs.append(Z)
+                inp = Z
+                continue
             if last:
                 zmax = torch.empty((G, Cl), device=dev)
                 zmin = torch.empty((G, Cl), device=dev)
@@ -205,6 +233,7 @@ class _SAMlpPool(torch.autograd.Function):
                               g1, g2, g3)
         ctx.cfg = (B, N, np_, ns, C, bool(training), feats_pm is not None and feats_pm.requires_grad,
                    w1.shape, w2.shape, w3.shape, Cin, lin)
+        ctx.no_z1 = no_z1
         ctx.inv = (inv_start, inv_list) if inv_start is not None else None
         return out_cm, out_pm
 
@@ -260,12 +289,13 @@ class _SAMlpPool(torch.autograd.Function):
                   S[1, 1].data_ptr())
         first_lin = lin and not need_dfeat and Kp == 8 and _FIRST_LIN[0]
         d_feats = None
-        if first_lin and _MID_FIRST[0] and C1 == 64 and C2 == 64:
+        assert not ctx.no_z1 or (first_lin and C1 == 64 and C2 == 64), "Z1 was not written: its backward needs butd_sa_mid_first_bwd"
+        if first_lin and (_MID_FIRST[0] or ctx.no_z1) and C1 == 64 and C2 == 64:
             # layers 2 and 1 in one pass over (g2, Z2, Z1, X): dW2, dW1 and layer 1's sums, nothing written per row
             nf, nd = _mid_scratch(P, C1, Kp)
             ws_f = torch.empty(nf, device=dev)
             ws_d = torch.empty(nd, dtype=torch.float64, device=dev)
-            _call("butd_sa_mid_first_bwd", X, P, C1, Kp, dH2.data_ptr(), Z2.data_ptr(), Z1.data_ptr(), X.data_ptr(),
+            _call("butd_sa_mid_first_bwd", X, P, C1, Kp, dH2.data_ptr(), Z2.data_ptr(), None if ctx.no_z1 else Z1.data_ptr(), X.data_ptr(),
                   g2.data_ptr(), scale(1).data_ptr(), shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(),
                   S[1, 0].data_ptr(), S[1, 1].data_ptr(), scale(0).data_ptr(), shift(0).data_ptr(), mean(0).data_ptr(),
                   rstd(0).data_ptr(), w2.data_ptr(), w1.data_ptr(), dW2.data_ptr(), dW1.data_ptr(), S[0, 0].data_ptr(),

@@ -129,6 +129,7 @@ int butd_sa_first_bwd(long P, int C1, int Kp, const float *dH1, const float *Z1,
  *   S1_1, S2_1 (written) and dW1 (C x 8) as butd_sa_first_bwd gives them.
  * Replaces butd_sa_dz_mid + the layer's weight- / input-gradient products + butd_sa_first_bwd (2.45 GB -> 0.84 GB at the
  * bench size).  Partials per workgroup, summed in double: no atomics. */
+/* Z1 may be NULL: the forward then never wrote it (butd_sa_first_two_fwd) and the kernel recomputes z1 = X W1^T per tile. */
 int butd_sa_mid_first_bwd_scratch(long P, int C, int Kp, long *ws_floats, long *ws_doubles);
 int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z2, const float *Z1, const float *X,
                           const float *gamma2, const float *scale2, const float *shift2, const float *mean2,
@@ -136,6 +137,16 @@ int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z
                           const float *shift1, const float *mean1, const float *rstd1, const float *W2, const float *W1,
                           float *dW2, float *dW1, double *S1_1, double *S2_1, float *ws_f, double *ws_d,
                           butd_stream_t stream);
+
+/* SA1's first two layers FORWARD without writing Z1 (C = 64, 8 grouped input columns).  Z1 = X W1^T is linear in X, so
+ * layer 1's BatchNorm sums follow from the moments of X:  phase 0 -- mom (72 doubles, zero on entry) <- [column sums of X |
+ * X^T X], sum1[c] = W1[c] . SX, sumsq1[c] = W1[c]^T XX W1[c] (written; the caller then runs butd_sa_bn_finalize as usual).
+ * phase 1 -- with layer 1's scale / shift: Z2 = relu(scale1 * (X W1^T) + shift1) W2^T (z1 formed per tile, 8 multiply-adds
+ * per element), written, and its column sums ADDED to sum2 / sumsq2 (zero on entry).  Replaces butd_sa_thin_conv, the
+ * layer-2 product launch and butd_sa_colstats; the backward of these layers is butd_sa_mid_first_bwd with Z1 = NULL. */
+int butd_sa_first_two_fwd(long P, int C, int Kp, const float *X, const float *W1, const float *W2, double *mom,
+                          double *sum1, double *sumsq1, const float *scale1, const float *shift1, float *Z2, double *sum2,
+                          double *sumsq2, int phase, butd_stream_t stream);
 
 /* Hidden layers, part 1 (read-only pass over dH, Z (P x C)): with g = dH * [scale*z+shift > 0],
  * S1[c] += sum_p g, S2[c] += sum_p g*zhat (double, caller zero-fills). */

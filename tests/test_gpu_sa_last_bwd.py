@@ -179,19 +179,35 @@ def test_first_layer_without_input_gradient(cfg):
     outs = {}
     # False: mask_stats + dz_mid + thin product;  True: butd_sa_first_bwd;  "mid": butd_sa_mid_first_bwd (layers 2 AND 1 in
     # one pass over (g2, Z2, Z1, X): also no dZ2, no dH1)
-    for first, mid in ((False, False), (True, False), (True, True)):
-        prev = fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0]
-        fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0] = first, mid
+    # "noz1": also the forward never writes Z1 (butd_sa_first_two_fwd: layer 1's BatchNorm sums from the moments of X, z1
+    # formed on the fly forward and backward)
+    for key, first, mid, noz1 in ((False, False, False, False), (True, True, False, False), ("mid", True, True, False),
+                                  ("noz1", True, True, True)):
+        prev = fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0], fused_sa._NO_Z1[0]
+        fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0], fused_sa._NO_Z1[0] = first, mid, noz1
         try:
-            outs["mid" if mid else first] = _run(m, xyz, feats, probe, linear=True, input_grad=False)
+            state = {k: v.clone() for k, v in m.state_dict().items()}
+            outs[key] = _run(m, xyz, feats, probe, linear=True, input_grad=False) + ({k: v.clone() for k, v in m.state_dict().items()},)
+            m.load_state_dict(state)
         finally:
-            fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0] = prev
-    ref = _run(m, xyz, feats, probe, linear=True, input_grad=True)
+            fused_sa._FIRST_LIN[0], fused_sa._MID_FIRST[0], fused_sa._NO_Z1[0] = prev
+    prev = fused_sa._NO_Z1[0]
+    fused_sa._NO_Z1[0] = False
+    try:
+        ref = _run(m, xyz, feats, probe, linear=True, input_grad=True)
+    finally:
+        fused_sa._NO_Z1[0] = prev
     assert torch.equal(outs[True][0], outs[False][0]) and torch.equal(outs["mid"][0], outs[False][0])
+    assert _err(outs["noz1"][0], outs[False][0]) < 2e-6
+    for k, v in outs[False][3].items():               # BatchNorm running statistics after the step
+        if "running" in k:
+            assert _err(outs["noz1"][3][k], v) < 1e-5, k
     for n in outs[False][2]:
         for k in (True, "mid"):
             assert _err(outs[k][2][n], outs[False][2][n]) < 2e-5, (k, n, _err(outs[k][2][n], outs[False][2][n]))
             assert _err(outs[k][2][n], ref[2][n]) < 2e-5, (k, n)
+        bad, mean, size, worst = _stats(outs["noz1"][2][n], outs[False][2][n])       # (another forward rounding: reroutes allowed)
+        assert bad <= max(2, 1e-3 * size) and mean < 2e-5 + 2 * worst / size and worst < 2e-2, (n, bad, size, mean, worst)
 
 
 @pytest.mark.parametrize("cfg", CFGS[1:4])

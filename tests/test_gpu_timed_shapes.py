@@ -221,7 +221,10 @@ def test_config2_model_train_mode_hip_vs_torch():
                   "cross_encoder.layers.1.cross_layer.cross_d.in_proj_weight",
                   "decoder.0.self_attn.out_proj.weight", "decoder.5.cross_v.in_proj_weight", "decoder.3.ffn.0.weight",
                   "prediction_heads.4.center_residual_head.net.0.weight", "text_projector.0.weight"):
-            _close(g_h[n], g_t[n], 1e-2 if n.startswith("backbone_net") else 3e-3, n, frac=1e-3)
+            # (a head's first weight: ONE ReLU gate of its second layer deciding the other way moves a whole row of 288 =
+            #  0.35 % of the tensor -- seen when the backbone's forward changed its summation order in round 4)
+            _close(g_h[n], g_t[n], 1e-2 if n.startswith("backbone_net") else 3e-3, n,
+                   frac=4e-3 if n.startswith("prediction_heads") else 1e-3)
     finally:
         attention_blocks.set_strict(False)
         attention_blocks.set_backend("torch")
