@@ -200,7 +200,8 @@ def sa_linear_roofline(args, gemm):
     efficient launches of gemm_kernel, are the ones that moved)."""
     if not _LAST_CHILD_ROWS or not gemm.get("launches_per_step"):
         return None
-    names = ("sa_last_fwd_kernel", "sa_last_fused_kernel", "sa_last_mfma_kernel", "sa_last_sparse_kernel", "sa_mid_first_kernel")
+    names = ("sa_last_fwd_kernel", "sa_last_fused_kernel", "sa_last_mfma_kernel", "sa_last_sparse_kernel", "sa_mid_first_kernel",
+             "sa_l12_fwd_kernel")
     gemm_calls = sum(c for n, c, _ in _LAST_CHILD_ROWS if "gemm_kernel" in n)
     steps = gemm_calls / gemm["launches_per_step"]            # steps in the child's trace
     per = {k: sum(t for n, _, t in _LAST_CHILD_ROWS if k in n) / steps * 1e-6 for k in names}     # ms per step
@@ -209,14 +210,19 @@ def sa_linear_roofline(args, gemm):
         return None
     B, npts = args.batch, args.points
     levels = [(B * 2048 * 64, 64, 128), (B * 1024 * 32, 128, 256), (B * 512 * 16, 128, 256), (B * 256 * 16, 128, 256)]
-    flops = sum(2.0 * P * c2 * c3 + 4.0 * P * c2 * c2 for P, c2, c3 in levels) + 4.0 * levels[0][0] * 64 * 64
+    P1 = levels[0][0]
+    flops = sum(2.0 * P * c2 * c3 + 4.0 * P * c2 * c2 for P, c2, c3 in levels) + 4.0 * P1 * 64 * 64
     bytes_ = sum(4.0 * P * c2 * (1 + 2) for P, c2, _ in levels)           # forward reads Z2; backward reads Z2, writes g2
     bytes_ += sum(4.0 * P * c2 * 2 for P, c2, _ in levels[1:])            # 128-wide levels: two-kernel backward (O round trip)
-    bytes_ += 4.0 * levels[0][0] * (3 * 64 + 8)                           # SA1 lower pass
+    if per["sa_l12_fwd_kernel"] > 0:      # SA1's first two layers forward without Z1; the lower pass recomputes z1 twice
+        flops += 2.0 * P1 * 64 * 64 + 3 * 2.0 * P1 * 64 * 8
+        bytes_ += 4.0 * P1 * (8 + 64) + 4.0 * P1 * (2 * 64 + 8)
+    else:
+        bytes_ += 4.0 * P1 * (3 * 64 + 8)                                 # SA1 lower pass reading Z1
     both_ms = ms + gemm["ms_per_step_in_kernel"]
     both = (flops + gemm["algorithmic_flops_per_step"]) / (both_ms * 1e-3) / 1e12
-    return {"kernel": "sa_last_fwd / sa_last_fused / sa_last_mfma + sa_last_sparse / sa_mid_first (set-abstraction last layer + "
-                      "max-pool by linearity, SA1 lower layers: the products that left gemm_kernel)",
+    return {"kernel": "sa_last_fwd / sa_last_fused / sa_last_mfma + sa_last_sparse / sa_mid_first / sa_l12_fwd (set-abstraction last layer "
+                      "+ max-pool by linearity, SA1 lower layers: the products that left gemm_kernel)",
             "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TF, 4), "traffic": None,
             "ms_per_step_in_kernels": round(ms, 3), "ms_per_kernel": {k: round(v, 3) for k, v in per.items()},
