@@ -167,7 +167,7 @@ class _SAMlpPool(torch.autograd.Function):
             last = li == 2
             if no_z1 and li < 2:
                 if li == 0:
-                    mom = torch.zeros(72, dtype=torch.float64, device=dev)
+                    mom = zeros(72, dtype=torch.float64, device=dev)
                     _call("butd_sa_first_two_fwd", xyz, P, C1, Kp, X.data_ptr(), ws[0].data_ptr(), ws[1].data_ptr(),
                           mom.data_ptr(), stats[0, 0, 0].data_ptr(), stats[0, 0, 1].data_ptr(), None, None, None, None,
                           None, 0)
