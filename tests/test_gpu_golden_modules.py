@@ -19,11 +19,41 @@ def load(name):
     return np.load(os.path.join(G, name), allow_pickle=False)
 
 
+# Bounds (of max|ref|), set in round 4 from what both backends actually reach on MI355X (gpurun_out/golden_errors.json,
+# written by this file): encoder / decoder-layer goldens 0.9e-6 outputs, 1.7e-6 gradients; eval-mode backbone 6e-7 outputs,
+# 3.4e-4 gradients; eval-mode model 2.9e-6; train-mode backbone 8e-6 outputs; train-mode 3 + 6-layer model 6.5e-5 (fused)
+# / 1.3e-4 (stock ops) outputs.  Each bound is ~10x its observation (the rounds before had 1e-3 / 2e-3 everywhere).
+OUT_TOL = 2e-5          # encoder, decoder layer, eval-mode backbone and model: outputs
+GRAD_TOL = 2e-5         # encoder, decoder layer: gradients
+BACKBONE_EVAL_GRAD_TOL = 1.5e-3
+TRAIN_OUT_TOL = 1e-4    # train-mode backbone outputs (batch statistics reduced in another order than the CPU reference)
+TRAIN6_OUT_TOL = 5e-4   # train-mode 3 + 6-layer model outputs
+
+_OBSERVED = []      # (test, max error, bound, share beyond the bound): written to gpurun_out/golden_errors.json
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _dump_observed_errors():
+    """What the bounds of this file are set FROM: every close() / grad_close() call's observed error next to its bound."""
+    yield
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if _OBSERVED and os.path.isdir(os.path.join(root, "gpurun_out")):
+        import json
+        with open(os.path.join(root, "gpurun_out", "golden_errors.json"), "w") as f:
+            json.dump(_OBSERVED, f, indent=0)
+
+
+def _observe(err, tol):
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0]
+    _OBSERVED.append([test, float(err.max()), float(err.mean()), float(tol), float((err > tol).mean())])
+
+
 def close(t, ref, tol=1e-3, outlier_frac=0.0):
     """|t - ref| <= tol * max|ref| everywhere, except for at most ``outlier_frac`` of the elements
     (max-pool arg-max flips between near-equal candidates reroute a few gradient entries)."""
     a = t.detach().float().cpu().numpy()
     scale = max(float(np.abs(ref).max()), 1e-6)
+    _observe(np.abs(a - ref) / scale, tol)
     if outlier_frac:
         bad = np.abs(a - ref) / scale > tol
         assert bad.mean() <= outlier_frac, f"{bad.sum()} of {bad.size} elements beyond {tol}"
@@ -56,19 +86,19 @@ def test_encoder_golden(backend):
         inp[k].requires_grad_(True)
     vis_out, text_out = model(inp["vis"], inp["pos"], inp["vis_mask"], inp["text"], inp["text_mask"],
                               {}, detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
-    close(vis_out, g["vis_out"])
-    close(text_out, g["text_out"])
+    close(vis_out, g["vis_out"], OUT_TOL)
+    close(text_out, g["text_out"], OUT_TOL)
     ((vis_out * probe(vis_out.shape, 1).cuda()).sum() + (text_out * probe(text_out.shape, 2).cuda()).sum()).backward()
-    close(inp["vis"].grad, g["g_vis"], 2e-3)
-    close(inp["text"].grad, g["g_text"], 2e-3)
-    close(inp["pos"].grad, g["g_pos"], 2e-3)
-    close(inp["boxes"].grad, g["g_boxes"], 2e-3)
+    close(inp["vis"].grad, g["g_vis"], GRAD_TOL)
+    close(inp["text"].grad, g["g_text"], GRAD_TOL)
+    close(inp["pos"].grad, g["g_pos"], GRAD_TOL)
+    close(inp["boxes"].grad, g["g_boxes"], GRAD_TOL)
     p = dict(model.named_parameters())
-    close(p["layers.0.cross_layer.cross_lv.in_proj_weight"].grad, g["g_l0_cross_lv_in_proj_weight"], 2e-3)
+    close(p["layers.0.cross_layer.cross_lv.in_proj_weight"].grad, g["g_l0_cross_lv_in_proj_weight"], GRAD_TOL)
     close(p["layers.2.self_attention_visual.self_attn.out_proj.weight"].grad,
-          g["g_l2_self_attention_visual_out_proj_weight"], 2e-3)
-    close(p["layers.1.cross_layer.ffn_vl.0.weight"].grad, g["g_l1_ffn_vl_0_weight"], 2e-3)
-    close(p["layers.1.cross_layer.norm_d.weight"].grad, g["g_l1_norm_d_weight"], 2e-3)
+          g["g_l2_self_attention_visual_out_proj_weight"], GRAD_TOL)
+    close(p["layers.1.cross_layer.ffn_vl.0.weight"].grad, g["g_l1_ffn_vl_0_weight"], GRAD_TOL)
+    close(p["layers.1.cross_layer.norm_d.weight"].grad, g["g_l1_norm_d_weight"], GRAD_TOL)
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
@@ -84,16 +114,16 @@ def test_decoder_layer_golden(backend, mode):
         inp[k].requires_grad_(True)
     out = layer(inp["query"], inp["vis"], inp["text"], inp["query_pos"], None, inp["text_mask"],
                 detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
-    close(out, g["out"])
+    close(out, g["out"], OUT_TOL)
     (out * probe(out.shape, 3).cuda()).sum().backward()
-    close(inp["query"].grad, g["g_query"], 2e-3)
-    close(inp["vis"].grad, g["g_vis"], 2e-3)
-    close(inp["text"].grad, g["g_text"], 2e-3)
-    close(inp["boxes"].grad, g["g_boxes"], 2e-3)
+    close(inp["query"].grad, g["g_query"], GRAD_TOL)
+    close(inp["vis"].grad, g["g_vis"], GRAD_TOL)
+    close(inp["text"].grad, g["g_text"], GRAD_TOL)
+    close(inp["boxes"].grad, g["g_boxes"], GRAD_TOL)
     p = dict(layer.named_parameters())
-    close(p["cross_v.in_proj_weight"].grad, g["g_cross_v_in_proj_weight"], 2e-3)
-    close(p["self_posembed.position_embedding_head.0.weight"].grad, g["g_self_posembed_0_weight"], 2e-3)
-    close(p["ffn.3.weight"].grad, g["g_ffn_3_weight"], 2e-3)
+    close(p["cross_v.in_proj_weight"].grad, g["g_cross_v_in_proj_weight"], GRAD_TOL)
+    close(p["self_posembed.position_embedding_head.0.weight"].grad, g["g_self_posembed_0_weight"], GRAD_TOL)
+    close(p["ffn.3.weight"].grad, g["g_ffn_3_weight"], GRAD_TOL)
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
@@ -107,15 +137,17 @@ def test_backbone_golden(mode):
         np.testing.assert_array_equal(ep[k].cpu().numpy(), g[k])
     np.testing.assert_array_equal(ep["sa1_xyz"].cpu().numpy(), g["sa1_xyz"])
     np.testing.assert_array_equal(ep["sa4_xyz"].cpu().numpy(), g["sa4_xyz"])
-    close(ep["sa1_features"][:, :, :64], g["sa1_features_head"])
-    close(ep["sa2_features"][:, :, :64], g["sa2_features_head"])
-    close(ep["sa4_features"], g["sa4_features"])
-    close(ep["fp2_features"][0], g["fp2_features_b0"])
+    otol = TRAIN_OUT_TOL if mode == "train" else OUT_TOL
+    close(ep["sa1_features"][:, :, :64], g["sa1_features_head"], otol)
+    close(ep["sa2_features"][:, :, :64], g["sa2_features_head"], otol)
+    close(ep["sa4_features"], g["sa4_features"], otol)
+    close(ep["fp2_features"][0], g["fp2_features_b0"], otol)
     (ep["fp2_features"] * probe(ep["fp2_features"].shape, 4).cuda()).sum().backward()
     p = dict(net.named_parameters())
     # weight gradients through up to 14 batch-norm layers: the GPU reduces the batch statistics in a
-    # different order than the CPU reference run, so the deepest ones get a looser (1e-2) bound
-    gtol = 1e-2 if mode == "train" else 2e-3
+    # different order than the CPU reference run, so the deepest ones get a looser (1e-2) bound; observed in train mode:
+    # 0.07 % of the elements beyond 1e-2 (max-pool winners that flip between near-equal candidates), mean 2.2e-3
+    gtol = 1e-2 if mode == "train" else BACKBONE_EVAL_GRAD_TOL
     frac = 1e-3 if mode == "train" else 0.0
     close(p["sa1.mlp_module.layer0.conv.weight"].grad, g["g_sa1_layer0_conv"], gtol, frac)
     close(p["sa3.mlp_module.layer2.conv.weight"].grad, g["g_sa3_layer2_conv"], gtol, frac)
@@ -145,8 +177,8 @@ def test_bdetr_golden(backend):
     for k in ("seeds_obj_cls_logits", "text_feats", "text_memory", "proj_tokens", "proposal_center",
               "proposal_pred_size", "proposal_proj_queries", "0head_center", "last_center",
               "last_pred_size", "last_sem_cls_scores", "last_proj_queries"):
-        close(ep[k], g[k])
-    close(ep["seed_features"][0], g["seed_features_b0"])
+        close(ep[k], g[k], OUT_TOL)
+    close(ep["seed_features"][0], g["seed_features_b0"], OUT_TOL)
 
 
 def test_bdetr_train_six_layers_golden(backend):
@@ -173,15 +205,23 @@ def test_bdetr_train_six_layers_golden(backend):
     # tests/test_gpu_gradient_truth.py, profiles/r03_gradient_error_vs_fp64.txt) --
     # the heads normalise over only 2 x 82 samples (BatchNorm1d batch statistics), whose backward subtracts
     # batch means (cancellation); stock torch on this GPU lands at 4e-3 of the scale against the CPU-run
-    # reference, the fused path at 1.6e-2 on the last decoder layer (scratch/diag_train6.py).  Bound: 2e-2
-    # max, 5e-3 mean.
+    # reference, the fused path at 1.6e-2 on the last decoder layer in round 3 (scratch/diag_train6.py).  Round 4 (exact
+    # BatchNorm sums of SA1's first layer, deterministic partial sums in the set-abstraction backward): the FUSED path is at
+    # 7.8e-3 max / 1.6e-3 mean over the 14 gradient tensors, identical on every run and box seen; stock torch ops on this
+    # GPU at 1.9e-2 / 1.6e-3.  Bounds: fused 1e-2 max, 2.5e-3 mean; stock ops 2.5e-2 max, 5e-3 mean.
+    gmax, gmean = (1e-2, 2.5e-3) if backend == "hip" else (2.5e-2, 5e-3)
+
     def grad_close(t, ref):
         a = t.detach().float().cpu().numpy()
         scale = max(float(np.abs(ref).max()), 1e-6)
         err = np.abs(a - ref) / scale
-        assert err.max() <= 2e-2 and err.mean() <= 5e-3, (err.max(), err.mean())
+        _observe(err, gmax)
+        assert err.max() <= gmax and err.mean() <= gmean, (err.max(), err.mean())
 
-    _check_train6(ep, model, g, close, grad_close, backbone_tol=grad_close)
+    def out_close(t, ref):
+        close(t, ref, TRAIN6_OUT_TOL)
+
+    _check_train6(ep, model, g, out_close, grad_close, backbone_tol=grad_close)
 
 
 # ---- BASELINE configs[3]'s arithmetic ("bf16 attention / FFN") against the REFERENCE's vectors ------------------------
