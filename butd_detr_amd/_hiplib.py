@@ -78,6 +78,9 @@ ATTENTION_SYMBOLS = {
                                            + [_c_float, _c_u32, _c_void_p, _c_void_p, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_bwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 10
                                        + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+    "butd_layernorm_bwd_blocks": (_c_int, [_c_int]),
+    "butd_add_dropout_layernorm_bwd_partial": (_c_int, [_c_int, _c_int] + [_c_void_p] * 9
+                                               + [_c_float, _c_u32, _c_void_p, _c_void_p]),
 }
 
 class PanelStage(ctypes.Structure):

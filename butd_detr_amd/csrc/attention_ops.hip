@@ -105,7 +105,8 @@ __global__ __launch_bounds__(kLnBwdThreads) void ln_bwd_kernel(
     const float *__restrict__ residual, const float *__restrict__ gamma,
     const float *__restrict__ mean, const float *__restrict__ rstd, float *__restrict__ dx,
     float *__restrict__ d_residual, float *__restrict__ dgamma, float *__restrict__ dbeta,
-    float dropout_p, uint32_t site, const uint64_t *__restrict__ rng_counter, int rows_per_wave) {
+    float dropout_p, uint32_t site, const uint64_t *__restrict__ rng_counter, int rows_per_wave,
+    float *__restrict__ partials) {
   __shared__ float red[2][kLnBwdThreads / 64][64 * PER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool drop = dropout_p > 0.f;
@@ -174,8 +175,13 @@ __global__ __launch_bounds__(kLnBwdThreads) void ln_bwd_kernel(
       a += red[0][w][c];
       b += red[1][w][c];
     }
-    atomicAdd(dgamma + c, a);
-    atomicAdd(dbeta + c, b);
+    if (partials) {   // this workgroup's column sums, folded by whoever runs next (no same-address atomics)
+      partials[(long)blockIdx.x * 2 * cols + c] = a;
+      partials[(long)blockIdx.x * 2 * cols + cols + c] = b;
+    } else {
+      atomicAdd(dgamma + c, a);
+      atomicAdd(dbeta + c, b);
+    }
   }
 }
 
@@ -220,26 +226,54 @@ int butd_add_dropout_layernorm_fwd_pos(int rows, int cols, const float *x, const
   return (int)hipGetLastError();
 }
 
+namespace {
+// one row per wave while that still leaves workgroups for every CU to spare (a 2048-row call is 128
+// workgroups); several rows per wave only for very tall inputs, where it trims the dgamma/dbeta atomics
+// (measured: the column-sum atomics are half of the kernel's time at 8192 rows -- 512 workgroups on the same
+// 576 addresses; two rows per wave halve them there: 21.2 -> 18.4 us.  Folding private copies with a
+// last-workgroup ticket needs an agent-scope release per workgroup = an L2 write-back each: 159 us.)
+inline int ln_bwd_rows_per_wave(int rows) {
+  static const int forced = getenv("BUTD_LN_RPW") ? atoi(getenv("BUTD_LN_RPW")) : 0;
+  return forced ? forced : (rows >= 65536 ? kLnRowsPerWave : rows >= 8192 ? 2 : 1);
+}
+inline int ln_bwd_blocks(int rows) {
+  const int rows_per_block = (kLnBwdThreads / 64) * ln_bwd_rows_per_wave(rows);
+  return (rows + rows_per_block - 1) / rows_per_block;
+}
+int ln_bwd_launch(int rows, int cols, const float *dy, const float *x, const float *residual, const float *gamma,
+                  const float *mean, const float *rstd, float *dx, float *d_residual, float *dgamma, float *dbeta,
+                  float *partials, float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                  butd_stream_t stream) {
+  if (rows <= 0) return 0;
+  if (cols <= 0 || cols > 64 * kLnMaxPerLane) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const int rpw = ln_bwd_rows_per_wave(rows);
+  const dim3 grid(ln_bwd_blocks(rows));
+  LN_DISPATCH_T(kLnBwdThreads, ln_bwd_kernel, rows, cols, dy, x, residual, gamma, mean, rstd, dx, d_residual, dgamma,
+                dbeta, dropout_p, dropout_site, rng_counter, rpw, partials);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
 int butd_add_dropout_layernorm_bwd(int rows, int cols, const float *dy, const float *x,
                                    const float *residual, const float *gamma, const float *mean,
                                    const float *rstd, float *dx, float *d_residual, float *dgamma,
                                    float *dbeta, float dropout_p, uint32_t dropout_site,
                                    const uint64_t *rng_counter, butd_stream_t stream) {
-  if (rows <= 0) return 0;
-  if (cols <= 0 || cols > 64 * kLnMaxPerLane) return (int)hipErrorInvalidValue;
-  hipStream_t s = (hipStream_t)stream;
-  // one row per wave while that still leaves workgroups for every CU to spare (a 2048-row call is 128
-  // workgroups); several rows per wave only for very tall inputs, where it trims the dgamma/dbeta atomics
-  static const int forced = getenv("BUTD_LN_RPW") ? atoi(getenv("BUTD_LN_RPW")) : 0;
-  // (measured: the column-sum atomics are half of the kernel's time at 8192 rows -- 512 workgroups on the same
-  // 576 addresses; two rows per wave halve them there: 21.2 -> 18.4 us.  Folding private copies with a
-  // last-workgroup ticket needs an agent-scope release per workgroup = an L2 write-back each: 159 us.)
-  const int rpw = forced ? forced : (rows >= 65536 ? kLnRowsPerWave : rows >= 8192 ? 2 : 1);
-  const int rows_per_block = (kLnBwdThreads / 64) * rpw;
-  const dim3 grid((rows + rows_per_block - 1) / rows_per_block);
-  LN_DISPATCH_T(kLnBwdThreads, ln_bwd_kernel, rows, cols, dy, x, residual, gamma, mean, rstd, dx, d_residual, dgamma,
-              dbeta, dropout_p, dropout_site, rng_counter, rpw);
-  return (int)hipGetLastError();
+  return ln_bwd_launch(rows, cols, dy, x, residual, gamma, mean, rstd, dx, d_residual, dgamma, dbeta, nullptr,
+                       dropout_p, dropout_site, rng_counter, stream);
+}
+
+int butd_layernorm_bwd_blocks(int rows) { return rows > 0 ? ln_bwd_blocks(rows) : 0; }
+
+int butd_add_dropout_layernorm_bwd_partial(int rows, int cols, const float *dy, const float *x,
+                                           const float *residual, const float *gamma, const float *mean,
+                                           const float *rstd, float *dx, float *d_residual, float *partials,
+                                           float dropout_p, uint32_t dropout_site,
+                                           const uint64_t *rng_counter, butd_stream_t stream) {
+  if (partials == nullptr) return (int)hipErrorInvalidValue;
+  return ln_bwd_launch(rows, cols, dy, x, residual, gamma, mean, rstd, dx, d_residual, nullptr, nullptr, partials,
+                       dropout_p, dropout_site, rng_counter, stream);
 }
 
 }  // extern "C"

@@ -226,6 +226,56 @@ def _check(*tensors):
 
 
 # -------------------------------------------------------------------------------------------------
+# LayerNorm backward without same-address atomics: the kernel writes per-workgroup column sums, the grouped launch that
+# follows it in every block folds them (one more problem: dgamma | dbeta = ones(1, blocks) . partials).  Measured alone
+# (profiles/r04_small_kernels.txt): the 128 .. 512 atomics per column are 2.9 us of 8.5 us at 2048 rows, 5.0 of 18.4 at
+# 8192.  BUTD_LN_FOLD=0: the atomic kernel (round 3's).
+# -------------------------------------------------------------------------------------------------
+_ln_fold = [os.environ.get("BUTD_LN_FOLD", "1") == "1"]
+_ones_rows = {}
+
+
+def set_ln_fold(flag):
+    prev, _ln_fold[0] = _ln_fold[0], bool(flag)
+    return prev
+
+
+def _ones_row(dev, n):
+    t = _ones_rows.get(dev)
+    if t is None or t.numel() < n:
+        if torch.cuda.is_current_stream_capturing():      # (a fill captured into a graph has not run yet: no fold now)
+            return None
+        t = torch.ones(max(n, 4096), device=dev)
+        _ones_rows[dev] = t
+    return t
+
+
+def _ln_bwd(M, E, dy, x, res, gamma, mean, rstd, dx, d_res, d_gamma, d_beta, p, site, ref):
+    """butd_add_dropout_layernorm_bwd; returns the problems the NEXT grouped launch has to carry ([] or the fold)."""
+    dev = ref.device
+    nb = _lib.butd_layernorm_bwd_blocks(M)
+    ones = None
+    if (_ln_fold[0] and not _compute_bf16[0] and nb >= 4 and nb % 4 == 0 and E % 4 == 0
+            and d_beta.data_ptr() == d_gamma.data_ptr() + 4 * E):
+        ones = _ones_row(dev, nb)
+    with torch.cuda.device(dev):
+        if ones is not None:
+            part = torch.empty((nb, 2 * E), device=dev)
+            err = _lib.butd_add_dropout_layernorm_bwd_partial(
+                M, E, dy.data_ptr(), x.data_ptr(), _ptr(res), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                dx.data_ptr(), d_res.data_ptr(), part.data_ptr(), p, site, rng_counter(dev).data_ptr(), _stream(ref))
+        else:
+            err = _lib.butd_add_dropout_layernorm_bwd(
+                M, E, dy.data_ptr(), x.data_ptr(), _ptr(res), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                dx.data_ptr(), d_res.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(), p, site,
+                rng_counter(dev).data_ptr(), _stream(ref))
+    _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+    if ones is None:
+        return []
+    return [_problem(ones, part, d_gamma, 1, 2 * E, nb, (nb, 1), (1, 2 * E), 2 * E)]
+
+
+# -------------------------------------------------------------------------------------------------
 # Row-panel chains (include/butd_panel.h): the row-wise operators behind an attention core -- out-projection, dropout,
 # residual, LayerNorm, + pos, projections of the result that the NEXT blocks need, the FFN -- as one launch.
 # -------------------------------------------------------------------------------------------------
@@ -327,16 +377,10 @@ class _AttentionBlock(torch.autograd.Function):
         d_beta = slab[o:o + E]
         d_res = torch.empty((B, Lq, E), device=dev)
         d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else d_res
-        with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_bwd(
-                Mq, E, dy.data_ptr(), proj.data_ptr(), residual.data_ptr(), gamma.data_ptr(),
-                mean.data_ptr(), rstd.data_ptr(), d_proj.data_ptr(), d_res.data_ptr(),
-                d_gamma.data_ptr(), d_beta.data_ptr(), p_out, site_out, rng_counter(dev).data_ptr(),
-                _stream(xq))
-        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        fold = _ln_bwd(Mq, E, dy, proj, residual, gamma, mean, rstd, d_proj, d_res, d_gamma, d_beta, p_out, site_out, xq)
         d_att = torch.empty((B, Lq, E), device=dev)
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
-               _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], xq)
+               _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)] + fold, xq)
         short = _short_key_bwd(Lq, Lk)
         dq = torch.empty((B, Lq, E), device=dev)
         dk = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
@@ -428,18 +472,13 @@ class _FfnBlock(torch.autograd.Function):
         d_beta = slab[off:off + E]
         d_x = torch.empty((B, L, E), device=dev)          # residual path first, FFN path accumulates
         d_o = torch.empty((B, L, E), device=dev)
-        with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_bwd(
-                M, E, dy.data_ptr(), o.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                rstd.data_ptr(), d_o.data_ptr(), d_x.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(),
-                p2, site2, rng_counter(dev).data_ptr(), _stream(x))
-        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        fold = _ln_bwd(M, E, dy, o, x, gamma, mean, rstd, d_o, d_x, d_gamma, d_beta, p2, site2, x)
         d_h = torch.empty((B, L, Fh), device=dev)
         gate = 1.0 / (1.0 - p1) if p1 > 0 else 1.0        # h = relu(z) * keep / (1-p): h > 0 <=> live
         # the product that creates d_h applies the ReLU / dropout gate in its epilogue (c_gate): the two products that
         # read d_h then stay on the float4 staging path (they carried h as a companion operand before)
         _gemm([_dgrad(d_o, w2, d_h, M, E, Fh, gate=h, gate_scale=gate),
-               _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)], x)
+               _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)] + fold, x)
         _gemm([_dgrad(d_h, w1, d_x, M, Fh, E, c_add=True),
                _wgrad(d_h, x, d_w1, d_b1, M, Fh, E)], x)
         return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None, None, None
@@ -769,16 +808,10 @@ class _XpmBlock(torch.autograd.Function):
         d_beta = slab[o:o + E]
         R = torch.empty((B, Lq, E), device=dev)              # d(residual path) -> total gradient of x
         d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else R
-        with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_bwd(
-                Mq, E, dy.data_ptr(), proj.data_ptr(), x.data_ptr(), gamma.data_ptr(),
-                mean.data_ptr(), rstd.data_ptr(), d_proj.data_ptr(), R.data_ptr(),
-                d_gamma.data_ptr(), d_beta.data_ptr(), p_out, site_out, rng_counter(dev).data_ptr(),
-                _stream(x))
-        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        fold = _ln_bwd(Mq, E, dy, proj, x, gamma, mean, rstd, d_proj, R, d_gamma, d_beta, p_out, site_out, x)
         d_att = torch.empty((B, Lq, E), device=dev)
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
-               _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], x)
+               _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)] + fold, x)
         # gradients of the attention core, packed: self: G = [dq | dk | dv]; cross: dq, G = [dk | dv]
         short = _short_key_bwd(Lq, Lk)      # (one kernel that ACCUMULATES dk / dv: zero-filled from the step's arena)
         new_g = (lambda shape: zeros(shape, device=dev)) if short else (lambda shape: torch.empty(shape, device=dev))
@@ -978,14 +1011,9 @@ class _XkvBlock(torch.autograd.Function):
         d_gamma, d_beta = slab[E * E + E:E * E + 2 * E], slab[E * E + 2 * E:]
         R = torch.empty((B, Lq, E), device=dev)
         d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else R
-        with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_bwd(
-                Mq, E, dy.data_ptr(), proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                rstd.data_ptr(), d_proj.data_ptr(), R.data_ptr(), d_gamma.data_ptr(), d_beta.data_ptr(), p_out,
-                site_out, rng_counter(dev).data_ptr(), _stream(x))
-        _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
+        fold = _ln_bwd(Mq, E, dy, proj, x, gamma, mean, rstd, d_proj, R, d_gamma, d_beta, p_out, site_out, x)
         d_att = torch.empty((B, Lq, E), device=dev)
-        _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E), _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)], x)
+        _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E), _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)] + fold, x)
         short = _short_key_bwd(Lq, Lk)
         dq = torch.empty((B, Lq, E), device=dev)
         G = zeros((B, Lk, 2 * E), device=dev) if short else torch.empty((B, Lk, 2 * E), device=dev)

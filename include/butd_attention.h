@@ -183,6 +183,19 @@ int butd_add_dropout_layernorm_bwd(int rows, int cols, const float *dy, const fl
                                    float *dbeta, float dropout_p, uint32_t dropout_site,
                                    const uint64_t *rng_counter, butd_stream_t stream);
 
+/* The same without atomics: workgroup w of the launch (butd_layernorm_bwd_blocks(rows) of them) writes the column sums
+ * of ITS rows to partials[w][0 .. cols) (dgamma) and partials[w][cols .. 2 cols) (dbeta); partials is
+ * (blocks, 2 * cols), fully overwritten.  The caller folds it -- dgamma | dbeta = ones(1, blocks) . partials is one more
+ * problem (M = 1, N = 2 cols, K = blocks) of the grouped product that follows a LayerNorm backward in every block of
+ * encoder_decoder_layers.py:75-124, 166-186, 340-406, so the 128 .. 512 same-address float atomics per column (2.9 us of
+ * the kernel's 8.5 us at 2048 rows, 5.0 of 18.4 at 8192) disappear and the two gradients become bit-reproducible. */
+int butd_layernorm_bwd_blocks(int rows);
+int butd_add_dropout_layernorm_bwd_partial(int rows, int cols, const float *dy, const float *x,
+                                           const float *residual, const float *gamma, const float *mean,
+                                           const float *rstd, float *dx, float *d_residual, float *partials,
+                                           float dropout_p, uint32_t dropout_site,
+                                           const uint64_t *rng_counter, butd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -430,3 +430,70 @@ def test_short_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, 
     for a, bq, name in zip(res["one"], res["two"], ("dq", "dk", "dv", "delta", "padding")):
         assert torch.isfinite(a).all(), name
         _close(a, bq, 1e-5 if name != "padding" else 1e-12)
+
+
+@pytest.mark.parametrize("rows,E", [(2048, 288), (8192, 288), (640, 288), (64, 32), (2048, 64)])
+def test_layernorm_backward_partials_equal_the_atomic_kernel(mods, rows, E):
+    """butd_add_dropout_layernorm_bwd_partial + the fold (ones . partials as one problem of the grouped product, what every
+    block's backward appends to its next launch) against the kernel that accumulates dgamma / dbeta with atomics, and
+    against float64; dx / d_residual identical."""
+    _, fa, _, _ = mods
+    from butd_detr_amd import _hiplib
+    lib = _hiplib.load()
+    torch.manual_seed(rows + E)
+    dev = torch.device("cuda", 0)
+    x, res, dy = (torch.randn(rows, E, device=dev) for _ in range(3))
+    gamma = torch.randn(E, device=dev)
+    s = x + res
+    mean, var = s.mean(1), s.var(1, unbiased=False)
+    rstd = (var + 1e-5).rsqrt()
+    st = torch.cuda.current_stream().cuda_stream
+    ctr = fa.rng_counter(dev).data_ptr()
+    dx_a, dr_a, dx_p, dr_p = (torch.empty(rows, E, device=dev) for _ in range(4))
+    gb_a = torch.zeros(2 * E, device=dev)
+    assert lib.butd_add_dropout_layernorm_bwd(rows, E, dy.data_ptr(), x.data_ptr(), res.data_ptr(), gamma.data_ptr(),
+                                              mean.data_ptr(), rstd.data_ptr(), dx_a.data_ptr(), dr_a.data_ptr(),
+                                              gb_a.data_ptr(), gb_a.data_ptr() + 4 * E, 0.0, 3, ctr, st) == 0
+    nb = lib.butd_layernorm_bwd_blocks(rows)
+    assert nb >= 1 and nb % 4 == 0
+    part = torch.full((nb, 2 * E), float("nan"), device=dev)        # fully overwritten
+    assert lib.butd_add_dropout_layernorm_bwd_partial(rows, E, dy.data_ptr(), x.data_ptr(), res.data_ptr(),
+                                                      gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                      dx_p.data_ptr(), dr_p.data_ptr(), part.data_ptr(), 0.0, 3, ctr, st) == 0
+    gb_p = torch.full((2 * E,), float("nan"), device=dev)
+    fa._gemm([fa._problem(fa._ones_row(dev, nb), part, gb_p, 1, 2 * E, nb, (nb, 1), (1, 2 * E), 2 * E)], x)
+    torch.cuda.synchronize()
+    assert torch.equal(dx_a, dx_p) and torch.equal(dr_a, dr_p)
+    xhat = ((s - mean[:, None]) * rstd[:, None]).double()
+    want = torch.cat([(dy.double() * xhat).sum(0), dy.double().sum(0)])
+    scale = float(want.abs().max())
+    assert float((gb_p.double() - want).abs().max()) <= 2e-6 * scale * max(1.0, (rows / 2048) ** 0.5)
+    assert float((gb_p - gb_a).abs().max()) <= 1e-5 * scale
+    assert float((part.sum(0).double() - want).abs().max()) <= 2e-6 * scale * max(1.0, (rows / 2048) ** 0.5)
+
+
+def test_blocks_with_and_without_the_layernorm_fold_agree_and_the_fold_is_reproducible(mods):
+    ab, fa, _, make_ffn = mods
+    torch.manual_seed(3)
+    E = 288
+    ffn = make_ffn(E, 256, 0.1).cuda().eval()
+    norm = torch.nn.LayerNorm(E).cuda()
+    x = torch.randn(8, 256, E, device="cuda", requires_grad=True)
+    probe = torch.randn(8, 256, E, device="cuda")
+
+    def run():
+        for t in [x] + list(norm.parameters()) + list(ffn.parameters()):
+            t.grad = None
+        (fa.ffn_block(ffn, norm, x) * probe).sum().backward()
+        return [t.grad.clone() for t in [x] + list(norm.parameters()) + list(ffn.parameters())]
+
+    prev = fa.set_ln_fold(True)
+    try:
+        g1, g2 = run(), run()
+        fa.set_ln_fold(False)
+        g0 = run()
+    finally:
+        fa.set_ln_fold(prev)
+    assert torch.equal(g1[1], g2[1]) and torch.equal(g1[2], g2[2])      # dgamma, dbeta: no atomics, bit-reproducible
+    for a, b in zip(g1, g0):
+        _close(a, b, 1e-5)
