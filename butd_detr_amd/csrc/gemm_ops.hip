@@ -21,6 +21,8 @@
 //     a block ...) in a 1-D grid; epilogues: bias / scale / ReLU / dropout, column sums (BatchNorm
 //     statistics), accumulation into existing tensors (c_add / c2), atomics for split-K.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1076,6 +1078,14 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
       return (int)hipErrorInvalidValue;
     if (fast_eligible(p)) fast_idx[nf++] = i; else slow_idx[ns++] = i;
   }
+  static const bool log_slow = getenv("BUTD_GEMM_LOG_SLOW") != nullptr;   // which problems miss the float4 path (stderr)
+  if (log_slow)
+    for (int j = 0; j < ns; ++j) {
+      const butd_gemm_problem &p = problems[slow_idx[j]];
+      fprintf(stderr, "butd_gemm slow: M %d N %d K %d lda (%ld,%ld) ldb (%ld,%ld) split %d a2 %d ones %d align %d of %d in group\n",
+              p.M, p.N, p.K, (long)p.lda_m, (long)p.lda_k, (long)p.ldb_n, (long)p.ldb_k, p.split_k, p.a2 != nullptr,
+              (int)p.ones_col, (int)((((uintptr_t)p.a) | ((uintptr_t)p.b)) & 15), count);
+    }
   int err = launch_group(problems, fast_idx, nf, true, rng_counter, (hipStream_t)stream);
   if (err) return err;
   return launch_group(problems, slow_idx, ns, false, rng_counter, (hipStream_t)stream);
