@@ -717,7 +717,8 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
     // (scratch/ubench/mfma_valu.hip), so every instruction of this epilogue is paid in matrix time: per float4 it is
     // one ds_read_b128, 4 fma (+4 max, +8 for the column statistics, +4 for an accumulating store) and one store.
     if (m0 + TM <= pM && n0 + TN <= pN && !drop && P.c2 == nullptr && (ldc & 3) == 0 &&
-        (((uintptr_t)cptr | (uintptr_t)P.bias | (uintptr_t)P.c_gate) & 15) == 0) {
+        (((uintptr_t)cptr | (uintptr_t)P.bias | (uintptr_t)P.c_gate | (uintptr_t)P.c_bn_z | (uintptr_t)P.c_bn_aff) & 15) == 0 &&
+        (P.c_bn_ld & 3) == 0) {
       double *const col_sum = P.col_sum, *const col_sumsq = P.col_sumsq;
       const bool c_add = P.c_add != 0;
       const bool streaming = !c_add && (long)pM * pN >= (16L << 20);   // >= 64 MB
@@ -729,6 +730,17 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
       f32x4 cs = {0.f, 0.f, 0.f, 0.f}, cq = {0.f, 0.f, 0.f, 0.f};
       const float *const gate = P.c_gate;
       const float gate_scale = P.c_gate_scale;
+      // c_bn: the gate is the ReLU of a BatchNorm (scale * z + shift > 0, z = the saved pre-activation in C's layout) and
+      // the statistics are the two column sums its backward needs: sum g, sum g * zhat
+      const float *const bnz = P.c_bn_z;
+      f32x4 bn_mu = {0.f, 0.f, 0.f, 0.f}, bn_rs = bn_mu, bn_sc = bn_mu, bn_sh = bn_mu;
+      if (bnz && active) {
+        const float *af = P.c_bn_aff + n;
+        bn_mu = *reinterpret_cast<const f32x4 *>(af);
+        bn_rs = *reinterpret_cast<const f32x4 *>(af + P.c_bn_ld);
+        bn_sc = *reinterpret_cast<const f32x4 *>(af + 2 * P.c_bn_ld);
+        bn_sh = *reinterpret_cast<const f32x4 *>(af + 3 * P.c_bn_ld);
+      }
       auto rows = [&](auto relu_t, auto stats_t, auto add_t) {
         if (!active) return;
         float *dst = cptr + (long)(m0 + rphase) * ldc + n;
@@ -745,8 +757,17 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
             v[2] = gt[2] > 0.f ? v[2] * gate_scale : 0.f; v[3] = gt[3] > 0.f ? v[3] * gate_scale : 0.f;
           }
           if constexpr (decltype(stats_t)::value) {
-            cs += v;
-            cq += v * v;
+            if (bnz) {   // (uniform)
+              const f32x4 z4 = *reinterpret_cast<const f32x4 *>(bnz + (dst - cptr));
+              const f32x4 pre = z4 * bn_sc + bn_sh;
+              v[0] = pre[0] > 0.f ? v[0] : 0.f; v[1] = pre[1] > 0.f ? v[1] : 0.f;
+              v[2] = pre[2] > 0.f ? v[2] : 0.f; v[3] = pre[3] > 0.f ? v[3] : 0.f;
+              cs += v;
+              cq += v * ((z4 - bn_mu) * bn_rs);
+            } else {
+              cs += v;
+              cq += v * v;
+            }
           }
           if constexpr (decltype(add_t)::value) v += *reinterpret_cast<const f32x4 *>(dst);
           store_c4(dst, make_float4(v[0], v[1], v[2], v[3]), streaming);
@@ -811,8 +832,16 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
             v[e] = rng::keep(ctr, site, (uint32_t)((long)m * pN + n + e), p_drop) ? v[e] * inv_keep : 0.f;
           if (P.c_gate && n + e < pN) v[e] = P.c_gate[(long)m * ldc + n + e] > 0.f ? v[e] * P.c_gate_scale : 0.f;
           if (n + e < pN) {
-            cs[e] += v[e];
-            cq[e] += v[e] * v[e];
+            if (P.c_bn_z) {
+              const float *af = P.c_bn_aff + n + e;
+              const float z = P.c_bn_z[(long)m * ldc + n + e];
+              v[e] = (z * af[2 * P.c_bn_ld] + af[3 * P.c_bn_ld] > 0.f) ? v[e] : 0.f;
+              cs[e] += v[e];
+              cq[e] += v[e] * ((z - af[0]) * af[P.c_bn_ld]);
+            } else {
+              cs[e] += v[e];
+              cq[e] += v[e] * v[e];
+            }
           }
         }
         float *dst = cptr + (long)m * ldc + n;
@@ -1072,6 +1101,8 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
     if ((p.col_sum != nullptr || p.c_add || p.c2 != nullptr || p.c_gate != nullptr) && (p.accumulate || p.ones_col || p.split_k > 1))
       return (int)hipErrorInvalidValue;
     if (p.col_slots > 1 && (p.col_slots & (p.col_slots - 1))) return (int)hipErrorInvalidValue;
+    if (p.c_bn_z && (!p.c_bn_aff || !p.col_sum || !p.col_sumsq || p.relu || p.dropout_p > 0.f || p.c2 != nullptr))
+      return (int)hipErrorInvalidValue;
     // (the in-kernel BatchNorm bookkeeping exists on the float4 path only, on unsplit forward products)
     if (p.a_bn_sum && (!fast_eligible(p) || p.split_k > 1 || !p.a_bn_sumsq || !p.a_bn_gamma || !p.a_bn_beta ||
                        p.a_bn_count <= 0 || p.a_chan_scale))

@@ -170,7 +170,7 @@ def get_compute_dtype():
 def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.0, bias=None,
              bias_grad=None, scale=1.0, relu=False, accumulate=False, ones_col=False, split_k=1,
              dropout_p=0.0, site=0, a_affine=None, b_affine=None, a_drop=(0.0, 0), b_drop=(0.0, 0),
-             col_stats=None, c_add=False, c2=None, col_slots=(0, 0), gate=None, gate_scale=1.0, a_bn=None):
+             col_stats=None, c_add=False, c2=None, col_slots=(0, 0), gate=None, gate_scale=1.0, a_bn=None, c_bn=None):
     """a_bn = (sum, sumsq, gamma, beta, running_mean, running_var, nbt, out (4 rows), ld_out, count, eps, momentum): the A
     operand's BatchNorm + ReLU computed by the kernel from the producer's column sums (butd_gemm_problem.a_bn_*)."""
     asc, ash = a_affine if a_affine is not None else (None, None)
@@ -184,9 +184,12 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                        _ptr(col_stats[1]) if col_stats is not None else None,
                        int(c_add), _ptr(c2), int(col_slots[0]), int(col_slots[1]), int(_compute_bf16[0]),
                        _ptr(gate), float(gate_scale),
-                       *(() if a_bn is None else (_ptr(a_bn[0]), _ptr(a_bn[1]), _ptr(a_bn[2]), _ptr(a_bn[3]), _ptr(a_bn[4]),
-                                                  _ptr(a_bn[5]), _ptr(a_bn[6]), _ptr(a_bn[7]), int(a_bn[8]), int(a_bn[9]),
-                                                  float(a_bn[10]), float(a_bn[11]))))
+                       *((None,) * 8 + (0, 0, 0.0, 0.0) if a_bn is None else
+                         (_ptr(a_bn[0]), _ptr(a_bn[1]), _ptr(a_bn[2]), _ptr(a_bn[3]), _ptr(a_bn[4]),
+                          _ptr(a_bn[5]), _ptr(a_bn[6]), _ptr(a_bn[7]), int(a_bn[8]), int(a_bn[9]),
+                          float(a_bn[10]), float(a_bn[11]))),
+                       # c_bn = (z, aff (4 rows: mean, rstd, scale, shift), ld of aff): butd_gemm_problem.c_bn_*
+                       *(() if c_bn is None else (_ptr(c_bn[0]), _ptr(c_bn[1]), int(c_bn[2]))))
 
 
 def _gemm(problems, ref):

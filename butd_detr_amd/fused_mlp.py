@@ -14,6 +14,8 @@ MIOpen with NCHW transposes, BatchNorm, ReLU, Dropout kernels and their backward
 A chain ends either in a plain convolution (heads, position embeddings) or -- ``out is None`` -- in
 BatchNorm + ReLU (SharedMLP), whose activation is then materialised by ``butd_mlp_bn_relu_apply``.
 """
+import os
+
 import torch
 
 from . import _hiplib
@@ -22,6 +24,14 @@ from .fused_attention import _gemm, _problem, _stream, rng_counter, _site, zeros
 
 _lib = _hiplib.load()
 _FOLD_BN = [__import__("os").environ.get("BUTD_FOLD_BN", "1") != "0"]     # A/B switch of the in-product BatchNorm bookkeeping
+
+
+_FUSE_STATS = [os.environ.get("BUTD_MLP_FUSE_STATS", "1") == "1"]
+
+
+def set_fuse_stats(flag):
+    prev, _FUSE_STATS[0] = _FUSE_STATS[0], bool(flag)
+    return prev
 
 
 def _call(name, ref, *args):
@@ -179,6 +189,20 @@ class _MlpChains(torch.autograd.Function):
                             ones_col=db is not None, accumulate=True, split_k=_split(P),
                             b_affine=b_aff, b_drop=b_drop)
 
+        # The product that CREATES the gradient arriving at layer l's BatchNorm + ReLU applies the ReLU gate and leaves the
+        # two column sums of the BatchNorm backward behind (butd_gemm_problem.c_bn_*): butd_mlp_mask_stats then has
+        # nothing left to do for that layer.  Not with a dropout behind the activation (its mask lives in mask_stats) and
+        # not for the gradient that arrives from outside (a BatchNorm + ReLU tail).  BUTD_MLP_FUSE_STATS=0: round 3's launches.
+        p_of = lambda l: 0.0 if (spec.tail and l == nh - 1) else float(p)
+        fused_stats = lambda l: _FUSE_STATS[0] and p_of(l) == 0.0
+
+        def bn_epilogue(l, i):
+            if not fused_stats(l):
+                return {}
+            s_ = sl(l, i)
+            return dict(c_bn=(Z[l][:, s_], aff[l, 0, s_], aff.stride(1)), col_stats=(S[l, 0, s_], S[l, 1, s_]))
+
+        stats_done = False
         GHl = G * Hs[-1]
         if spec.tail:      # d(out) is d(relu(bn(z))) of the last layer: it IS that layer's dH
             dH = d_outs[0].contiguous()
@@ -201,17 +225,19 @@ class _MlpChains(torch.autograd.Function):
                 n_out, ldo = spec.outs[i], d_outs[i].stride(0)
                 probs.append(wgrad(d_outs[i], ldo, n_out, nh, i, dWo[i][0], dWo[i][1]))
                 probs.append(_problem(d_outs[i], outp[i][0], dH[:, sl(nh - 1, i)], P, Hs[-1], n_out,
-                                      (ldo, 1), (1, Hs[-1]), GHl))
+                                      (ldo, 1), (1, Hs[-1]), GHl, **bn_epilogue(nh - 1, i)))
             _gemm(probs, x)
+            stats_done = fused_stats(nh - 1)
         need_dx = ctx.needs_input_grad[0]
         dx = None
         for l in reversed(range(nh)):
             H, GH = Hs[l], G * Hs[l]
             # the activation of a BatchNorm+ReLU tail is not followed by a dropout
-            p_l = 0.0 if (spec.tail and l == nh - 1) else float(p)
-            _call("butd_mlp_mask_stats", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
-                  aff[l, 3].data_ptr(), aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), p_l,
-                  spec.site0 + l * G, H, rng_counter(dev).data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr())
+            p_l = p_of(l)
+            if not stats_done:
+                _call("butd_mlp_mask_stats", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
+                      aff[l, 3].data_ptr(), aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), p_l,
+                      spec.site0 + l * G, H, rng_counter(dev).data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr())
             _call("butd_mlp_dz", x, P, GH, GH, dH.data_ptr(), Z[l].data_ptr(), aff[l, 2].data_ptr(),
                   aff[l, 0].data_ptr(), aff[l, 1].data_ptr(), S[l, 0].data_ptr(), S[l, 1].data_ptr(),
                   int(spec.training), Sf[l, 0].data_ptr(), Sf[l, 1].data_ptr())
@@ -227,11 +253,12 @@ class _MlpChains(torch.autograd.Function):
                 if l > 0:
                     Hp = Hs[l - 1]
                     probs.append(_problem(dZ[:, sl(l, i)], w, dH[:, sl(l - 1, i)], P, Hp, H, (GH, 1), (1, Hp),
-                                          G * Hp))
+                                          G * Hp, **bn_epilogue(l - 1, i)))
                 elif need_dx:
                     probs.append(_problem(dZ[:, sl(l, i)], w, dx, P, Cin, H, (GH, 1), (1, Cin), Cin,
                                           accumulate=G > 1))
             _gemm(probs, x)
+            stats_done = l > 0 and fused_stats(l - 1)
         grads = []
         for i in range(G):
             for l in range(nh):

@@ -100,6 +100,16 @@ typedef struct {
   float *a_bn_out;
   long a_bn_ld, a_bn_count;
   float a_bn_eps, a_bn_momentum;
+  /* Optional: the stored result is the gradient that arrives at a BatchNorm + ReLU (a Conv1d + BatchNorm + ReLU chain's
+   * backward, pytorch_utils.py:39-58 / models/modules.py:19-42), and this product applies the ReLU gate and leaves the two
+   * column sums of the BatchNorm backward behind -- what butd_mlp_mask_stats (include/butd_mlp.h) did in a pass of its own:
+   *   z = c_bn_z[m*ldc + n] (the layer's saved pre-activation, C's layout),  mean, rstd, scale, shift = c_bn_aff[0..3][n]
+   *   (rows c_bn_ld floats apart: the a_bn_out table of the forward pass),
+   *   g = scale * z + shift > 0 ? epilogue(v) : 0;   C[m,n] <- g;
+   *   col_sum[n] += sum_m g,   col_sumsq[n] += sum_m g * (z - mean) * rstd       (double, atomics; caller zero-fills)
+   * Plain-store problems without ReLU / output dropout / c2; col_sum and col_sumsq are required. */
+  const float *c_bn_z, *c_bn_aff;
+  long c_bn_ld;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).

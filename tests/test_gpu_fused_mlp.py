@@ -267,3 +267,44 @@ def test_fp_module_matches_torch(backend, train, mlp, n, m):
         return [out], [a.grad, k.grad]
 
     _compare(backend, ref, fused, run, train)
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,Q", [(8, 256), (2, 100)])
+def test_gate_and_statistics_in_the_product_epilogue_equal_the_separate_pass(backend, train, B, Q):
+    """butd_gemm_problem.c_bn_* (the product that creates a hidden gradient applies the BatchNorm + ReLU gate and leaves
+    the two column sums of the BatchNorm backward) against butd_mlp_mask_stats as a pass of its own: same gradients for
+    a whole predict head (three chains; the 3-wide box heads go through the element-wise staged kernel, the 256-wide
+    class head through the float4 one; (2, 100): ragged row tiles)."""
+    from butd_detr_amd import fused_mlp
+    from butd_detr_amd.modules import ClsAgnosticPredictHead
+    torch.manual_seed(Q)
+    head = ClsAgnosticPredictHead(256, 1, Q, 288, objectness=True, heading=False, compute_sem_scores=True).cuda()
+    _randomize_bn(head)
+    _set_dropout(head, 0.0)
+    head.train(train)
+    feats = torch.randn(B, Q, 288, device="cuda")
+    base = torch.randn(B, Q, 3, device="cuda")
+    probes = [torch.randn(B, Q, 3, device="cuda"), torch.randn(B, Q, 3, device="cuda"),
+              torch.randn(B, Q, 256, device="cuda"), torch.randn(B, Q, device="cuda")]
+
+    def run():
+        for p_ in head.parameters():
+            p_.grad = None
+        x = feats.clone().requires_grad_(True)
+        ep = {}
+        center, size = head(x.transpose(1, 2), base, ep, prefix="t_", features_pm=x)
+        outs = [center, size, ep["t_sem_cls_scores"], ep["t_objectness_scores"]]
+        sum((o * p_).sum() for o, p_ in zip(outs, probes)).backward()
+        return [x.grad.clone()] + [p_.grad.clone() for p_ in head.parameters() if p_.grad is not None]
+
+    prev = fused_mlp.set_fuse_stats(True)
+    try:
+        g_fused = run()
+        fused_mlp.set_fuse_stats(False)
+        g_sep = run()
+    finally:
+        fused_mlp.set_fuse_stats(prev)
+    assert len(g_fused) == len(g_sep) > 10
+    for a, b in zip(g_fused, g_sep):
+        _close(a, b, 2e-5)
