@@ -58,7 +58,8 @@ class GemmProblem(ctypes.Structure):
                 ("a_bn_running_mean", _c_void_p), ("a_bn_running_var", _c_void_p), ("a_bn_nbt", _c_void_p),
                 ("a_bn_out", _c_void_p), ("a_bn_ld", _c_long), ("a_bn_count", _c_long),
                 ("a_bn_eps", _c_float), ("a_bn_momentum", _c_float),
-                ("c_bn_z", _c_void_p), ("c_bn_aff", _c_void_p), ("c_bn_ld", _c_long)]
+                ("c_bn_z", _c_void_p), ("c_bn_aff", _c_void_p), ("c_bn_ld", _c_long),
+                ("c_bn_drop_p", _c_float), ("c_bn_drop_site", _c_u32)]
 
 
 ATTENTION_SYMBOLS = {

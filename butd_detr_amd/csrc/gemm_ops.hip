@@ -273,7 +273,7 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
   const bool ones = P.ones_col != 0;
   // operand dropout: the (step, site) halves of the hash are kernel-invariant
   const bool a_dropout = P.a_drop_p > 0.f, b_dropout = P.b_drop_p > 0.f;
-  const uint64_t step_ctr = ((a_dropout || b_dropout || P.dropout_p > 0.f) && rng_counter) ? *rng_counter : 0ull;
+  const uint64_t step_ctr = ((a_dropout || b_dropout || P.dropout_p > 0.f || P.c_bn_drop_p > 0.f) && rng_counter) ? *rng_counter : 0ull;
   const uint32_t a_key = rng::site_key(step_ctr, P.a_drop_site), b_key = rng::site_key(step_ctr, P.b_drop_site);
   const float a_inv = a_dropout ? 1.f / (1.f - P.a_drop_p) : 1.f, b_inv = b_dropout ? 1.f / (1.f - P.b_drop_p) : 1.f;
 
@@ -741,6 +741,11 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
         bn_sc = *reinterpret_cast<const f32x4 *>(af + 2 * P.c_bn_ld);
         bn_sh = *reinterpret_cast<const f32x4 *>(af + 3 * P.c_bn_ld);
       }
+      // ... with a Dropout behind that ReLU (models/modules.py:64-72): its mask, regenerated as butd_mlp_mask_stats did
+      const float bn_p = P.c_bn_drop_p;
+      const bool bn_drop = bnz && bn_p > 0.f;
+      const float bn_inv = bn_drop ? 1.f / (1.f - bn_p) : 1.f;
+      const uint32_t bn_key = bn_drop ? rng::site_key(ctr, P.c_bn_drop_site) : 0u;
       auto rows = [&](auto relu_t, auto stats_t, auto add_t) {
         if (!active) return;
         float *dst = cptr + (long)(m0 + rphase) * ldc + n;
@@ -762,6 +767,11 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
               const f32x4 pre = z4 * bn_sc + bn_sh;
               v[0] = pre[0] > 0.f ? v[0] : 0.f; v[1] = pre[1] > 0.f ? v[1] : 0.f;
               v[2] = pre[2] > 0.f ? v[2] : 0.f; v[3] = pre[3] > 0.f ? v[3] : 0.f;
+              if (bn_drop) {   // (uniform)
+                const uint32_t i0 = (uint32_t)(dst - cptr);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = rng::keep_keyed(bn_key, i0 + (uint32_t)e, bn_p) ? v[e] * bn_inv : 0.f;
+              }
               cs += v;
               cq += v * ((z4 - bn_mu) * bn_rs);
             } else {
@@ -836,6 +846,9 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
               const float *af = P.c_bn_aff + n + e;
               const float z = P.c_bn_z[(long)m * ldc + n + e];
               v[e] = (z * af[2 * P.c_bn_ld] + af[3 * P.c_bn_ld] > 0.f) ? v[e] : 0.f;
+              if (P.c_bn_drop_p > 0.f)
+                v[e] = rng::keep(ctr, P.c_bn_drop_site, (uint32_t)((long)m * ldc + n + e), P.c_bn_drop_p)
+                           ? v[e] * (1.f / (1.f - P.c_bn_drop_p)) : 0.f;
               cs[e] += v[e];
               cq[e] += v[e] * ((z - af[0]) * af[P.c_bn_ld]);
             } else {

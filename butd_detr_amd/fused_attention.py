@@ -188,8 +188,8 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                          (_ptr(a_bn[0]), _ptr(a_bn[1]), _ptr(a_bn[2]), _ptr(a_bn[3]), _ptr(a_bn[4]),
                           _ptr(a_bn[5]), _ptr(a_bn[6]), _ptr(a_bn[7]), int(a_bn[8]), int(a_bn[9]),
                           float(a_bn[10]), float(a_bn[11]))),
-                       # c_bn = (z, aff (4 rows: mean, rstd, scale, shift), ld of aff): butd_gemm_problem.c_bn_*
-                       *(() if c_bn is None else (_ptr(c_bn[0]), _ptr(c_bn[1]), int(c_bn[2]))))
+                       # c_bn = (z, aff (4 rows: mean, rstd, scale, shift), ld of aff, dropout p, site): butd_gemm_problem.c_bn_*
+                       *(() if c_bn is None else (_ptr(c_bn[0]), _ptr(c_bn[1]), int(c_bn[2]), float(c_bn[3]), int(c_bn[4]))))
 
 
 def _gemm(problems, ref):

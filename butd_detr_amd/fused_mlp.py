@@ -191,16 +191,17 @@ class _MlpChains(torch.autograd.Function):
 
         # The product that CREATES the gradient arriving at layer l's BatchNorm + ReLU applies the ReLU gate and leaves the
         # two column sums of the BatchNorm backward behind (butd_gemm_problem.c_bn_*): butd_mlp_mask_stats then has
-        # nothing left to do for that layer.  Not with a dropout behind the activation (its mask lives in mask_stats) and
-        # not for the gradient that arrives from outside (a BatchNorm + ReLU tail).  BUTD_MLP_FUSE_STATS=0: round 3's launches.
+        # nothing left to do for that layer (a dropout behind the activation included: the same counter hash).  Not for the
+        # gradient that arrives from outside (a BatchNorm + ReLU tail).  BUTD_MLP_FUSE_STATS=0: round 3's launches.
         p_of = lambda l: 0.0 if (spec.tail and l == nh - 1) else float(p)
-        fused_stats = lambda l: _FUSE_STATS[0] and p_of(l) == 0.0
+        fused_stats = lambda l: _FUSE_STATS[0]
 
         def bn_epilogue(l, i):
             if not fused_stats(l):
                 return {}
             s_ = sl(l, i)
-            return dict(c_bn=(Z[l][:, s_], aff[l, 0, s_], aff.stride(1)), col_stats=(S[l, 0, s_], S[l, 1, s_]))
+            return dict(c_bn=(Z[l][:, s_], aff[l, 0, s_], aff.stride(1), p_of(l), spec.site0 + l * G + i),
+                        col_stats=(S[l, 0, s_], S[l, 1, s_]))
 
         stats_done = False
         GHl = G * Hs[-1]

@@ -107,9 +107,14 @@ typedef struct {
    *   (rows c_bn_ld floats apart: the a_bn_out table of the forward pass),
    *   g = scale * z + shift > 0 ? epilogue(v) : 0;   C[m,n] <- g;
    *   col_sum[n] += sum_m g,   col_sumsq[n] += sum_m g * (z - mean) * rstd       (double, atomics; caller zero-fills)
+   * With c_bn_drop_p > 0 the activation was followed by a Dropout (ThreeLayerMLP, models/modules.py:64-72):
+   *   g <- keep(step counter, c_bn_drop_site, m*ldc + n) ? g / (1 - p) : 0     before it is stored and summed
+   * -- the mask the forward drew for the operand with base pointer c_bn_z's twin (same site, same element offsets).
    * Plain-store problems without ReLU / output dropout / c2; col_sum and col_sumsq are required. */
   const float *c_bn_z, *c_bn_aff;
   long c_bn_ld;
+  float c_bn_drop_p;
+  uint32_t c_bn_drop_site;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).

@@ -269,19 +269,21 @@ def test_fp_module_matches_torch(backend, train, mlp, n, m):
     _compare(backend, ref, fused, run, train)
 
 
-@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("train,p_drop", [(True, 0.0), (True, 0.3), (False, 0.0)])
 @pytest.mark.parametrize("B,Q", [(8, 256), (2, 100)])
-def test_gate_and_statistics_in_the_product_epilogue_equal_the_separate_pass(backend, train, B, Q):
+def test_gate_and_statistics_in_the_product_epilogue_equal_the_separate_pass(backend, train, p_drop, B, Q):
     """butd_gemm_problem.c_bn_* (the product that creates a hidden gradient applies the BatchNorm + ReLU gate and leaves
     the two column sums of the BatchNorm backward) against butd_mlp_mask_stats as a pass of its own: same gradients for
     a whole predict head (three chains; the 3-wide box heads go through the element-wise staged kernel, the 256-wide
-    class head through the float4 one; (2, 100): ragged row tiles)."""
+    class head through the float4 one; (2, 100): ragged row tiles; p 0.3: the reference's Dropout behind every hidden
+    activation, its mask regenerated inside the epilogue)."""
     from butd_detr_amd import fused_mlp
     from butd_detr_amd.modules import ClsAgnosticPredictHead
+    backend.set_backend("hip")               # (the fixture only restores the stock backend afterwards)
     torch.manual_seed(Q)
     head = ClsAgnosticPredictHead(256, 1, Q, 288, objectness=True, heading=False, compute_sem_scores=True).cuda()
     _randomize_bn(head)
-    _set_dropout(head, 0.0)
+    _set_dropout(head, p_drop)
     head.train(train)
     feats = torch.randn(B, Q, 288, device="cuda")
     base = torch.randn(B, Q, 3, device="cuda")
@@ -289,6 +291,8 @@ def test_gate_and_statistics_in_the_product_epilogue_equal_the_separate_pass(bac
               torch.randn(B, Q, 256, device="cuda"), torch.randn(B, Q, device="cuda")]
 
     def run():
+        from butd_detr_amd import fused_attention
+        fused_attention._site[0] = 0          # the same dropout sites (= the same masks) in both runs
         for p_ in head.parameters():
             p_.grad = None
         x = feats.clone().requires_grad_(True)
@@ -308,3 +312,7 @@ def test_gate_and_statistics_in_the_product_epilogue_equal_the_separate_pass(bac
     assert len(g_fused) == len(g_sep) > 10
     for a, b in zip(g_fused, g_sep):
         _close(a, b, 2e-5)
+    if train and p_drop > 0:                 # the fused chains ran: a second step draws other masks
+        from butd_detr_amd import fused_attention
+        fused_attention.new_step(feats.device)
+        assert not torch.equal(run()[0], g_sep[0])
