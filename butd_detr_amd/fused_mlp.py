@@ -26,7 +26,8 @@ _lib = _hiplib.load()
 _FOLD_BN = [__import__("os").environ.get("BUTD_FOLD_BN", "1") != "0"]     # A/B switch of the in-product BatchNorm bookkeeping
 
 
-_FUSE_STATS = [os.environ.get("BUTD_MLP_FUSE_STATS", "1") == "1"]
+_FUSE_STATS = [os.environ.get("BUTD_MLP_FUSE_STATS", "1") != "0"]
+_FUSE_DROP = [os.environ.get("BUTD_MLP_FUSE_STATS", "1") != "nodrop"]      # "nodrop": only chains without a Dropout (A/B)
 
 
 def set_fuse_stats(flag):
@@ -194,7 +195,7 @@ class _MlpChains(torch.autograd.Function):
         # nothing left to do for that layer (a dropout behind the activation included: the same counter hash).  Not for the
         # gradient that arrives from outside (a BatchNorm + ReLU tail).  BUTD_MLP_FUSE_STATS=0: round 3's launches.
         p_of = lambda l: 0.0 if (spec.tail and l == nh - 1) else float(p)
-        fused_stats = lambda l: _FUSE_STATS[0]
+        fused_stats = lambda l: _FUSE_STATS[0] and (_FUSE_DROP[0] or p_of(l) == 0.0)
 
         def bn_epilogue(l, i):
             if not fused_stats(l):
