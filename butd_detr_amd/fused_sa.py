@@ -81,6 +81,7 @@ def _last_scratch(P, C2, C3):
     return _scratch_sizes[key]
 
 
+_FUSE_STATS = [os.environ.get("BUTD_SA_FUSE_STATS", "1") != "0"]   # layer 1's gate + BatchNorm-backward sums in the epilogue of the product that creates dH1
 _GATHER = [os.environ.get("BUTD_SA_GATHER", "1") != "0"]      # feature gradient as a gather over the inverted neighbour lists
 
 
@@ -306,8 +307,16 @@ class _SAMlpPool(torch.autograd.Function):
               shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
         dZ2 = dH2
         dH1 = torch.empty((P, C1), device=dev)
+        # butd_sa_mask_stats of layer 1 as an epilogue mode of the product that writes dH1 (butd_gemm_problem.c_bn_*); the
+        # 10^3..10^4 row tiles of a column add into 16 private copies of the sums (col_slots), folded below
+        fuse1 = _FUSE_STATS[0] and not first_lin and C1 % 4 == 0
+        if fuse1:
+            Sx = zeros((16, 2, C1), dtype=torch.float64, device=dev)
+            bn1 = dict(c_bn=(Z1, aff[0, 0], aff.stride(1), 0.0, 0), col_stats=(Sx[0, 0], Sx[0, 1]), col_slots=(16, 2 * C1))
+        else:
+            bn1 = {}
         _gemm([_wgrad(dZ2, Z1, dW2, None, P, C2, C1, b_affine=(scale(0), shift(0))),
-               _dgrad(dZ2, w2, dH1, P, C2, C1)], X)
+               _dgrad(dZ2, w2, dH1, P, C2, C1, **bn1)], X)
         # ---- layer 1
         if first_lin:
             # no input gradient wanted (SA1): the sums and dW1 from one pass over (dH1, Z1, X) -- no dZ1, no thin product
@@ -318,9 +327,12 @@ class _SAMlpPool(torch.autograd.Function):
                   shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), w1.data_ptr(), dW1.data_ptr(),
                   S[0, 0].data_ptr(), S[0, 1].data_ptr(), ws_f.data_ptr(), ws_d.data_ptr())
         else:
-            _call("butd_sa_mask_stats", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), scale(0).data_ptr(),
-                  shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
-                  S[0, 1].data_ptr())
+            if fuse1:
+                S[0, :, :C1] = Sx.sum(0)
+            else:
+                _call("butd_sa_mask_stats", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), scale(0).data_ptr(),
+                      shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
+                      S[0, 1].data_ptr())
             _call("butd_sa_dz_mid", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), g1.data_ptr(), scale(0).data_ptr(),
                   shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), tr)
             dZ1 = dH1

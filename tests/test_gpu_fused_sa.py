@@ -119,3 +119,41 @@ def test_sa_level_as_one_kernel_in_eval_mode(cfg):
     _close(y2, y1, 1e-4)
     _close(pm.transpose(1, 2), y1, 1e-4)
     _close(y2, y3, 1e-4)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_first_layer_gate_and_sums_in_the_product_epilogue_equal_butd_sa_mask_stats(train):
+    """SA2's shape: layer 1's ReLU gate and BatchNorm-backward column sums as an epilogue mode of the product that writes
+    dH1 (butd_gemm_problem.c_bn_* with 16 private copies of the sums) against butd_sa_mask_stats as its own pass."""
+    from butd_detr_amd import attention_blocks, fused_sa
+    from butd_detr_amd.pointnet2_modules import PointnetSAModuleVotes
+    torch.manual_seed(7)
+    mod = PointnetSAModuleVotes(npoint=1024, radius=0.6, nsample=32, mlp=[128, 128, 128, 256], use_xyz=True,
+                                normalize_xyz=True).cuda().train(train)
+    xyz = torch.rand(2, 2048, 3, device="cuda") * 2 - 1
+    feats = torch.randn(2, 128, 2048, device="cuda")
+    probe = torch.randn(2, 256, 1024, device="cuda")
+    state = {n: b.clone() for n, b in mod.named_buffers()}
+
+    def run(flag):
+        prev, fused_sa._FUSE_STATS[0] = fused_sa._FUSE_STATS[0], flag
+        try:
+            with torch.no_grad():
+                for n, b in mod.named_buffers():
+                    b.copy_(state[n])
+            mod.zero_grad()
+            f = feats.clone().requires_grad_(True)
+            _, y, _ = mod(xyz, f)
+            assert mod.last_features_pm is not None, "fused path not taken"
+            (y * probe).sum().backward()
+            return [f.grad.clone()] + [p.grad.clone() for p in mod.parameters()]
+        finally:
+            fused_sa._FUSE_STATS[0] = prev
+
+    attention_blocks.set_backend("hip")
+    try:
+        on, off = run(True), run(False)
+    finally:
+        attention_blocks.set_backend("torch")
+    for a, b in zip(on, off):
+        _close(a, b, 2e-5)
