@@ -558,9 +558,30 @@ def make_criterion(args):
     return HungarianCriterion(num_decoder_layers=6, use_contrastive_align=True, use_soft_token_loss=True)
 
 
+def _spawn_ranks(args):
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves, exactly the way the driver's
+    torch.distributed.run line does (one process per GPU, env:// rendezvous on 127.0.0.1, RCCL), and hand its exit code
+    back.  The ranks' stdout is inherited, so rank 0's JSON line is this command's last line too."""
+    import socket
+    import subprocess
+    if not os.environ.get("BUTD_BENCH_ONE_GPU") and torch.cuda.device_count() < args.gpus:
+        sys.exit(f"bench.py --gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s)")
+    with socket.socket() as sock:              # a free rendezvous port (released before torchrun binds it)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.roofline_child:
+        _spawn_ranks(args)                     # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and not args.roofline_child and os.environ.get("BUTD_BENCH_FORCE_DIST") != "1":
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
@@ -578,6 +599,8 @@ def main():
         # N>1 code path can be rehearsed on a one-GPU box (tests/test_gpu_two_ranks.py): RCCL refuses two ranks
         # on one device
         dist.init_process_group(backend=os.environ.get("BUTD_BENCH_BACKEND", "nccl"), init_method="env://")
+    ranks_in_group = dist.get_world_size() if dist.is_initialized() else 1     # what the backend itself reports
+    assert ranks_in_group == world, (ranks_in_group, world)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     device = torch.device("cuda", 0 if os.environ.get("BUTD_BENCH_ONE_GPU") else local_rank)
     torch.cuda.set_device(device)
@@ -660,6 +683,8 @@ def main():
                        "criterion": ("compute_hungarian_loss (matcher 1/0/2, soft token + contrastive align, "
                                      "assignment on the device)" if criterion is not None else "dense surrogate"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "ranks_in_process_group": ranks_in_group,
+                       "collective_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "attention_backend": backend, "launch": "eager+DDP+torch AdamW" if args.eager else "hipGraph replay (FPS chain of the next batch prefetched on a forked stream) + flat-gradient all-reduce + packed AdamW", "final_loss": round(float(loss), 4)},
         }
         if backend == "hip":

@@ -165,7 +165,7 @@ CRITERION_SYMBOLS = {
     "butd_contrastive_rows": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P, _P]),
     "butd_seed_objectness": (_c_int, [_c_int] * 5 + [_P] * 10 + [_P]),
     "butd_loss_combine": (_c_int, [_c_int] + [_P] * 6 + [_c_int] + [_c_float] * 3 + [_P, _P]),
-    "butd_loss_combine_bwd": (_c_int, [_c_int, _P] + [_c_float] * 3 + [_P] * 5 + [_P]),
+    "butd_loss_combine_bwd": (_c_int, [_c_int, _P, _P, _c_int] + [_c_float] * 3 + [_P] * 5 + [_P]),
     "butd_contrastive_cols": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P]),
 }
 

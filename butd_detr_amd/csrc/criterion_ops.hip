@@ -477,11 +477,15 @@ __global__ void loss_combine_kernel(int P, const float *ce, const float *bbox, c
   out[1] = s[0]; out[2] = s[1]; out[3] = s[2]; out[4] = s[3];
 }
 
-// gradients of the above for an upstream scalar g: every element of a term gets g * its weight
-__global__ void loss_combine_bwd_kernel(int P, const float *g, float w_gen, float w_sum, float w_bbox, float *d_ce,
-                                        float *d_bbox, float *d_giou, float *d_align, float *d_generation) {
+// gradients of the above for an upstream scalar g: every element of a term gets g * its weight -- and 0 when an assignment
+// failed (the stock expression is torch.where(bad, nan, loss): no gradient reaches the terms of an invalid match)
+__global__ void loss_combine_bwd_kernel(int P, const float *g, const int *status_words, int nstatus, float w_gen,
+                                        float w_sum, float w_bbox, float *d_ce, float *d_bbox, float *d_giou,
+                                        float *d_align, float *d_generation) {
   const int i = threadIdx.x;
-  const float gv = g[0];
+  bool bad = false;
+  for (int j = 0; j < nstatus; ++j) bad = bad || status_words[j] != 0;
+  const float gv = bad ? 0.f : g[0];
   if (i < P) {
     if (d_ce) d_ce[i] = gv * w_sum;
     if (d_bbox) d_bbox[i] = gv * w_sum * w_bbox;
@@ -589,11 +593,12 @@ int butd_loss_combine(int P, const float *loss_ce, const float *loss_bbox, const
   return status();
 }
 
-int butd_loss_combine_bwd(int P, const float *g, float w_gen, float w_sum, float w_bbox, float *d_ce, float *d_bbox,
-                          float *d_giou, float *d_align, float *d_generation, butd_stream_t stream) {
+int butd_loss_combine_bwd(int P, const float *g, const int *status_words, int nstatus, float w_gen, float w_sum,
+                          float w_bbox, float *d_ce, float *d_bbox, float *d_giou, float *d_align, float *d_generation,
+                          butd_stream_t stream) {
   if (P <= 0 || P > 64 || !g) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, P, g, w_gen, w_sum, w_bbox,
-                     d_ce, d_bbox, d_giou, d_align, d_generation);
+  hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, P, g, status_words,
+                     status_words ? nstatus : 0, w_gen, w_sum, w_bbox, d_ce, d_bbox, d_giou, d_align, d_generation);
   return status();
 }
 

@@ -236,6 +236,7 @@ def _check(*tensors):
 # -------------------------------------------------------------------------------------------------
 _ln_fold = [os.environ.get("BUTD_LN_FOLD", "1") == "1"]
 _ones_rows = {}
+_ones_retired = []      # never released: a captured graph may have an older row's address baked in
 
 
 def set_ln_fold(flag):
@@ -248,13 +249,17 @@ def _ones_row(dev, n):
     if t is None or t.numel() < n:
         if torch.cuda.is_current_stream_capturing():      # (a fill captured into a graph has not run yet: no fold now)
             return None
+        if t is not None:
+            _ones_retired.append(t)
         t = torch.ones(max(n, 4096), device=dev)
         _ones_rows[dev] = t
     return t
 
 
 def _ln_bwd(M, E, dy, x, res, gamma, mean, rstd, dx, d_res, d_gamma, d_beta, p, site, ref):
-    """butd_add_dropout_layernorm_bwd; returns the problems the NEXT grouped launch has to carry ([] or the fold)."""
+    """butd_add_dropout_layernorm_bwd; returns the problems the NEXT grouped launch has to carry ([] or the fold).
+    The fold problem owns the partial-sum table (``_keep``): the caller's list keeps it alive until the grouped launch
+    that reads it has been enqueued -- an output of that very launch allocated in between must not land on its memory."""
     dev = ref.device
     nb = _lib.butd_layernorm_bwd_blocks(M)
     ones = None
@@ -275,7 +280,9 @@ def _ln_bwd(M, E, dy, x, res, gamma, mean, rstd, dx, d_res, d_gamma, d_beta, p, 
     _hiplib.check(err, "butd_add_dropout_layernorm_bwd")
     if ones is None:
         return []
-    return [_problem(ones, part, d_gamma, 1, 2 * E, nb, (nb, 1), (1, 2 * E), 2 * E)]
+    fold = _problem(ones, part, d_gamma, 1, 2 * E, nb, (nb, 1), (1, 2 * E), 2 * E)
+    fold._keep = (part, ones)
+    return [fold]
 
 
 # -------------------------------------------------------------------------------------------------

@@ -549,6 +549,7 @@ class _CombineLosses(torch.autograd.Function):
                                                 ptr(terms[4]), ptr(st), 0 if st is None else st.numel(), w_gen, w_sum,
                                                 w_bbox, out.data_ptr(), _stream(bbox)), "butd_loss_combine")
         ctx.cfg = (P, w_gen, w_sum, w_bbox, [None if t is None else t.shape for t in (ce, bbox, giou, align, generation)])
+        ctx.status = st         # (not differentiable; the backward zeroes the gradients of an invalid match)
         parts = out.unbind(0)
         ctx.mark_non_differentiable(*parts[1:])
         return parts
@@ -561,8 +562,10 @@ class _CombineLosses(torch.autograd.Function):
         grads = [None if sh is None else torch.empty(sh, device=g.device) for sh in shapes]
         ptr = lambda t: None if t is None else t.data_ptr()
         with torch.cuda.device(g.device):
-            _hiplib.check(lib.butd_loss_combine_bwd(P, g.data_ptr(), w_gen, w_sum, w_bbox, ptr(grads[0]), ptr(grads[1]),
-                                                    ptr(grads[2]), ptr(grads[3]), ptr(grads[4]), _stream(g)),
+            st = ctx.status
+            _hiplib.check(lib.butd_loss_combine_bwd(P, g.data_ptr(), ptr(st), 0 if st is None else st.numel(), w_gen,
+                                                    w_sum, w_bbox, ptr(grads[0]), ptr(grads[1]), ptr(grads[2]),
+                                                    ptr(grads[3]), ptr(grads[4]), _stream(g)),
                           "butd_loss_combine_bwd")
         return (*grads, None, None, None, None)
 

@@ -92,9 +92,12 @@ int butd_loss_combine(int P, const float *loss_ce, const float *loss_bbox, const
                       const float *loss_align, const float *generation, const int *status_words, int nstatus,
                       float w_gen, float w_sum, float w_bbox, float *out5, butd_stream_t stream);
 
-/* Its gradient for an upstream device scalar g: d term[i] = g * weight (NULL outputs are skipped). */
-int butd_loss_combine_bwd(int P, const float *g, float w_gen, float w_sum, float w_bbox, float *d_ce, float *d_bbox,
-                          float *d_giou, float *d_align, float *d_generation, butd_stream_t stream);
+/* Its gradient for an upstream device scalar g: d term[i] = g * weight (NULL outputs are skipped); all zeros when any
+ * status word is nonzero -- the stock expression torch.where(bad, nan, loss) sends no gradient into an invalid match, and
+ * inside a captured step nobody can look at the loss before the optimizer runs. */
+int butd_loss_combine_bwd(int P, const float *g, const int *status_words, int nstatus, float w_gen, float w_sum,
+                          float w_bbox, float *d_ce, float *d_bbox, float *d_giou, float *d_align, float *d_generation,
+                          butd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,30 @@ def test_bench_runs_its_multi_rank_path():
     assert rec["value"] > 0 and rec["scaling"] == "weak" and "cpu_baseline" not in rec
 
 
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """``python bench.py --gpus 2`` with NO torch.distributed.run in front and no WORLD_SIZE in the environment (the shape
+    of the driver's N = 1 command with another N): bench.py must start the two ranks itself and report what the process
+    group -- not the flag -- says.  Round 4's bench parsed --gpus and never read it."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(BUTD_BENCH_BACKEND="gloo", BUTD_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+           "--points", "8192", "--queries", "64", "--tokens", "24"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["ranks_in_process_group"] == 2
+    assert rec["config"]["global_batch"] == 4 and rec["config"]["collective_backend"] == "gloo"
+    # a launcher that started another number of ranks than --gpus says is an error, not a silently different run
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1"], cwd=ROOT,
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr
+
+
 def test_bench_brings_rccl_up_next_to_the_graph_replays():
     """What one GPU can check of the N > 1 launch: ``backend="nccl"`` (RCCL) initialised at world size 1, the
     step's collectives issued anyway (BUTD_BENCH_FORCE_DIST=1 -> two-piece capture, asynchronous all-reduce of
