@@ -203,7 +203,8 @@ def sa_linear_roofline(args, gemm):
     names = ("sa_last_fwd_kernel", "sa_last_fused_kernel", "sa_last_mfma_kernel", "sa_last_sparse_kernel", "sa_mid_first_kernel",
              "sa_l12_fwd_kernel")
     gemm_calls = sum(c for n, c, _ in _LAST_CHILD_ROWS if "gemm_kernel" in n)
-    steps = gemm_calls / gemm["launches_per_step"]            # steps in the child's trace
+    steps = (sum(c for n, c, _ in _LAST_CHILD_ROWS if "lsap_kernel" in n)
+             or gemm_calls / gemm["launches_per_step"])       # steps in the child's trace
     per = {k: sum(t for n, _, t in _LAST_CHILD_ROWS if k in n) / steps * 1e-6 for k in names}     # ms per step
     ms = sum(per.values())
     if ms <= 0:
@@ -260,21 +261,33 @@ def gemm_roofline(args, fallback_step=None):
         if fallback_step is None:
             raise
         work, avg_ms = _event_timed_gemm_work(fallback_step)
-        calls = work["launches"]
+        calls, total_ns = work["launches"], 0
         source = f"HIP event pairs around every launch of one eager step (rocprofv3 child unavailable: {exc!r:.120})"
-    ms_step = avg_ms * work["launches"]
+    # steps in the child's trace = launches of the assignment kernel (one per step: criterion = hungarian); the grouped
+    # calls counted in Python are NOT the kernel launches (a call with float4-aligned and element-wise staged problems is
+    # two launches, the riders of the deterministic split-K folds none, their final flush one more): round 4 multiplied
+    # the average launch by the calls
+    steps = sum(c for n, c, _ in _LAST_CHILD_ROWS if "lsap_kernel" in n) if source is None else 0
+    if steps > 0:
+        launches = calls / steps
+        ms_step = total_ns / steps * 1e-6
+    else:
+        launches = work["launches"]
+        ms_step = avg_ms * work["launches"]
     achieved = work["flops"] / (ms_step * 1e-3) / 1e12
-    traffic = _pmc_traffic("gemm_kernel")
-    return {"kernel": "gemm_kernel (grouped fp32 MFMA GEMM, all %d launches of one training step)" % work["launches"],
+    traffic, traffic_source = _pmc_traffic("gemm_kernel", with_source=True)
+    return {"kernel": "gemm_kernel (grouped fp32 MFMA GEMM, all %.1f launches of one training step)" % launches,
             "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(achieved / FP32_MATRIX_PEAK_TF, 4), "traffic": traffic,
-            "launches_per_step": work["launches"], "avg_launch_ms": round(avg_ms, 5),
+            "traffic_source": traffic_source,
+            "launches_per_step": round(launches, 2), "grouped_calls_per_step": work["launches"],
+            "avg_launch_ms": round(avg_ms, 5),
             "ms_per_step_in_kernel": round(ms_step, 3),
             "duration_source": source or ("rocprofv3 --kernel-trace --stats of the captured step in a child process "
-                                          "(%d launches profiled)" % calls),
+                                          "(%d launches over %d steps profiled)" % (calls, steps)),
             "algorithmic_flops_per_step": work["flops"], "algorithmic_bytes_per_step": work["bytes"],
-            "algorithmic_bytes_per_launch": round(work["bytes"] / max(work["launches"], 1)),
-            "traffic_over_algorithmic": (round(traffic / (work["bytes"] / max(work["launches"], 1)), 3)
+            "algorithmic_bytes_per_launch": round(work["bytes"] / max(launches, 1)),
+            "traffic_over_algorithmic": (round(traffic / (work["bytes"] / max(launches, 1)), 3)
                                          if traffic else None)}
 
 
@@ -326,16 +339,19 @@ def attention_roofline(batch, reps=10, bf16=False):
             "fwd_ms": round(ms_f, 4), "bwd_ms": round(ms_b, 4)}
 
 
-def _pmc_traffic(kernel):
-    """HBM bytes per launch from the committed PMC profile (profiles/r04_pmc.json, else r03 / r02), or None."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+def _pmc_traffic(kernel, with_source=False):
+    """HBM bytes per launch from the newest committed PMC profile (profiles/r05_pmc.json, else r04 / r03 / r02), or None.
+    NOT measured in this run: the counters need their own rocprofv3 --pmc passes (scratch/pmc.sh); ``traffic_source``
+    in the record names the file."""
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name))).get(kernel, {}).get("hbm_bytes_per_launch")
         except Exception:
             v = None
         if v is not None:
-            return v
-    return None
+            src = f"profiles/{name} (separate rocprofv3 --pmc passes of the same command; not collected in this run)"
+            return (v, src) if with_source else v
+    return (None, None) if with_source else None
 
 
 def ball_query_roofline(inputs, steps=20):

@@ -59,7 +59,10 @@ class GemmProblem(ctypes.Structure):
                 ("a_bn_out", _c_void_p), ("a_bn_ld", _c_long), ("a_bn_count", _c_long),
                 ("a_bn_eps", _c_float), ("a_bn_momentum", _c_float),
                 ("c_bn_z", _c_void_p), ("c_bn_aff", _c_void_p), ("c_bn_ld", _c_long),
-                ("c_bn_drop_p", _c_float), ("c_bn_drop_site", _c_u32)]
+                ("c_bn_drop_p", _c_float), ("c_bn_drop_site", _c_u32),
+                ("c_partial", _c_void_p), ("c_partial_stride", _c_long),
+                ("fold_src", _c_void_p), ("fold_count", _c_int),
+                ("fold_stride", _c_long), ("fold_len", _c_long), ("fold_len2", _c_long)]
 
 
 ATTENTION_SYMBOLS = {
@@ -83,22 +86,6 @@ ATTENTION_SYMBOLS = {
     "butd_layernorm_bwd_blocks": (_c_int, [_c_int]),
     "butd_add_dropout_layernorm_bwd_partial": (_c_int, [_c_int, _c_int] + [_c_void_p] * 9
                                                + [_c_float, _c_u32, _c_void_p, _c_void_p]),
-}
-
-class PanelStage(ctypes.Structure):
-    """ctypes mirror of ``butd_panel_stage`` (include/butd_panel.h)."""
-    _fields_ = [("w", _c_void_p), ("bias", _c_void_p), ("N", _c_int), ("K", _c_int), ("scale", _c_float),
-                ("in_buf", _c_int), ("relu", _c_int), ("drop_p", _c_float), ("drop_site", _c_u32),
-                ("pre", _c_void_p), ("ln", _c_int), ("res", _c_void_p), ("res_buf", _c_int),
-                ("gamma", _c_void_p), ("beta", _c_void_p), ("eps", _c_float),
-                ("mean", _c_void_p), ("rstd", _c_void_p), ("out", _c_void_p), ("out_buf", _c_int),
-                ("pos", _c_void_p), ("out_pos", _c_void_p), ("pos_buf", _c_int)]
-
-
-PANEL_SYMBOLS = {
-    "butd_panel_chain": (_c_int, [_c_int, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p, _c_int,
-                                  ctypes.POINTER(PanelStage), _c_int, _c_int, _c_void_p, _c_void_p]),
-    "butd_panel_set_rows": (_c_int, [_c_int]),
 }
 
 _P = _c_void_p
@@ -195,6 +182,8 @@ GRAPH_SYMBOLS = {
     "butd_graph_node_counts": (_c_int, [_P, ctypes.POINTER(ctypes.c_int * 16)]),
     "butd_runtime_versions": (_c_int, [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "butd_timeline_mark": (_c_int, [_P, _c_int, _P]),
+    "butd_stream_create": (_c_int, [_c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "butd_stream_destroy": (_c_int, [_P]),
 }
 
 ALL_SYMBOLS = dict(POINTNET2_SYMBOLS)
@@ -206,7 +195,6 @@ ALL_SYMBOLS.update(LSAP_SYMBOLS)
 ALL_SYMBOLS.update(CRITERION_SYMBOLS)
 ALL_SYMBOLS.update(AUGMENT_SYMBOLS)
 ALL_SYMBOLS.update(GRAPH_SYMBOLS)
-ALL_SYMBOLS.update(PANEL_SYMBOLS)
 ALL_SYMBOLS.update(ROWWISE_SYMBOLS)
 
 _lib = None

@@ -107,47 +107,28 @@ def attention_block(attn, dropout, norm, *, residual, query, key, value, key_pad
     return norm(residual + dropout(out))
 
 
-def q_projection(attn, use_pos=True):
-    """``emit`` entry of ``block``: the query projection of ``attn`` (scaled by 1/sqrt(head_dim) as the attention core
-    expects it), applied to the emitting block's output (+ its ``next_pos`` when ``use_pos``)."""
-    E = attn.embed_dim
-    return (attn.in_proj_weight[:E], attn.in_proj_bias[:E], math.sqrt(1.0 / float(E // attn.num_heads)), use_pos)
-
-
-def kv_projections(attn):
-    """``emit`` entries: the key and value projections of ``attn`` applied to the emitting block's output (the memory
-    of a cross-attention block: keys / values carry no position embedding, encoder_decoder_layers.py:83,101-102)."""
-    E = attn.embed_dim
-    return [(attn.in_proj_weight[E:2 * E], attn.in_proj_bias[E:2 * E], 1.0, False),
-            (attn.in_proj_weight[2 * E:], attn.in_proj_bias[2 * E:], 1.0, False)]
-
-
-def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None,
-          q_pre=None, kv_pre=None, emit=None, ffn=None, kv_ext=None):
+def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None, ffn=None):
     """The block in the two shapes the model uses it (every call site of
     encoder_decoder_layers.py:87-122,149-155,179-185,356-404):
         memory is None:  self-attention,  query = key = x (+ pos), value = x
         otherwise:       cross-attention, query = x (+ pos), key = value = memory
     with residual x.  Knowing the structure lets the fused backward return summed gradients.
 
-    Chaining (fused backend; the stock path ignores the hints and every block computes its own operands):
-    ``next_pos`` -- also produce ``y + next_pos``, the next block's ``xq_pre``;
-    ``emit``     -- projections of y (``q_projection`` / ``kv_projections`` of LATER blocks) computed by the kernel that
-                    holds y's rows in LDS; handed to those blocks as ``q_pre`` / ``kv_pre`` (values only);
-    ``ffn``      -- (ffn Sequential, norm): the FFN block that follows, in the same kernel.
-    Returns y when none of next_pos / emit / ffn is given, else (y, y + next_pos | None, [emitted ...])."""
+    Hand-over hints (fused backend; the stock path ignores them and every block computes its own operands):
+    ``next_pos`` -- also produce ``y + next_pos`` (from the LayerNorm kernel that writes y), the next block's ``xq_pre``;
+    ``ffn``      -- (ffn Sequential, norm): the FFN block that follows (``next_pos`` then belongs to ITS output).
+    Returns y when neither next_pos nor ffn is given, else (y, y + next_pos | None)."""
     if _BACKEND == "hip" and x.is_cuda:
         from . import fused_attention
-        return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask, xq_pre, next_pos,
-                                     q_pre, kv_pre, emit, ffn, kv_ext)
+        return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask, xq_pre, next_pos, ffn)
     q = x if pos is None else x + pos
     k, v = (q, x) if memory is None else (memory, memory)
     y = norm(x + dropout(_mha_torch(attn, q, k, v, key_padding_mask)))
     if ffn is not None:
         y = ffn[1](y + ffn[0](y))
-    if next_pos is None and emit is None and ffn is None:
+    if next_pos is None and ffn is None:
         return y
-    return y, None, []     # (y + next_pos and the emitted projections are the fused path's by-products only)
+    return y, None     # (y + next_pos is the fused path's by-product only)
 
 
 def ffn_block(ffn, norm, x):

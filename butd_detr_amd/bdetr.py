@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import attention_blocks, text_stream
+from . import attention_blocks, graph_audit, switches, text_stream
 from .fan_out import fan_out, unstack
 from .backbone_module import Pointnet2Backbone
 from .encoder_decoder_layers import BiDecoderLayer, BiEncoder, BiEncoderLayer
@@ -62,26 +62,6 @@ def _embedding_lookup(weight, ids):
     if weight.is_cuda and weight.requires_grad and torch.is_grad_enabled():
         return _EmbeddingLookup.apply(weight, ids)
     return torch.nn.functional.embedding(ids, weight)
-
-
-_KV_STREAMS = {}
-
-
-def _kv_stream(device):
-    st = _KV_STREAMS.get(device)
-    if st is None:
-        st = _KV_STREAMS[device] = torch.cuda.Stream(device)
-    return st
-
-
-_HEAD_STREAMS = {}
-
-
-def _head_stream(device):
-    st = _HEAD_STREAMS.get(device)
-    if st is None:
-        st = _HEAD_STREAMS[device] = torch.cuda.Stream(device)
-    return st
 
 
 class BeaUTyDETR(nn.Module):
@@ -155,7 +135,7 @@ class BeaUTyDETR(nn.Module):
             self.contrastive_align_projection_image = _align_mlp(d_model)
             self.contrastive_align_projection_text = _align_mlp(d_model)
 
-        self.overlap_text_tower = os.environ.get("BUTD_TEXT_OVERLAP", "1") != "0"   # env: debug hook
+        self.overlap_text_tower = switches.flag("text_overlap", True)
         # text stream options (text_stream.py): an UtteranceCache in HBM, "f32" | "bf16" language-model arithmetic
         self.text_cache = None
         self.text_precision = "f32"
@@ -227,7 +207,7 @@ class BeaUTyDETR(nn.Module):
             # graphs get their hidden hazards); the trainable projector runs on the main stream after the join
             main = torch.cuda.current_stream(pc.device)
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(pc.device)
+                self._side_stream = graph_audit.own_stream(pc.device, role="model.text")
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -265,7 +245,7 @@ class BeaUTyDETR(nn.Module):
     def _proj_mlp(seq, x):
         """The Linear-ReLU-Linear-ReLU-Linear projections on the grouped GEMM (fused gate / bias / ReLU epilogues)
         when the fused backend is active; the stock modules otherwise."""
-        if x.is_cuda and attention_blocks.get_backend() == "hip" and os.environ.get("BUTD_PROJ_CHAIN", "1") != "0":
+        if x.is_cuda and attention_blocks.get_backend() == "hip":
             from .fused_attention import linear_relu_chain
             return linear_relu_chain(seq, x)
         return seq(x)
@@ -338,7 +318,6 @@ class BeaUTyDETR(nn.Module):
         n_dec = len(self.decoder)
         vis_l, text_l = fan_out(vis, n_dec), fan_out(text_feats, n_dec)
         det_l = fan_out(detected_feats if self.butd else None, n_dec)
-        kv_layers, kv_events = self._decoder_memory_kv(vis_l, text_l, det_l)
         for i, (layer, head) in enumerate(zip(self.decoder, self.prediction_heads)):
             prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
             if self.self_position_embedding == "none":
@@ -349,12 +328,9 @@ class BeaUTyDETR(nn.Module):
                 query_pos = torch.cat([base_xyz, base_size], -1)
             else:
                 raise NotImplementedError
-            if kv_layers is not None:
-                torch.cuda.current_stream(query.device).wait_event(kv_events[i])     # this layer's k, v are ready
             query = layer(query, vis_l[i], text_l[i], query_pos, None, text_padding_mask,
                           detected_feats=det_l[i],
-                          detected_mask=detected_mask if self.butd else None,
-                          **({} if kv_layers is None else {"memory_kv": kv_layers[i]}))
+                          detected_mask=detected_mask if self.butd else None)
             # the layer output feeds the next layer, its head and the contrastive projection
             query, q_head, q_proj = fan_out(query, 3)
             if self.contrastive_align_loss:
@@ -368,38 +344,6 @@ class BeaUTyDETR(nn.Module):
                 end_points[f"{prefix}proj_queries"] = proj[i]
         return end_points
 
-    def _decoder_memory_kv(self, vis_l, text_l, det_l):
-        """The key / value projections of the decoder's three constant memories for EVERY layer, on a forked stream
-        (fused backend; OFF unless BUTD_DECODER_KV_FORK=1 -- MEASURED, round 4, 3 x 60-step runs each: 25.14 ms with,
-        25.02 ms without: inside a block's grouped launch these products already fill the CUs the query-side products
-        leave idle, and a second queue adds launches without adding overlap; kept as the A/B of that measurement).
-        Nothing of them depends on the query chain, so they run next to it; autograd runs their backward -- the
-        8192-row input- and weight-gradient products of the vision memory, and the deferred query-projection weight
-        gradients -- on that stream as well (fused_attention.memory_kv).  -> ([(KVHolder, [(k, v), ...]) per layer],
-        [event per layer]) or (None, None)."""
-        ref = vis_l[0]
-        if not (self._fused(ref) and os.environ.get("BUTD_DECODER_KV_FORK", "0") == "1"):
-            return None, None
-        from .fused_attention import memory_kv
-        main = torch.cuda.current_stream(ref.device)
-        side = _kv_stream(ref.device)
-        side.wait_stream(main)
-        layers, events = [], []
-        with torch.cuda.stream(side):
-            for i, layer in enumerate(self.decoder):
-                mems = [text_l[i]] + ([det_l[i]] if self.butd else []) + [vis_l[i]]
-                for m in mems:
-                    m.record_stream(side)
-                holder, kv = memory_kv(layer.cross_attentions(with_boxes=self.butd), mems)
-                for k, v in kv:
-                    k.record_stream(main)
-                    v.record_stream(main)
-                layers.append((holder, kv))
-                ev = torch.cuda.Event()
-                ev.record(side)
-                events.append(ev)
-        return layers, events
-
     @staticmethod
     def _stage_hook(inputs, stage):
         """Optional callbacks of the caller at stage boundaries of the forward pass (``inputs["_stage_hooks"] =
@@ -411,36 +355,10 @@ class BeaUTyDETR(nn.Module):
             hooks[stage]()
 
     def _run_head(self, head, features, cluster_xyz, end_points, prefix, features_pm=None):
-        """One prediction head (bdetr.py:306-312).  On the fused backend it runs on a FORKED stream: in the forward pass
-        the next decoder layer needs its boxes, so nothing overlaps there (fork + join back to back) -- but autograd
-        runs a node's backward on the stream of its forward, and the backward of every head depends on the loss
-        alone (the boxes handed to the next layer are detached, bdetr.py:275-276): the seven heads' backward chains
-        (~10 launches of 2048-row kernels each, ~0.15 ms) then run on that stream NEXT TO the decoder layers' backward
-        instead of between them.  MEASURED (round 4, bench configuration): 25.79 ms per step with the fork, 25.61 without --
-        the chip shares two queues of small launches no better than one, as round 3 found for the weight-gradient
-        products -- so it is OFF unless BUTD_HEAD_FORK=1 (kept as the A/B switch of that measurement)."""
-        fork = (features.is_cuda and attention_blocks.get_backend() == "hip" and torch.is_grad_enabled()
-                and os.environ.get("BUTD_HEAD_FORK", "0") == "1")
-        if not fork:
-            return head(features, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix, features_pm=features_pm)
-        main = torch.cuda.current_stream(features.device)
-        side = _head_stream(features.device)
-        before = set(end_points.keys())
-        side.wait_stream(main)
-        features.record_stream(side)
-        cluster_xyz.record_stream(side)
-        if features_pm is not None:
-            features_pm.record_stream(side)
-        with torch.cuda.stream(side):
-            center, size = head(features, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix,
-                                features_pm=features_pm)
-        main.wait_stream(side)
-        for k in set(end_points.keys()) - before:       # produced on the side stream, read by the criterion on main
-            if torch.is_tensor(end_points[k]):
-                end_points[k].record_stream(main)
-        center.record_stream(main)
-        size.record_stream(main)
-        return center, size
+        """One prediction head (bdetr.py:306-312).  (Round 4 measured the heads on a forked stream -- their backward depends
+        on the loss alone -- at +0.18 ms per step: two queues of small launches share the chip no better than one;
+        profiles/r04_side_branches.txt.  Removed in round 5.)"""
+        return head(features, base_xyz=cluster_xyz, end_points=end_points, prefix=prefix, features_pm=features_pm)
 
     # parameters whose gradients are complete only once backward has passed the encoder: everything else
     # (decoder, heads, query generation, contrastive projections) is done when backward reaches the three

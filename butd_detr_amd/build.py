@@ -29,7 +29,13 @@ TU_FLAGS = {
     "criterion_ops.hip": ["-ffp-contract=off"],
     "augment_ops.hip": ["-ffp-contract=off"],
     "rowwise_ops.hip": ["-ffp-contract=off"],
-    "attention_ops.hip": [],
+    # MFMA accumulators in VGPRs (the "VGPR form" of the matrix instructions): the softmax / epilogue code reads them in
+    # place instead of through v_accvgpr_read / _write (60 of the ~430 instructions of a forward attention key tile, 12 876
+    # static ones in gemm_ops); measured round 5: attention backward 442 -> 426 us, step 23.33 -> 23.13 ms (profiles/r05_vgpr_form.txt)
+    "attention_ops.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "gemm_ops.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "sa_last_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "sa_fused.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
 }
 
 

@@ -545,6 +545,16 @@ __device__ inline uint32_t pair_hash(uint32_t key, uint32_t pair) { return rng::
 // therefore written for instruction count: exp2 with the log2(e) factor folded into one fma, bias / all-keys-masked
 // handling only in tiles that have masked keys, dropout hashed per key pair and its 1/(1-p) applied once at the end,
 // V operands as ds_read_b128 from the transposed image (no per-value select), staging offsets precomputed.
+// -DATTN_PROF (scratch/attn_phase_prof.sh; never in the product build): wave 0 of workgroup 0 accumulates the shader clock
+// (s_memtime) it spends in each phase of a key tile -- S = K.Q^T, softmax + dropout, P.V, commit + barrier -- into
+// g_attn_prof[0..4] (+ [5] = tiles), read back by butd_attention_prof_read.
+#ifdef ATTN_PROF
+__device__ unsigned long long g_attn_prof[8];
+#define PROF_T(x) const unsigned long long x = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define PROF_T(x)
+#endif
+
 template <int NS, int NT, int NG, bool BF = false>
 __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
@@ -609,15 +619,23 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
   }
   __syncthreads();
   int cur = 0;
+#ifdef ATTN_PROF
+  unsigned long long pf[5] = {0, 0, 0, 0, 0};
+#endif
   for (int it = 0; it < iters; ++it) {
     const int key0 = (it * NG + grp) * 64;
     const bool more = it + 1 < iters;
+    PROF_T(t0);
     if (more) {
       const int nk = key0 + NG * 64;
       sg.fetch(kr, kb + (long)nk * E, Lk - nk);
       sg.fetch(vr, vb + (long)nk * E, Lk - nk);
       if (tid < 64) br = key_bias(mb, nk + tid, Lk);
     }
+    PROF_T(t1);
+#ifdef ATTN_PROF
+    unsigned long long t2 = t1, t3 = t1, t4 = t1;
+#endif
     if (live) {
       f32x4 st[4];
 #pragma unroll
@@ -630,6 +648,12 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
       f32x4 va[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) va[nt] = *reinterpret_cast<const f32x4 *>(&Vt[cur][nt * 16 + fr][fg * 4]);
+#ifdef ATTN_PROF
+      asm volatile("s_nop 0" :: "v"(st[3][3]));      // (the last score accumulator has to be there)
+      __builtin_amdgcn_sched_barrier(0);
+      t2 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 
       const bool masked_tile = mb != nullptr || key0 + 64 > Lk;   // uniform: bias and dead-row handling needed
       float m_new, alpha, m2;
@@ -675,6 +699,12 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
       l = l * alpha + psum;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+#ifdef ATTN_PROF
+      asm volatile("s_nop 0" :: "v"(st[3][3]), "v"(o[NT - 1][3]));
+      __builtin_amdgcn_sched_barrier(0);
+      t3 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       // O^T[n][q] += V^T[n][key] P^T[key][q]
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -703,6 +733,12 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
         }
       }
       m = m_new;
+#ifdef ATTN_PROF
+      asm volatile("s_nop 0" :: "v"(o[NT - 1][3]));
+      __builtin_amdgcn_sched_barrier(0);
+      t4 = __builtin_readcyclecounter();
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
     if (more) {
       sg.commit_frag(&Kimg[cur ^ 1][0][0], kr);
@@ -710,8 +746,20 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
       if (tid < 64) Bias[cur ^ 1][tid] = br;
     }
     __syncthreads();
+#ifdef ATTN_PROF
+    {
+      PROF_T(t5);
+      pf[0] += t1 - t0; pf[1] += t2 - t1; pf[2] += t3 - t2; pf[3] += t4 - t3; pf[4] += t5 - t4;
+    }
+#endif
     cur ^= 1;
   }
+#ifdef ATTN_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int i = 0; i < 5; ++i) g_attn_prof[i] = pf[i];
+    g_attn_prof[5] = (unsigned long long)iters;
+  }
+#endif
   if constexpr (NG == 2) {
     constexpr int kX = 4 * NT + 2;
     float *xch = &KimgG[0][0][0][0];   // free after the loop's last barrier
@@ -1598,3 +1646,9 @@ int butd_attention_bwd_bf16(int B, int H, int Lq, int Lk, int D, const float *q,
 }
 
 }  // extern "C"
+
+#ifdef ATTN_PROF
+extern "C" int butd_attention_prof_read(unsigned long long *host8) {
+  return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_attn_prof), sizeof(unsigned long long) * 8);
+}
+#endif

@@ -199,6 +199,37 @@ __device__ inline void commit_generic(float *tile, const Frag4 &f, const Operand
   }
 }
 
+// A FOLD problem (butd_gemm_problem.fold_src): the fixed-order sum of the partial slabs a deterministic split-K problem
+// of an EARLIER launch left behind; workgroup `chunk` of the problem's range owns 2048 consecutive floats of the
+// (weights | bias) vector.  Element-wise, no LDS: it rides in whatever grouped launch comes next on the stream.
+constexpr int kFoldChunk = 2048;
+__device__ __forceinline__ void fold_slabs(const butd_gemm_problem &P, int chunk) {
+  const long len1 = P.fold_len, total = P.fold_len + P.fold_len2, stride = P.fold_stride;
+  const float *const src = P.fold_src;
+  const int S = P.fold_count;
+  const bool add = P.c_add != 0;
+  const bool vec1 = ((uintptr_t)P.c & 15) == 0, vec2 = ((uintptr_t)P.bias_grad & 15) == 0 && (len1 & 3) == 0;
+#pragma unroll
+  for (int u = 0; u < kFoldChunk / (4 * kThreads); ++u) {
+    const long i = (long)chunk * kFoldChunk + (long)(u * kThreads + (int)threadIdx.x) * 4;
+    if (i >= total) return;
+    const bool first = i < len1;                 // (len1 % 4 == 0: a float4 never straddles the two destinations)
+    float *const dst = first ? P.c + i : P.bias_grad + (i - len1);
+    if (i + 3 < total && (first ? vec1 : vec2)) {
+      f32x4 acc = *reinterpret_cast<const f32x4 *>(src + i);
+      for (int sl = 1; sl < S; ++sl) acc += *reinterpret_cast<const f32x4 *>(src + (long)sl * stride + i);
+      if (add) acc += *reinterpret_cast<const f32x4 *>(dst);
+      *reinterpret_cast<f32x4 *>(dst) = acc;
+    } else {
+      for (int e = 0; e < 4 && i + e < total; ++e) {
+        float a = src[i + e];
+        for (int sl = 1; sl < S; ++sl) a += src[(long)sl * stride + i + e];
+        dst[e] = add ? dst[e] + a : a;
+      }
+    }
+  }
+}
+
 struct Whole { static constexpr bool ragged = false; };   // slab kinds of the fast path (see below)
 struct Ragged { static constexpr bool ragged = true; };
 
@@ -246,6 +277,10 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
   pi = min(pi, batch.count - 1);
   const butd_gemm_problem &P = batch.p[pi];
   int rel = wg - batch.blk_begin[pi];
+  if (P.fold_src) {          // (uniform per workgroup) the ride-along fold of an earlier launch's split-K slabs
+    fold_slabs(P, rel);
+    return;
+  }
   const int tn = batch.tiles_n[pi], tm = batch.tiles_m[pi];
   const int bx = rel % tn;
   rel /= tn;
@@ -906,6 +941,46 @@ __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
     }
     return;
   }
+  if (float *const part = P.c_partial) {
+    // deterministic split-K: this slice's share as plain stores into its own slab (dense [M][N] + the ones-column's
+    // M results behind it), staged through LDS for float4 row segments; a later launch folds the slabs in slice order
+    constexpr int kLdC = TN + 4;
+    constexpr int kRQ = TN / 4;
+    constexpr int kRowPhases = kThreads / kRQ;
+    static_assert(2 * (TM + TN) * kLd >= TM * kLdC, "C tile must fit the operand buffers");
+    float *Cs = lds;
+#pragma unroll
+    for (int i = 0; i < kMI; ++i)
+#pragma unroll
+      for (int j = 0; j < kNJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          Cs[(wr * kWM + i * 16 + fg * 4 + r) * kLdC + wc * kWN + j * 16 + fr] = acc[i][j][r];
+    __syncthreads();
+    const int c4 = (tid % kRQ) * 4, rphase = tid / kRQ;
+    if (rphase >= kRowPhases) return;
+    float *const base = part + (long)slice * P.c_partial_stride;
+    float *const bslab = base + (long)pM * pN;
+    const int n = n0 + c4;
+    const bool vec = (pN & 3) == 0 && n + 3 < pN;
+    if (n > pN || (n == pN && !ones_col)) return;
+    for (int row = rphase; row < TM; row += kRowPhases) {
+      const int m = m0 + row;
+      if (m >= pM) break;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&Cs[row * kLdC + c4]) * scale;
+      float *dst = base + (long)m * pN + n;
+      if (vec) {
+        *reinterpret_cast<f32x4 *>(dst) = v;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e < pN) dst[e] = v[e];
+          else if (ones_col && n + e == pN) bslab[m] = v[e];
+        }
+      }
+    }
+    return;
+  }
   // accumulate / bias-gradient path: element-wise atomics straight from the accumulators
   float bias_v[kNJ];
 #pragma unroll
@@ -970,7 +1045,12 @@ long fill_batch(GemmBatch &batch, const butd_gemm_problem *problems, const int *
     butd_gemm_problem p = problems[index[i]];
     if (p.split_k < 1) p.split_k = 1;
     const int ncols = p.N + (p.ones_col ? 1 : 0);
-    const int tn = (ncols + tile_n - 1) / tile_n, tm = (p.M + tile_m - 1) / tile_m;
+    int tn = (ncols + tile_n - 1) / tile_n, tm = (p.M + tile_m - 1) / tile_m;
+    if (p.fold_src) {       // element-wise: one workgroup per 2048 floats of (weights | bias)
+      tn = (int)((p.fold_len + p.fold_len2 + kFoldChunk - 1) / kFoldChunk);
+      tm = 1;
+      p.split_k = 1;
+    }
     batch.blk_begin[batch.count] = (int)total;
     batch.tiles_n[batch.count] = tn;
     batch.tiles_m[batch.count] = tm;
@@ -1005,6 +1085,7 @@ void choose(const butd_gemm_problem *problems, const int *index, int count, bool
   long max_k_acc = 0, max_m_plain = 0, tiles32 = 0;
   for (int i = 0; i < count; ++i) {
     const butd_gemm_problem &p = problems[index[i]];
+    if (p.fold_src) continue;      // (element-wise riders do not vote on the tile)
     if (p.accumulate || p.split_k > 1 || p.ones_col) {
       any_acc = true;
       if (p.K > max_k_acc) max_k_acc = p.K;
@@ -1063,7 +1144,8 @@ int launch_group(const butd_gemm_problem *problems, const int *index, int count,
     pipe = g_forced_pipe >= 0 ? g_forced_pipe : 2;
   }
   bool bf16 = fast;
-  for (int i = 0; i < count; ++i) bf16 = bf16 && problems[index[i]].compute_bf16 != 0;
+  for (int i = 0; i < count; ++i)
+    if (!problems[index[i]].fold_src) bf16 = bf16 && problems[index[i]].compute_bf16 != 0;
   GemmBatch batch;
   const long total = fill_batch(batch, problems, index, count, kMenu[best].tm, kMenu[best].tn);
   if (total < 0) return (int)hipErrorInvalidValue;
@@ -1106,10 +1188,25 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
   if (count <= 0) return 0;
   if (count > kMaxProblems) return (int)hipErrorInvalidValue;
   // the problems of a group are independent: the fast-eligible ones and the rest run as two launches
-  int fast_idx[kMaxProblems], slow_idx[kMaxProblems], nf = 0, ns = 0;
+  int fast_idx[kMaxProblems], slow_idx[kMaxProblems], fold_idx[kMaxProblems], nf = 0, ns = 0, nfold = 0;
   for (int i = 0; i < count; ++i) {
     const butd_gemm_problem &p = problems[i];
+    if (p.fold_src) {
+      if (!p.c || p.fold_count < 1 || p.fold_len <= 0 || (p.fold_len & 3) || p.fold_len2 < 0 || (p.fold_stride & 3) ||
+          (p.fold_len2 > 0 && !p.bias_grad) || (((uintptr_t)p.fold_src) & 15) || p.c_partial)
+        return (int)hipErrorInvalidValue;
+      fold_idx[nfold++] = i;
+      continue;
+    }
     if (p.M <= 0 || p.N <= 0) continue;
+    if (p.c_partial && (!p.accumulate || p.bias || p.relu || p.dropout_p > 0.f || (((uintptr_t)p.c_partial) & 15) ||
+                        (p.c_partial_stride & 3) || p.c_partial_stride < (long)p.M * p.N + (p.ones_col ? p.M : 0) ||
+                        p.split_k < 1))
+      return (int)hipErrorInvalidValue;
+    if (p.c_partial) {      // every slice must own a slab of the contraction: an empty one would leave its share unwritten
+      const int kslab = (p.K + kBK - 1) / kBK, per = (kslab + p.split_k - 1) / p.split_k;
+      if ((long)(p.split_k - 1) * per >= kslab) return (int)hipErrorInvalidValue;
+    }
     if (p.split_k > 1 && !p.accumulate) return (int)hipErrorInvalidValue;
     if ((p.col_sum != nullptr || p.c_add || p.c2 != nullptr || p.c_gate != nullptr) && (p.accumulate || p.ones_col || p.split_k > 1))
       return (int)hipErrorInvalidValue;
@@ -1130,6 +1227,11 @@ int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64
               p.M, p.N, p.K, (long)p.lda_m, (long)p.lda_k, (long)p.ldb_n, (long)p.ldb_k, p.split_k, p.a2 != nullptr,
               (int)p.ones_col, (int)((((uintptr_t)p.a) | ((uintptr_t)p.b)) & 15), count);
     }
+  // the riders join the float4 launch when there is one (else the element-wise staged one, else they are the launch)
+  for (int j = 0; j < nfold; ++j) {
+    if (nf > 0 || ns == 0) fast_idx[nf++] = fold_idx[j];
+    else slow_idx[ns++] = fold_idx[j];
+  }
   int err = launch_group(problems, fast_idx, nf, true, rng_counter, (hipStream_t)stream);
   if (err) return err;
   return launch_group(problems, slow_idx, ns, false, rng_counter, (hipStream_t)stream);

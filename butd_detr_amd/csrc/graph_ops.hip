@@ -131,3 +131,20 @@ extern "C" int butd_runtime_versions(int *runtime, int *driver) {
   if (e != hipSuccess) return (int)e;
   return (int)hipDriverGetVersion(driver);
 }
+
+extern "C" int butd_stream_create(int priority, void **stream) {
+  if (!stream) return (int)hipErrorInvalidValue;
+  int lo = 0, hi = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);     // lo = least priority (numerically largest)
+  if (e != hipSuccess) return (int)e;
+  if (priority < hi) priority = hi;
+  if (priority > lo) priority = lo;
+  hipStream_t s = nullptr;
+  e = hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority);
+  *stream = (void *)s;
+  return (int)e;
+}
+
+extern "C" int butd_stream_destroy(void *stream) {
+  return stream ? (int)hipStreamDestroy((hipStream_t)stream) : 0;
+}

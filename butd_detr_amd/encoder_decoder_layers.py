@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from . import attention_blocks as ab
+from . import graph_audit, switches
 from .fan_out import fan_out
 
 
@@ -111,37 +112,29 @@ class CrossAttentionLayer(nn.Module):
                                      detected_feats, detected_mask)
         return vis_out, text_out
 
-    def language_branch(self, text_feats, vis_feats, vis_key_padding_mask, q_pre=None, kv_pre=None):
-        """language attends to vision, then its FFN (one chain: the FFN runs in the kernel behind the attention core)"""
+    def language_branch(self, text_feats, vis_feats, vis_key_padding_mask):
+        """language attends to vision, then its FFN"""
         return ab.block(self.cross_lv, self.dropout_lv, self.norm_lv, x=text_feats, memory=vis_feats,
-                        key_padding_mask=vis_key_padding_mask, q_pre=q_pre, kv_pre=kv_pre,
-                        ffn=(self.ffn_lv, self.norm_lv2))[0]
+                        key_padding_mask=vis_key_padding_mask, ffn=(self.ffn_lv, self.norm_lv2))[0]
 
     def vision_branch(self, vis_feats, text_in, text_key_padding_mask, pos_feats,
-                      detected_feats=None, detected_mask=None, xq_pre=None, q_pre=None, kv_pre=None, next_pos=None):
+                      detected_feats=None, detected_mask=None, xq_pre=None, next_pos=None):
         """vision attends to language (keys/values = the layer INPUT text), [to the boxes], FFN.
         ``next_pos``: -> (out, out + next_pos): the `src + pos` of the next layer's self-attention, from the FFN's
         LayerNorm kernel (values only; None on the stock path)."""
         # positional features only on the query (:79-80)
         boxes = detected_feats is not None and self.use_butd_enc_attn
-        vis_feats, _, em = ab.block(self.cross_vl, self.dropout_vl, self.norm_vl, x=vis_feats, pos=pos_feats,
-                                    memory=text_in, key_padding_mask=text_key_padding_mask, xq_pre=xq_pre,
-                                    q_pre=q_pre, kv_pre=kv_pre,
-                                    emit=[ab.q_projection(self.cross_d, False)] if boxes else None,
-                                    ffn=None if boxes else (self.ffn_vl, self.norm_vl2),
-                                    next_pos=None if boxes else next_pos)
-        vis_pos = _
         if boxes:
-            vis_feats, vis_pos, _ = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=vis_feats,
-                                             memory=detected_feats, key_padding_mask=detected_mask,
-                                             q_pre=em[0] if em else None, ffn=(self.ffn_vl, self.norm_vl2),
-                                             next_pos=next_pos)
+            vis_feats = ab.block(self.cross_vl, self.dropout_vl, self.norm_vl, x=vis_feats, pos=pos_feats,
+                                 memory=text_in, key_padding_mask=text_key_padding_mask, xq_pre=xq_pre)
+            vis_feats, vis_pos = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=vis_feats,
+                                          memory=detected_feats, key_padding_mask=detected_mask,
+                                          ffn=(self.ffn_vl, self.norm_vl2), next_pos=next_pos)
+        else:
+            vis_feats, vis_pos = ab.block(self.cross_vl, self.dropout_vl, self.norm_vl, x=vis_feats, pos=pos_feats,
+                                          memory=text_in, key_padding_mask=text_key_padding_mask, xq_pre=xq_pre,
+                                          ffn=(self.ffn_vl, self.norm_vl2), next_pos=next_pos)
         return vis_feats if next_pos is None else (vis_feats, vis_pos)
-
-    def self_emits(self):
-        """What the two self-attention blocks in front of this layer emit for it: (vision side, language side)."""
-        return ([ab.q_projection(self.cross_vl, True)] + ab.kv_projections(self.cross_lv),
-                [ab.q_projection(self.cross_lv, False)] + ab.kv_projections(self.cross_vl))
 
 
 class TransformerEncoderLayerNoFFN(nn.Module):
@@ -153,38 +146,37 @@ class TransformerEncoderLayerNoFFN(nn.Module):
         self.norm1 = nn.LayerNorm(d_model)
         self.dropout1 = nn.Dropout(dropout)
 
-    def forward(self, src, src_mask=None, src_key_padding_mask=None, emit=None):
-        """``emit``: projections of the output for the blocks that follow -> (out, None, [projections])."""
+    def forward(self, src, src_mask=None, src_key_padding_mask=None):
         assert src_mask is None, "attn_mask is never used on this path"
-        return ab.block(self.self_attn, self.dropout1, self.norm1, x=src,
-                        key_padding_mask=src_key_padding_mask, emit=emit)
+        return ab.block(self.self_attn, self.dropout1, self.norm1, x=src, key_padding_mask=src_key_padding_mask)
 
 
 class PosTransformerEncoderLayerNoFFN(TransformerEncoderLayerNoFFN):
     """Same, with the positional embedding added to query and key (not value)."""
 
-    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, emit=None, xq_pre=None):
-        """``emit``: as above; the output + pos is produced too -> (out, out + pos, [projections]).
+    def forward(self, src, pos, src_mask=None, src_key_padding_mask=None, xq_pre=None, with_pos=False):
+        """``with_pos``: -> (out, out + pos | None): the sum the following cross-attention takes as its query input, from
+        the LayerNorm kernel that writes out (values only; None on the stock path).
         ``xq_pre``: src + pos as an earlier kernel already wrote it (values only)."""
         assert src_mask is None, "attn_mask is never used on this path"
         return ab.block(self.self_attn, self.dropout1, self.norm1, x=src, pos=pos,
-                        key_padding_mask=src_key_padding_mask, emit=emit, xq_pre=xq_pre,
-                        next_pos=pos if emit is not None else None)
+                        key_padding_mask=src_key_padding_mask, xq_pre=xq_pre, next_pos=pos if with_pos else None)
 
 
 _LANGUAGE_STREAMS = {}
+_ENCODER_FORK = [switches.flag("encoder_fork", True)]
 
 
 def _language_stream(device):
     st = _LANGUAGE_STREAMS.get(device)
     if st is None:
-        st = _LANGUAGE_STREAMS[device] = torch.cuda.Stream(device)
+        st = _LANGUAGE_STREAMS[device] = graph_audit.own_stream(device, role="encoder.language")
     return st
 
 
 def _fork_language(t):
-    """Fused gfx950 path on a GPU only (BUTD_ENCODER_FORK=0 switches it off: debug hook)."""
-    return t.is_cuda and ab.get_backend() == "hip" and os.environ.get("BUTD_ENCODER_FORK", "1") != "0"
+    """Fused gfx950 path on a GPU only (BUTD_AB=encoder_fork=0 switches it off: A/B hook, worth 0.65 ms per step)."""
+    return t.is_cuda and ab.get_backend() == "hip" and _ENCODER_FORK[0]
 
 
 class BiEncoderLayer(nn.Module):
@@ -221,36 +213,27 @@ class BiEncoderLayer(nn.Module):
         # several times longer.  The two sides only read each other's self-attention outputs
         # (encoder_decoder_layers.py:83,101-102), so there are two hand-over points; fork / join are captured as
         # parallel branches of the hipGraph, autograd runs each node's backward on the stream of its forward.
-        # The self-attention blocks also emit the projections the cross layer needs from their outputs (its query
-        # projections on their own side, the key / value projections for the other side).
         cross = self.cross_layer
-        vis_emit, text_emit = cross.self_emits()
         if fork:
             side.wait_stream(main)
             text_feats.record_stream(side)
         with on_side():
-            text_self, text_em = text_feats, []
+            text_self = text_feats
             if self.self_attention_lang is not None:
-                text_self, _, text_em = self.self_attention_lang(text_feats, src_key_padding_mask=text_padding_mask,
-                                                                 emit=text_emit)
-        vis_self, vis_self_pos, vis_em = vis_feats, None, []
+                text_self = self.self_attention_lang(text_feats, src_key_padding_mask=text_padding_mask)
+        vis_self, vis_self_pos = vis_feats, None
         if self.self_attention_visual is not None:
-            vis_self, vis_self_pos, vis_em = self.self_attention_visual(vis_feats, pos_self,
-                                                                        src_key_padding_mask=padding_mask,
-                                                                        emit=vis_emit, xq_pre=vis_xq_pre)
+            vis_self, vis_self_pos = self.self_attention_visual(vis_feats, pos_self, src_key_padding_mask=padding_mask,
+                                                                xq_pre=vis_xq_pre, with_pos=True)
         if fork:
-            side.wait_stream(main)                  # language <- vision reads vis_self (+ its key / value projections)
-            main.wait_stream(side)                  # vision <- language reads text_self (+ ...)
-            for t in [vis_self] + list(vis_em[1:]):
-                t.record_stream(side)
-            for t in [text_self] + list(text_em[1:]):
-                t.record_stream(main)
-        q_vl, kv_lv = (vis_em[0], tuple(vis_em[1:])) if vis_em else (None, None)
-        q_lv, kv_vl = (text_em[0], tuple(text_em[1:])) if text_em else (None, None)
+            side.wait_stream(main)                  # language <- vision reads vis_self
+            main.wait_stream(side)                  # vision <- language reads text_self
+            vis_self.record_stream(side)
+            text_self.record_stream(main)
         with on_side():
-            text_out = cross.language_branch(text_self, vis_self, padding_mask, q_pre=q_lv, kv_pre=kv_lv)
+            text_out = cross.language_branch(text_self, vis_self, padding_mask)
         vis_out = cross.vision_branch(vis_self, text_self, text_padding_mask, pos_cross, detected_feats,
-                                      detected_mask, xq_pre=vis_self_pos, q_pre=q_vl, kv_pre=kv_vl, next_pos=next_pos)
+                                      detected_mask, xq_pre=vis_self_pos, next_pos=next_pos)
         if fork:
             main.wait_stream(side)                  # join
             text_out.record_stream(main)
@@ -270,7 +253,7 @@ class BiEncoder(nn.Module):
         # the position embedding and the box stream feed every layer: one gradient sum each (fan_out.py)
         # (two consumers per layer -- the self-attention and the vision <- language cross-attention: 2 n aliases, ONE sum)
         # (the one-launch sum takes up to 8 sources: deeper stacks keep one alias per layer)
-        handoff = os.environ.get("BUTD_ENC_POS_HANDOFF", "1") != "0"       # (A/B switch)
+        handoff = True          # (`src + pos` handed from layer to layer; A/B of round 4: neutral, 5 launches fewer)
         two = handoff and 2 * self.num_layers <= 8
         pos_l = fan_out(pos_feats, 2 * self.num_layers if two else self.num_layers)
         pos_of = (lambda i: (pos_l[2 * i], pos_l[2 * i + 1])) if two else (lambda i: pos_l[i])
@@ -323,15 +306,9 @@ class BiDecoderLayer(nn.Module):
         else:
             self.self_posembed = None
 
-    def cross_attentions(self, with_boxes=True):
-        """The cross-attention modules in the order of ``memory_kv``'s slots: language, [boxes], vision."""
-        return [self.cross_l] + ([self.cross_d] if with_boxes else []) + [self.cross_v]
-
     def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask,
-                text_key_padding_mask, detected_feats=None, detected_mask=None, memory_kv=None):
-        """query (B,Q,d), vis (B,V,d), lang (B,L,d), query_pos (B,Q,3|6) -> (B,Q,d).
-        ``memory_kv`` (optional, fused backend): (KVHolder, [(k, v) per cross-attention in ``cross_attentions()``
-        order]) -- the memories' key / value projections as ``fused_attention.memory_kv`` produced them."""
+                text_key_padding_mask, detected_feats=None, detected_mask=None):
+        """query (B,Q,d), vis (B,V,d), lang (B,L,d), query_pos (B,Q,3|6) -> (B,Q,d)."""
         if self.self_posembed is not None:
             query_pos = self.self_posembed(query_pos).transpose(1, 2).contiguous()
         else:
@@ -339,26 +316,20 @@ class BiDecoderLayer(nn.Module):
 
         # the four blocks' position gradients arrive together and are summed in one pass (fan_out.py)
         pos_s, pos_l, pos_d, pos_v = fan_out(query_pos, 4)
-        # ... and every block's kernel also writes `its output + query_pos` and the NEXT block's query projection
-        # while the rows are in LDS; the last one runs the FFN as well
-        nxt = query_pos if query_pos is not None else None
-        has_pos = nxt is not None
-        first = lambda em: em[0] if em else None
+        # ... and every block's LayerNorm kernel also writes `its output + query_pos`: the next block's query input
+        nxt = query_pos
+
+        def blk(*args, **kw):
+            out = ab.block(*args, next_pos=nxt, **kw)
+            return out if isinstance(out, tuple) else (out, None)
+
         boxes = detected_feats is not None
-        query, qp, em = ab.block(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s,
-                                 key_padding_mask=padding_mask, next_pos=nxt,
-                                 emit=[ab.q_projection(self.cross_l, has_pos)])
-        ext = (lambda i: None) if memory_kv is None else \
-            (lambda i: (memory_kv[1][i][0], memory_kv[1][i][1], memory_kv[0], i))
-        query, qp, em = ab.block(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l, xq_pre=qp,
-                                 q_pre=first(em), memory=lang_feats, key_padding_mask=text_key_padding_mask,
-                                 next_pos=nxt, emit=[ab.q_projection(self.cross_d if boxes else self.cross_v, has_pos)],
-                                 kv_ext=ext(0))
+        query, qp = blk(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s, key_padding_mask=padding_mask)
+        query, qp = blk(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l, xq_pre=qp, memory=lang_feats,
+                        key_padding_mask=text_key_padding_mask)
         if boxes:
-            query, qp, em = ab.block(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d, xq_pre=qp,
-                                     q_pre=first(em), memory=detected_feats, key_padding_mask=detected_mask,
-                                     next_pos=nxt, emit=[ab.q_projection(self.cross_v, has_pos)], kv_ext=ext(1))
-        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v, xq_pre=qp, q_pre=first(em),
-                         memory=vis_feats, key_padding_mask=None, ffn=(self.ffn, self.norm2),
-                         kv_ext=ext(2 if boxes else 1))[0]
+            query, qp = blk(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d, xq_pre=qp,
+                            memory=detected_feats, key_padding_mask=detected_mask)
+        query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v, xq_pre=qp,
+                         memory=vis_feats, key_padding_mask=None, ffn=(self.ffn, self.norm2))[0]
         return query.contiguous()

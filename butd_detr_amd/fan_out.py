@@ -12,7 +12,15 @@ import os
 
 import torch
 
-from . import _hiplib
+from . import _hiplib, switches
+
+_ENABLED = [switches.flag("fan_out", True)]
+
+
+def set_enabled(flag):
+    """A/B switch: off = plain reuse of the tensor, autograd's pairwise gradient sums (tests/test_gpu_free_running.py)."""
+    prev, _ENABLED[0] = _ENABLED[0], bool(flag)
+    return prev
 
 
 def _sum(grads):
@@ -51,9 +59,9 @@ class _FanOut(torch.autograd.Function):
 
 def fan_out(t, n):
     """n aliases of ``t`` (n >= 1); plain repetition when there is nothing to gain (no gradient, CPU, n < 3, or
-    BUTD_FAN_OUT=0: debug hook)."""
+    BUTD_AB=fan_out=0 / set_enabled(False): A/B hook)."""
     if (t is None or n < 3 or not t.is_cuda or not t.requires_grad or not torch.is_grad_enabled()
-            or os.environ.get("BUTD_FAN_OUT", "1") == "0"):
+            or not _ENABLED[0]):
         return (t,) * n
     return _FanOut.apply(t, n)
 
@@ -79,6 +87,6 @@ class _Unstack(torch.autograd.Function):
 def unstack(t):
     """The slices ``t[0], t[1], ...`` whose gradients are put back together by one ``stack`` (autograd's
     ``select_backward`` writes each slice's gradient into its own zero tensor of the full shape and adds them up)."""
-    if not t.requires_grad or not torch.is_grad_enabled() or os.environ.get("BUTD_FAN_OUT", "1") == "0":
+    if not t.requires_grad or not torch.is_grad_enabled() or not _ENABLED[0]:
         return tuple(t[i] for i in range(t.shape[0]))
     return _Unstack.apply(t)

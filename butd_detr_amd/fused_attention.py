@@ -18,7 +18,7 @@ import os
 
 import torch
 
-from . import _hiplib
+from . import _hiplib, switches
 from ._hiplib import GemmProblem
 
 _lib = _hiplib.load()
@@ -141,13 +141,12 @@ def _attn_bwd():
     return _lib.butd_attention_bwd_bf16 if _compute_bf16[0] else _lib.butd_attention_bwd
 
 
-_short_keys = [os.environ.get("BUTD_ATTN_SHORT_KEYS", "1") != "0"]
-_short_keys_all = [os.environ.get("BUTD_ATTN_SHORT_KEYS", "1") == "all"]
+_short_keys = [switches.flag("attn_short_keys", True)]
 _SHORT_KEYS_MAX = int(_lib.butd_attention_bwd_short_keys_max())
 
 
 def set_short_keys(flag):
-    """A/B switch (also BUTD_ATTN_SHORT_KEYS=0): the one-kernel backward for key sets of <= 144 rows."""
+    """A/B switch (BUTD_AB=attn_short_keys=0): the one-kernel backward for key sets of <= 144 rows."""
     prev, _short_keys[0] = _short_keys[0], bool(flag)
     return prev
 
@@ -157,10 +156,10 @@ def _short_key_bwd(Lq, Lk):
     call.  Measured (profiles/r04_attention_short_keys.txt, 8 x 8 heads): it wins where a workgroup walks several
     query tiles over one staged key set -- 1024 x 80: 88 us vs 115 us for the two kernels -- and loses where its dK / dV
     atomics are not amortised: 256 x 80: 58 vs 40 us, 256 x 132: 91 vs 47, 1024 x 132: 135 vs 123 (float atomics cost
-    ~25 ns per thousand on this part).  BUTD_ATTN_SHORT_KEYS=all forces it wherever it applies (tests)."""
+    ~25 ns per thousand on this part)."""
     if not _short_keys[0] or _compute_bf16[0] or Lk > _SHORT_KEYS_MAX:
         return False
-    return _short_keys_all[0] or (Lq >= 512 and Lk <= 80)
+    return Lq >= 512 and Lk <= 80
 
 
 def get_compute_dtype():
@@ -192,11 +191,74 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                        *(() if c_bn is None else (_ptr(c_bn[0]), _ptr(c_bn[1]), int(c_bn[2]), float(c_bn[3]), int(c_bn[4]))))
 
 
-def _gemm(problems, ref):
+_MAX_GROUP = 8
+# Deterministic split-K (include/butd_attention.h: c_partial / fold_src).  A weight-gradient problem writes per-slice slabs;
+# its fold is an element-wise rider that joins the NEXT grouped launch of the same backward function (no launch of its
+# own), and what is still pending when that function returns goes out as one small launch (``fold_scope``).  The gradient
+# tensors a backward function hands to autograd are therefore complete in stream order when it returns -- AccumulateGrad
+# may clone or add them right away (it steals the reference only when nothing else holds one), and
+# ``fused_sa._finish`` reshapes one; deferring the folds across functions (one flush per backward pass from an engine
+# callback) was tried first and left ffn.0.weight's gradient a clone of the untouched slab.  Outside a scope the fold is
+# launched at once.
+# OFF by default -- MEASURED (profiles/r05_wgrad_slabs.txt, 3 x 60 steps alternating): 24.15 ms per step with the slabs,
+# 23.35 with round 4's float atomics.  The atomics are executed by the memory side next to the matrix work of the other
+# workgroups (that is the 2x "wasted" traffic the counters show), the slabs cost ~90 small flush launches per step plus
+# their own write + read.  set_wgrad_slabs(True) / BUTD_AB=wgrad_slabs=1 is the bit-reproducible training mode.
+_wgrad_slabs = [switches.flag("wgrad_slabs", False)]
+_pending_folds = []        # fold problems whose producing launch is enqueued (current scope, current stream)
+_scope_depth = [0]
+
+
+def set_wgrad_slabs(flag):
+    prev, _wgrad_slabs[0] = _wgrad_slabs[0], bool(flag)
+    return prev
+
+
+def _launch(problems, device, stream_handle):
     arr = (GemmProblem * len(problems))(*problems)
-    with torch.cuda.device(ref.device):
-        err = _lib.butd_gemm_grouped(arr, len(problems), rng_counter(ref.device).data_ptr(), _stream(ref))
+    with torch.cuda.device(device):
+        err = _lib.butd_gemm_grouped(arr, len(problems), rng_counter(device).data_ptr(), stream_handle)
     _hiplib.check(err, "butd_gemm_grouped")
+
+
+def _flush_folds(ref):
+    """Launch the pending folds on the stream of ``ref`` (the end of a backward function, or an eager call)."""
+    folds = list(_pending_folds)
+    del _pending_folds[:]
+    for i in range(0, len(folds), _MAX_GROUP):
+        _launch(folds[i:i + _MAX_GROUP], ref.device, _stream(ref))
+
+
+def fold_scope(backward):
+    """Decorator of a ``Function.backward``: the split-K folds of its launches ride in its later launches; the rest is
+    flushed before it returns (a backward function runs on ONE stream: the stream of its forward)."""
+    import functools
+
+    @functools.wraps(backward)
+    def wrapped(ctx, *grads):
+        _scope_depth[0] += 1
+        try:
+            out = backward(ctx, *grads)
+        finally:
+            _scope_depth[0] -= 1
+        if _pending_folds and _scope_depth[0] == 0:
+            ref = next(g for g in grads if g is not None)
+            _flush_folds(ref)
+        return out
+    return wrapped
+
+
+def _gemm(problems, ref):
+    if _pending_folds and len(problems) < _MAX_GROUP:    # riders: folds of earlier launches of this backward function
+        room = _MAX_GROUP - len(problems)
+        problems = list(problems) + _pending_folds[:room]
+        del _pending_folds[:room]
+    _launch(problems, ref.device, _stream(ref))
+    new = [p._fold for p in problems if getattr(p, "_fold", None) is not None]
+    if new:
+        _pending_folds.extend(new)
+        if _scope_depth[0] == 0:
+            _flush_folds(ref)
 
 
 # operand descriptors ------------------------------------------------------------------------------
@@ -217,8 +279,31 @@ def _wgrad(dy, x, dw, db, M, N, K, **kw):
     # (a thin 10^6-row product such as SA1's first layer, 64 x 8: 155 us with 256 slices, 105 with 512)
     cap = 512 if N * K <= 1024 else 256
     split = max(1, min(cap, M // 512)) if M >= 16384 else min(32, max(M // 256, min(8, M // 64), 1))
-    return _problem(dy, x, dw, N, K, M, (1, N), (1, K), K, bias_grad=db, ones_col=db is not None,
-                    accumulate=True, split_k=split, **kw)
+    return _slabbed(_problem(dy, x, dw, N, K, M, (1, N), (1, K), K, bias_grad=db, ones_col=db is not None,
+                             accumulate=True, split_k=split, **kw), dw, db)
+
+
+def _slabbed(prob, dw, db):
+    """The accumulate (split-K, atomics) problem ``prob`` with target dw (dense rows) / db in its deterministic form:
+    per-slice slabs + a fold problem (``prob._fold``) that ``_gemm`` schedules.  The fold STORES: dw / db need no zero fill."""
+    if not _wgrad_slabs[0] or (prob.M * prob.N) % 4 or prob.ldc != prob.N or (dw.data_ptr() & 15):
+        return prob
+    kslab = (prob.K + 31) // 32
+    split = max(1, min(prob.split_k, kslab))
+    per = -(-kslab // split)
+    slices = -(-kslab // per)                  # every slice owns at least one 32-deep slab
+    len1, len2 = prob.M * prob.N, (prob.M if db is not None else 0)
+    stride = (len1 + len2 + 3) // 4 * 4
+    ws = torch.empty(slices * stride, device=dw.device)
+    prob.split_k, prob.c_partial, prob.c_partial_stride = slices, ws.data_ptr(), stride
+    fold = GemmProblem()
+    fold.c, fold.bias_grad = dw.data_ptr(), _ptr(db)
+    fold.M, fold.N, fold.K = 1, 1, 1
+    fold.fold_src, fold.fold_count, fold.fold_stride = ws.data_ptr(), slices, stride
+    fold.fold_len, fold.fold_len2 = len1, len2
+    fold._keep = (ws, dw, db)
+    prob._fold = fold
+    return prob
 
 
 def _check(*tensors):
@@ -232,9 +317,9 @@ def _check(*tensors):
 # LayerNorm backward without same-address atomics: the kernel writes per-workgroup column sums, the grouped launch that
 # follows it in every block folds them (one more problem: dgamma | dbeta = ones(1, blocks) . partials).  Measured alone
 # (profiles/r04_small_kernels.txt): the 128 .. 512 atomics per column are 2.9 us of 8.5 us at 2048 rows, 5.0 of 18.4 at
-# 8192.  BUTD_LN_FOLD=0: the atomic kernel (round 3's).
+# 8192.  set_ln_fold(False) / BUTD_AB=ln_fold=0: the atomic kernel (round 3's).
 # -------------------------------------------------------------------------------------------------
-_ln_fold = [os.environ.get("BUTD_LN_FOLD", "1") == "1"]
+_ln_fold = [switches.flag("ln_fold", True)]
 _ones_rows = {}
 _ones_retired = []      # never released: a captured graph may have an older row's address baked in
 
@@ -285,47 +370,6 @@ def _ln_bwd(M, E, dy, x, res, gamma, mean, rstd, dx, d_res, d_gamma, d_beta, p, 
     return [fold]
 
 
-# -------------------------------------------------------------------------------------------------
-# Row-panel chains (include/butd_panel.h): the row-wise operators behind an attention core -- out-projection, dropout,
-# residual, LayerNorm, + pos, projections of the result that the NEXT blocks need, the FFN -- as one launch.
-# -------------------------------------------------------------------------------------------------
-from ._hiplib import PanelStage  # noqa: E402
-
-# OFF by default: measured (profiles/r04_panel_chain.txt).  A stage of a 16-row panel is 360 dependent fp32 matrix
-# instructions per wave on at most 128 of the 256 CUs (2048 rows = 128 panels; the 16 x 16 x 4 tile cannot be cut
-# below 16 rows) = 10 us of matrix time per stage, 14 us with the weights streamed from L2 -- a grouped GEMM launch
-# serves the same product in 6.5-9.4 us on the whole chip.  Fusing therefore only pays where it removes launches
-# that do no matrix work: the step with every chain on is 0.9 ms SLOWER than with none (26.96 vs 26.09 ms).
-_panel_chain = [os.environ.get("BUTD_PANEL_CHAIN", "0") == "1"]
-
-
-def set_panel_chain(flag):
-    """A/B switch (also BUTD_PANEL_CHAIN=1): off = every operator of a block is its own launch, as in round 3."""
-    prev, _panel_chain[0] = _panel_chain[0], bool(flag)
-    return prev
-
-
-def _panel_ok(*dims):
-    return (_panel_chain[0] and not _compute_bf16[0] and all(d in (128, 256, 288) for d in dims))
-
-
-def _stage(w, bias, N, K, in_buf, out_buf, *, scale=1.0, relu=False, drop=(0.0, 0), pre=None, ln=None, res=None,
-           res_buf=-1, out=None, pos=None, out_pos=None, pos_buf=-1):
-    """ln = (gamma, beta, eps, mean, rstd) or None."""
-    g, b, eps, mean, rstd = ln if ln is not None else (None, None, 0.0, None, None)
-    return PanelStage(_ptr(w), _ptr(bias), N, K, float(scale), in_buf, int(relu), float(drop[0]), int(drop[1]),
-                      _ptr(pre), int(ln is not None), _ptr(res), res_buf, _ptr(g), _ptr(b), float(eps),
-                      _ptr(mean), _ptr(rstd), _ptr(out), out_buf, _ptr(pos), _ptr(out_pos), pos_buf)
-
-
-def _panel(rows, inp, in_cols, stages, nbuf, ref, in_buf=0, in_pos=None, in_sum=None, in_sum_buf=1):
-    arr = (PanelStage * len(stages))(*stages)
-    with torch.cuda.device(ref.device):
-        err = _lib.butd_panel_chain(rows, inp.data_ptr(), in_cols, in_buf, _ptr(in_pos), _ptr(in_sum), in_sum_buf,
-                                    arr, len(stages), nbuf, rng_counter(ref.device).data_ptr(), _stream(ref))
-    _hiplib.check(err, "butd_panel_chain")
-
-
 class _AttentionBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, residual, xq, xk, xv, mask, w_in, b_in, w_o, b_o, gamma, beta,
@@ -366,6 +410,7 @@ class _AttentionBlock(torch.autograd.Function):
         return y
 
     @staticmethod
+    @fold_scope
     def backward(ctx, dy):
         (residual, xq, xk, xv, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean,
          rstd) = ctx.saved_tensors
@@ -420,51 +465,40 @@ class _AttentionBlock(torch.autograd.Function):
 
 class _FfnBlock(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, p2, site1, site2, pre=None, next_pos=None):
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, p1, p2, site1, site2, next_pos=None):
         """``next_pos``: also return y + next_pos (values only), written by the LayerNorm kernel: the `src + pos` of the
         NEXT layer's first block (encoder_decoder_layers.py:179-185)."""
         B, L, E = x.shape
         Fh = w1.shape[0]
         M = B * L
         dev = x.device
-        if pre is not None:
-            # the kernel that produced x ran the FFN on the rows it still held in LDS (block(..., ffn=...)): values only
-            # -- the gradients are this Function's as ever
-            h, o, mean, rstd, y = pre
-        else:
-            h = torch.empty((B, L, Fh), device=dev)
-            o = torch.empty((B, L, E), device=dev)
-            y = torch.empty((B, L, E), device=dev)
-            mean = torch.empty((M,), device=dev)
-            rstd = torch.empty((M,), device=dev)
-            if _panel_ok(E, Fh):
-                _panel(M, x, E, [_stage(w1, b1, Fh, E, 0, 1, relu=True, drop=(p1, site1), out=h),
-                                 _stage(w2, b2, E, Fh, 1, 2, pre=o, drop=(p2, site2),
-                                        ln=(gamma, beta, eps, mean, rstd), res_buf=0, out=y)], 3, x)
-            else:
-                _gemm([_fwd(x, w1, h, M, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
-                _gemm([_fwd(h, w2, o, M, E, Fh, bias=b2)], x)
-                y_pos = torch.empty((B, L, E), device=dev) if next_pos is not None else None
-                with torch.cuda.device(dev):
-                    err = _lib.butd_add_dropout_layernorm_fwd_pos(
-                        M, E, o.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
-                        mean.data_ptr(), rstd.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _ptr(next_pos),
-                        _ptr(y_pos), _stream(x))
-                _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
-                if y_pos is not None:
-                    ctx.save_for_backward(x, w1, w2, gamma, h, o, mean, rstd)
-                    ctx.cfg = (p1, p2, site1, site2)
-                    ctx.mark_non_differentiable(y_pos)
-                    ctx.set_materialize_grads(False)
-                    return y, y_pos
+        h = torch.empty((B, L, Fh), device=dev)
+        o = torch.empty((B, L, E), device=dev)
+        y = torch.empty((B, L, E), device=dev)
+        mean = torch.empty((M,), device=dev)
+        rstd = torch.empty((M,), device=dev)
+        _gemm([_fwd(x, w1, h, M, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
+        _gemm([_fwd(h, w2, o, M, E, Fh, bias=b2)], x)
+        y_pos = torch.empty((B, L, E), device=dev) if next_pos is not None else None
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_fwd_pos(
+                M, E, o.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
+                mean.data_ptr(), rstd.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _ptr(next_pos),
+                _ptr(y_pos), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
         ctx.save_for_backward(x, w1, w2, gamma, h, o, mean, rstd)
         ctx.cfg = (p1, p2, site1, site2)
-        return y
+        if y_pos is None:
+            return y
+        ctx.mark_non_differentiable(y_pos)
+        ctx.set_materialize_grads(False)
+        return y, y_pos
 
     @staticmethod
+    @fold_scope
     def backward(ctx, dy, _d_y_pos=None):
         if dy is None:
-            return (None,) * 14
+            return (None,) * 13
         x, w1, w2, gamma, h, o, mean, rstd = ctx.saved_tensors
         p1, p2, site1, site2 = ctx.cfg
         B, L, E = x.shape
@@ -491,7 +525,7 @@ class _FfnBlock(torch.autograd.Function):
                _wgrad(d_o, h, d_w2, d_b2, M, E, Fh)] + fold, x)
         _gemm([_dgrad(d_h, w1, d_x, M, Fh, E, c_add=True),
                _wgrad(d_h, x, d_w1, d_b1, M, Fh, E)], x)
-        return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None, None, None
+        return d_x, d_w1, d_b1, d_w2, d_b2, d_gamma, d_beta, None, None, None, None, None, None
 
 
 class _LinearReluChain(torch.autograd.Function):
@@ -518,6 +552,7 @@ class _LinearReluChain(torch.autograd.Function):
         return acts[-1].view(*lead, ws[-1].shape[0])
 
     @staticmethod
+    @fold_scope
     def backward(ctx, dy):
         n = ctx.n
         acts, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
@@ -581,6 +616,7 @@ class _LinearF32(_LinearReluChain):
             _compute_bf16[0] = prev
 
     @staticmethod
+    @fold_scope
     def backward(ctx, dy):
         prev, _compute_bf16[0] = _compute_bf16[0], False
         try:
@@ -662,8 +698,8 @@ def multi_head_attention(attn, query, key, value, key_padding_mask=None):
 def _xwgrad(dy, ldy, x, dw, db, M, N, K):
     """dw[N,K] += dy[M,N]^T @ x[M,K] (dy rows ldy floats apart), db[N] += column sums of dy."""
     split = max(1, min(256, M // 512)) if M >= 16384 else min(32, max(M // 256, min(8, M // 64), 1))
-    return _problem(dy, x, dw, N, K, M, (1, ldy), (1, K), K, bias_grad=db, ones_col=True,
-                    accumulate=True, split_k=split)
+    return _slabbed(_problem(dy, x, dw, N, K, M, (1, ldy), (1, K), K, bias_grad=db, ones_col=True,
+                             accumulate=True, split_k=split), dw, db)
 
 
 class _XpmBlock(torch.autograd.Function):
@@ -672,59 +708,27 @@ class _XpmBlock(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, pos, mem, mask, w_in, b_in, w_o, b_o, gamma, beta,
-                num_heads, eps, p_attn, p_out, site_attn, site_out, xq_pre=None, next_pos=None,
-                q_pre=None, kv_pre=None, emit=None, ffn=None):
-        """-> (y, y + next_pos | None, *emitted projections, *(h, o, mean2, rstd2, y2) of a chained FFN).
-
-        q_pre / kv_pre: this block's query / (key, value) projections as an earlier kernel already produced them
-        (values only: the gradients of x, pos, mem and of the projection weights are this block's as ever).
-        emit: [(weight (E, E), bias (E), scale, use_pos)]: projections of y (or y + next_pos) that later blocks take as
-        their q_pre / kv_pre.  ffn: (w1, b1, w2, b2, gamma2, beta2, eps2, p1, p2, site1, site2): LayerNorm(y + FFN(y))
-        computed on the rows while they are in LDS, handed to _FfnBlock as ``pre``."""
+                num_heads, eps, p_attn, p_out, site_attn, site_out, xq_pre=None, next_pos=None):
+        """-> y, or (y, y + next_pos) when ``next_pos`` is given (values only, written by the LayerNorm kernel).
+        ``xq_pre``: x + pos as the previous block's LayerNorm kernel already wrote it."""
         B, Lq, E = x.shape
         H, D = num_heads, E // num_heads
         dev = x.device
         self_attn = mem is None
         scale = math.sqrt(1.0 / float(D))
-        chain = _panel_ok(E) and (ffn is None or _panel_ok(ffn[0].shape[0]))
         Mq = B * Lq
-        q = q_pre
-        k, v = kv_pre if kv_pre is not None else (None, None)
         xq = x if pos is None else xq_pre
-        if self_attn and q is None and k is None and chain:
-            # q, k, v of a self-attention block as one panel launch that also forms (and saves) x + pos
-            q = torch.empty((B, Lq, E), device=dev)
-            k = torch.empty((B, Lq, E), device=dev)
-            v = torch.empty((B, Lq, E), device=dev)
-            form = pos is not None and xq is None
-            if form:
-                xq = torch.empty((B, Lq, E), device=dev)
-            qk_in = 1 if pos is not None else 0
-            if form or pos is None:
-                _panel(Mq, x, E, [_stage(w_in[:E], b_in[:E], E, E, qk_in, 2, scale=scale, out=q),
-                                  _stage(w_in[E:2 * E], b_in[E:2 * E], E, E, qk_in, 2, out=k),
-                                  _stage(w_in[2 * E:], b_in[2 * E:], E, E, 0, 2, out=v)], 3, x,
-                       in_pos=pos if form else None, in_sum=xq if form else None)
-            else:       # x + pos arrived from the previous kernel: two inputs, one per launch
-                _panel(Mq, xq, E, [_stage(w_in[:E], b_in[:E], E, E, 0, 1, scale=scale, out=q),
-                                   _stage(w_in[E:2 * E], b_in[E:2 * E], E, E, 0, 1, out=k)], 2, x)
-                _panel(Mq, x, E, [_stage(w_in[2 * E:], b_in[2 * E:], E, E, 0, 1, out=v)], 2, x)
         if xq is None:
             xq = x + pos
         xk, xv = (xq, x) if self_attn else (mem, mem)
         Lk = xk.shape[1]
         Mk = B * Lk
-        probs = []
-        if q is None:
-            q = torch.empty((B, Lq, E), device=dev)
-            probs.append(_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale))
-        if k is None:
-            k = torch.empty((B, Lk, E), device=dev)
-            v = torch.empty((B, Lk, E), device=dev)
-            probs += [_fwd(xk, w_in[E:2 * E], k, Mk, E, E, bias=b_in[E:2 * E]),
-                      _fwd(xv, w_in[2 * E:], v, Mk, E, E, bias=b_in[2 * E:])]
-        if probs:
-            _gemm(probs, x)
+        q = torch.empty((B, Lq, E), device=dev)
+        k = torch.empty((B, Lk, E), device=dev)
+        v = torch.empty((B, Lk, E), device=dev)
+        _gemm([_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale),
+               _fwd(xk, w_in[E:2 * E], k, Mk, E, E, bias=b_in[E:2 * E]),
+               _fwd(xv, w_in[2 * E:], v, Mk, E, E, bias=b_in[2 * E:])], x)
         att = torch.empty((B, Lq, E), device=dev)
         lse = torch.empty((B, H, Lq), device=dev)
         with torch.cuda.device(dev):
@@ -737,66 +741,27 @@ class _XpmBlock(torch.autograd.Function):
         mean = torch.empty((Mq,), device=dev)
         rstd = torch.empty((Mq,), device=dev)
         y_pos = torch.empty((B, Lq, E), device=dev) if next_pos is not None else None
-        emit = emit or []
-        emitted = [torch.empty((B, Lq, E), device=dev) for _ in emit]
-        ffn_out = ()
-        if ffn is not None:
-            w1, b1, w2, b2, g2, be2, eps2, p1, p2, site1, site2 = ffn
-            Fh = w1.shape[0]
-            ffn_out = (torch.empty((B, Lq, Fh), device=dev), torch.empty((B, Lq, E), device=dev),
-                       torch.empty((Mq,), device=dev), torch.empty((Mq,), device=dev),
-                       torch.empty((B, Lq, E), device=dev))
-        if chain:
-            use_pos = any(e[3] for e in emit) and next_pos is not None
-            nbuf = 3
-            stages = [_stage(w_o, b_o, E, E, 0, 1, pre=proj, drop=(p_out, site_out), ln=(gamma, beta, eps, mean, rstd),
-                             res=x, out=y, pos=next_pos, out_pos=y_pos, pos_buf=2 if use_pos else -1)]
-            for (w_e, b_e, sc_e, pos_e), t in zip(emit, emitted):
-                stages.append(_stage(w_e, b_e, E, E, 2 if (pos_e and use_pos) else 1, 0, scale=sc_e, out=t))
-            if ffn is not None:
-                hb = 2
-                if use_pos:
-                    hb, nbuf = 3, 4
-                h, o2, mean2, rstd2, y2 = ffn_out
-                stages += [_stage(w1, b1, Fh, E, 1, hb, relu=True, drop=(p1, site1), out=h),
-                           _stage(w2, b2, E, Fh, hb, 0, pre=o2, drop=(p2, site2), ln=(g2, be2, eps2, mean2, rstd2),
-                                  res_buf=1, out=y2)]
-            _panel(Mq, att, E, stages, nbuf, x)
-        else:
-            _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
-            with torch.cuda.device(dev):
-                err = _lib.butd_add_dropout_layernorm_fwd_pos(
-                    Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
-                    y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
-                    rng_counter(dev).data_ptr(), _ptr(next_pos), _ptr(y_pos), _stream(x))
-            _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
-            if emit:
-                _gemm([_fwd(y_pos if (pos_e and y_pos is not None) else y, w_e, t, Mq, E, E, bias=b_e, scale=sc_e)
-                       for (w_e, b_e, sc_e, pos_e), t in zip(emit, emitted)], x)
-            if ffn is not None:
-                h, o2, mean2, rstd2, y2 = ffn_out
-                _gemm([_fwd(y, w1, h, Mq, Fh, E, bias=b1, relu=True, dropout_p=p1, site=site1)], x)
-                _gemm([_fwd(h, w2, o2, Mq, E, Fh, bias=b2)], x)
-                with torch.cuda.device(dev):
-                    err = _lib.butd_add_dropout_layernorm_fwd(
-                        Mq, E, o2.data_ptr(), y.data_ptr(), g2.data_ptr(), be2.data_ptr(), eps2, y2.data_ptr(),
-                        mean2.data_ptr(), rstd2.data_ptr(), p2, site2, rng_counter(dev).data_ptr(), _stream(x))
-                _hiplib.check(err, "butd_add_dropout_layernorm_fwd")
+        _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_fwd_pos(
+                Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
+                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
+                rng_counter(dev).data_ptr(), _ptr(next_pos), _ptr(y_pos), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
         ctx.save_for_backward(x, xq if pos is not None else None, mem, mask, w_in, w_o, gamma, q, k, v,
                               att, lse, proj, mean, rstd)
         ctx.cfg = (H, p_attn, p_out, site_attn, site_out)
-        extras = ([y_pos] if y_pos is not None else []) + emitted + list(ffn_out)
-        if not extras:
+        if y_pos is None:
             return y
-        ctx.mark_non_differentiable(*extras)
-        ctx.set_materialize_grads(False)             # no zero tensors for the (non-existent) gradients of the extras
-        ctx.n_out = 1 + len(extras)
-        return (y, *extras)
+        ctx.mark_non_differentiable(y_pos)
+        ctx.set_materialize_grads(False)             # no zero tensor for the (non-existent) gradient of y + next_pos
+        return y, y_pos
 
     @staticmethod
+    @fold_scope
     def backward(ctx, dy, *_d_extras):
         if dy is None:                                 # (gradients are not materialised: the block's output unused)
-            return (None,) * 22
+            return (None,) * 18
         x, xq_saved, mem, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean, rstd = ctx.saved_tensors
         H, p_attn, p_out, site_attn, site_out = ctx.cfg
         has_pos = xq_saved is not None
@@ -869,195 +834,18 @@ class _XpmBlock(torch.autograd.Function):
                    _xwgrad(dq, E, xq, d_w_in[:E], d_b_in[:E], Mq, E, E),
                    _xwgrad(G, ldg, mem, d_w_in[E:], d_b_in[E:], Mk, 2 * E, E)], x)
         return (R, d_pos, d_mem, None, d_w_in, d_b_in, d_w_o, d_b_o, d_gamma, d_beta,
-                None, None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None)
 
 
-# -------------------------------------------------------------------------------------------------
-# Decoder: the key / value projections of the constant memories (language, boxes, vision) on a FORKED stream.
-# A decoder layer's three cross-attention blocks (encoder_decoder_layers.py:376-404) project the SAME three memories in
-# every layer; nothing of that depends on the query chain.  ``MemoryKV`` computes a layer's six projections as one
-# grouped launch -- the model issues all layers' launches on a side stream while the main stream runs the query chain
-# (bdetr.BeaUTyDETR._decoder_memory_kv) -- and owns the WHOLE gradient of the three in-projection weights: autograd runs
-# its backward on that side stream too, so the 8192-row products d_mem = [dk|dv] W_kv, dW_kv = [dk|dv]^T mem and the
-# query-side weight gradients dW_q = dq^T (x + pos) leave the main queue, whose blocks keep only the product the next
-# block waits for (d(x + pos) = dq W_q).  ``_XkvBlock`` is the cross-attention block that takes k, v as differentiable
-# inputs and hands (dq, x + pos) to the holder for the deferred weight gradient.
-# -------------------------------------------------------------------------------------------------
-class KVHolder:
-    """Hand-over between the cross-attention blocks of one decoder layer and its MemoryKV node: slot i = block i's
-    (dq, x + pos) for the deferred query-projection weight gradient."""
-
-    def __init__(self, n):
-        self.q = [None] * n
-
-
-class _MemoryKV(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, holder, n, *args):
-        """args = mem_0 .. mem_{n-1}, w_in_0, b_in_0, ..., w_in_{n-1}, b_in_{n-1} -> k_0, v_0, ..., k_{n-1}, v_{n-1}."""
-        mems, wb = args[:n], args[n:]
-        probs, outs = [], []
-        for i, mem in enumerate(mems):
-            w, b = wb[2 * i], wb[2 * i + 1]
-            B, Lk, E = mem.shape
-            k = torch.empty((B, Lk, E), device=mem.device)
-            v = torch.empty((B, Lk, E), device=mem.device)
-            probs += [_fwd(mem, w[E:2 * E], k, B * Lk, E, E, bias=b[E:2 * E]),
-                      _fwd(mem, w[2 * E:], v, B * Lk, E, E, bias=b[2 * E:])]
-            outs += [k, v]
-        for i in range(0, len(probs), 8):
-            _gemm(probs[i:i + 8], mems[0])
-        ctx.save_for_backward(*mems, *wb[0::2])
-        ctx.holder, ctx.n = holder, n
-        ctx.set_materialize_grads(False)
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        n, holder = ctx.n, ctx.holder
-        mems, ws = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
-        dev = mems[0].device
-        probs, d_mems, d_wb = [], [], []
-        for i, (mem, w) in enumerate(zip(mems, ws)):
-            B, Lk, E = mem.shape
-            Mk = B * Lk
-            slab = zeros(3 * E * E + 3 * E, device=dev)
-            d_w, d_b = slab[:3 * E * E].view(3 * E, E), slab[3 * E * E:]
-            d_wb += [d_w, d_b]
-            dk, dv = grads[2 * i], grads[2 * i + 1]
-            if dk is None or dv is None:          # (the block's output went unused)
-                d_mems.append(None)
-            else:
-                # [dk | dv] as the blocks leave it: two column halves of one (B, Lk, 2E) matrix -- read in place
-                packed = (dk.dim() == 3 and dk.stride() == dv.stride() and dk.stride(2) == 1 and dk.stride(1) == 2 * E
-                          and dk.stride(0) == Lk * 2 * E and dv.data_ptr() == dk.data_ptr() + 4 * E)
-                G = dk if packed else torch.cat([dk, dv], dim=-1).contiguous()
-                d_mem = torch.empty((B, Lk, E), device=dev)
-                d_mems.append(d_mem)
-                probs += [_problem(G, w[E:], d_mem, Mk, E, 2 * E, (2 * E, 1), (1, E), E),
-                          _xwgrad(G, 2 * E, mem, d_w[E:], d_b[E:], Mk, 2 * E, E)]
-            stash = holder.q[i]
-            if stash is not None:
-                dq, xq = stash
-                holder.q[i] = None
-                Mq = dq.shape[0] * dq.shape[1]
-                probs.append(_xwgrad(dq, E, xq, d_w[:E], d_b[:E], Mq, E, E))
-        for i in range(0, len(probs), 8):
-            _gemm(probs[i:i + 8], mems[0])
-        return (None, None, *d_mems, *d_wb)
-
-
-def memory_kv(attns, mems):
-    """[(attention module, memory (B, Lk, E))] of one decoder layer -> (KVHolder, [(k, v), ...]): one grouped launch."""
-    holder = KVHolder(len(attns))
-    mems = [m.contiguous() for m in mems]
-    _check(*mems)
-    wb = []
-    for a in attns:
-        wb += [a.in_proj_weight, a.in_proj_bias]
-    out = _MemoryKV.apply(holder, len(attns), *mems, *wb)
-    return holder, [(out[2 * i], out[2 * i + 1]) for i in range(len(attns))]
-
-
-class _XkvBlock(torch.autograd.Function):
-    """LayerNorm(x + Dropout(MHA(x + pos, k, v))) with k, v given (MemoryKV): the gradients of k, v are returned, the
-    in-projection's weight gradient is MemoryKV's."""
-
-    @staticmethod
-    def forward(ctx, x, pos, k, v, mask, w_in, b_in, w_o, b_o, gamma, beta, num_heads, eps, p_attn, p_out,
-                site_attn, site_out, xq_pre, next_pos, holder, slot):
-        B, Lq, E = x.shape
-        Lk = k.shape[1]
-        H, D = num_heads, E // num_heads
-        dev = x.device
-        Mq = B * Lq
-        scale = math.sqrt(1.0 / float(D))
-        xq = x if pos is None else (xq_pre if xq_pre is not None else x + pos)
-        q = torch.empty((B, Lq, E), device=dev)
-        _gemm([_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale)], x)
-        att = torch.empty((B, Lq, E), device=dev)
-        lse = torch.empty((B, H, Lq), device=dev)
-        with torch.cuda.device(dev):
-            err = _attn_fwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask), att.data_ptr(),
-                              lse.data_ptr(), p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))
-        _hiplib.check(err, "butd_attention_fwd")
-        proj = torch.empty((B, Lq, E), device=dev)
-        _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
-        y = torch.empty((B, Lq, E), device=dev)
-        mean = torch.empty((Mq,), device=dev)
-        rstd = torch.empty((Mq,), device=dev)
-        y_pos = torch.empty((B, Lq, E), device=dev) if next_pos is not None else None
-        with torch.cuda.device(dev):
-            err = _lib.butd_add_dropout_layernorm_fwd_pos(
-                Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps, y.data_ptr(),
-                mean.data_ptr(), rstd.data_ptr(), p_out, site_out, rng_counter(dev).data_ptr(), _ptr(next_pos),
-                _ptr(y_pos), _stream(x))
-        _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
-        ctx.save_for_backward(x, xq if pos is not None else None, k, v, mask, w_in, w_o, gamma, q, att, lse, proj,
-                              mean, rstd)
-        ctx.cfg = (H, p_attn, p_out, site_attn, site_out, holder, slot)
-        if y_pos is None:
-            return y
-        ctx.mark_non_differentiable(y_pos)
-        ctx.set_materialize_grads(False)
-        return y, y_pos
-
-    @staticmethod
-    def backward(ctx, dy, _d_y_pos=None):
-        if dy is None:
-            return (None,) * 21
-        x, xq_saved, k, v, mask, w_in, w_o, gamma, q, att, lse, proj, mean, rstd = ctx.saved_tensors
-        H, p_attn, p_out, site_attn, site_out, holder, slot = ctx.cfg
-        has_pos = xq_saved is not None
-        xq = xq_saved if has_pos else x
-        B, Lq, E = x.shape
-        Lk = k.shape[1]
-        D = E // H
-        Mq = B * Lq
-        dev = x.device
-        dy = dy.contiguous()
-        slab = zeros(E * E + E + 2 * E, device=dev)
-        d_w_o, d_b_o = slab[:E * E].view(E, E), slab[E * E:E * E + E]
-        d_gamma, d_beta = slab[E * E + E:E * E + 2 * E], slab[E * E + 2 * E:]
-        R = torch.empty((B, Lq, E), device=dev)
-        d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else R
-        fold = _ln_bwd(Mq, E, dy, proj, x, gamma, mean, rstd, d_proj, R, d_gamma, d_beta, p_out, site_out, x)
-        d_att = torch.empty((B, Lq, E), device=dev)
-        _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E), _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)] + fold, x)
-        short = _short_key_bwd(Lq, Lk)
-        dq = torch.empty((B, Lq, E), device=dev)
-        G = zeros((B, Lk, 2 * E), device=dev) if short else torch.empty((B, Lk, 2 * E), device=dev)
-        delta = torch.empty((B, H, Lq), device=dev)
-        scale = math.sqrt(1.0 / float(D))
-        with torch.cuda.device(dev):
-            err = (_lib.butd_attention_bwd_short_keys if short else _attn_bwd())(
-                B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask), att.data_ptr(),
-                d_att.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), G.data_ptr(),
-                G.data_ptr() + 4 * E, E, 2 * E, scale, p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))
-        _hiplib.check(err, "butd_attention_bwd")
-        d_pos = None
-        if has_pos:       # d(x + pos) = dq W_q goes to pos AND is added into the residual-path gradient
-            d_pos = torch.empty((B, Lq, E), device=dev)
-            _gemm([_problem(dq, w_in, d_pos, Mq, E, E, (E, 1), (1, E), E, c2=R)], x)
-        else:
-            _gemm([_problem(dq, w_in, R, Mq, E, E, (E, 1), (1, E), E, c_add=True)], x)
-        holder.q[slot] = (dq, xq)       # MemoryKV's backward (side stream) turns it into dW_q
-        return (R, d_pos, G[:, :, :E], G[:, :, E:], None, None, None, d_w_o, d_b_o, d_gamma, d_beta,
-                None, None, None, None, None, None, None, None, None, None)
-
-
-def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None,
-          q_pre=None, kv_pre=None, emit=None, ffn=None, kv_ext=None):
+def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None, ffn=None):
     """LayerNorm(x + Dropout(MHA(x + pos, k, v))), (k, v) = (x + pos, x) or (memory, memory).
-    ``kv_ext`` = (k, v, KVHolder, slot): the memory's key / value projections as a ``memory_kv`` node produced them
-    (differentiable: their gradients go back to that node, which also owns the in-projection's weight gradient).
     ``next_pos``: also return ``y + next_pos`` (written by the kernel that produced y; no gradient flows through it) for
     the next block, which takes it as ``xq_pre`` in place of computing ``x + pos`` itself.
-    ``emit``: projections of y / y + next_pos (``q_projection``, ``kv_projections``) computed by the same kernel, to
-    be handed to later blocks as ``q_pre`` / ``kv_pre`` (values only: those blocks own the gradients).
-    ``ffn`` = (ffn Sequential, norm): the FFN block on y in the same kernel.
-    -> y                                   (no extras asked for)
-    -> (y, y + next_pos | None, [emitted...])   otherwise; with ``ffn`` the first element is LayerNorm(y + FFN(y))."""
+    ``ffn`` = (ffn Sequential, norm): the FFN block on y behind it (then ``next_pos`` belongs to the FFN's output).
+    -> y                       (neither asked for)
+    -> (y, y + next_pos | None)   otherwise; with ``ffn`` the first element is LayerNorm(y + FFN(y)).
+    (Round 4's row-panel chain kernels -- out-projection + LayerNorm + the next blocks' projections + FFN as one launch --
+    measured 0.9 ms slower in the step and are gone: profiles/r04_panel_chain.txt)"""
     training = attn.training
     p_attn = float(attn.dropout) if training else 0.0
     p_out = float(dropout.p) if (dropout is not None and dropout.training) else 0.0
@@ -1067,47 +855,20 @@ def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, 
     next_pos = None if next_pos is None else next_pos.detach().contiguous()
     xq_pre = None if (xq_pre is None or pos is None) else xq_pre.detach()
     _check(x, pos, memory)
-    if kv_ext is not None:
-        k_ext, v_ext, holder, slot = kv_ext
-        y = _XkvBlock.apply(x, pos, k_ext, v_ext, _as_mask(key_padding_mask), attn.in_proj_weight.detach(),
-                            attn.in_proj_bias.detach(), attn.out_proj.weight, attn.out_proj.bias, norm.weight,
-                            norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out, _next_site(), _next_site(),
-                            xq_pre, None if ffn is not None else next_pos, holder, slot)
-        y, y_pos = y if isinstance(y, tuple) else (y, None)
-        if ffn is not None:
-            y = ffn_block(ffn[0], ffn[1], y)
-        return (y, y_pos, []) if (next_pos is not None or emit is not None or ffn is not None) else y
-    extras_asked = next_pos is not None or emit is not None or ffn is not None
-    chain = _panel_ok(x.shape[-1]) and (ffn is None or _panel_ok(ffn[0][0].out_features))
-    if not chain:       # no chain kernels: the hints that only pay inside one are dropped (round 3's launches)
-        emit, q_pre, kv_pre = None, None, None
-    emit = [(w.detach(), b.detach(), sc, up) for w, b, sc, up in (emit or [])]
-    ffn_pack = None
+    extras_asked = next_pos is not None or ffn is not None
+    blk_pos = None if ffn is not None else next_pos
+    ffn_sites = (_next_site(), _next_site()) if ffn is not None else None     # (numbered before the block's own, as ever)
+    out = _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
+                          attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
+                          norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
+                          _next_site(), _next_site(), xq_pre, blk_pos)
+    y, y_pos = out if isinstance(out, tuple) else (out, None)
     if ffn is not None:
         seq, norm2 = ffn
         lin1, _, drop1, lin2, drop2 = seq
         p1 = float(drop1.p) if drop1.training else 0.0
         p2 = float(drop2.p) if drop2.training else 0.0
-        ffn_sites = (_next_site(), _next_site())      # (numbered before the block's own: the same on both paths)
-        if chain:
-            ffn_pack = (lin1.weight.detach(), lin1.bias.detach(), lin2.weight.detach(), lin2.bias.detach(),
-                        norm2.weight.detach(), norm2.bias.detach(), float(norm2.eps), p1, p2, *ffn_sites)
-    # with an FFN behind the block `next_pos` belongs to the FFN's output (the layer's output): unchained, the FFN's own
-    # LayerNorm kernel writes y + next_pos; chained, the panel kernel's last stage would (not built: the chain is off)
-    ffn_pos = next_pos if (ffn is not None and not chain) else None
-    blk_pos = None if ffn is not None else next_pos
-    out = _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
-                          attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
-                          norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
-                          _next_site(), _next_site(), xq_pre, blk_pos,
-                          None if q_pre is None else q_pre.detach(),
-                          None if kv_pre is None else tuple(t.detach() for t in kv_pre), emit, ffn_pack)
-    out = list(out) if isinstance(out, tuple) else [out]
-    y = out.pop(0)
-    y_pos = out.pop(0) if blk_pos is not None else None
-    emitted = [out.pop(0) for _ in emit]
-    if ffn is not None:
         r = _FfnBlock.apply(y, lin1.weight, lin1.bias, lin2.weight, lin2.bias, norm2.weight, norm2.bias,
-                            float(norm2.eps), p1, p2, *ffn_sites, tuple(out) if chain else None, ffn_pos)
+                            float(norm2.eps), p1, p2, *ffn_sites, next_pos)
         y, y_pos = r if isinstance(r, tuple) else (r, None)
-    return (y, y_pos, emitted) if extras_asked else y
+    return (y, y_pos) if extras_asked else y

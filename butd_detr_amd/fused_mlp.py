@@ -18,16 +18,16 @@ import os
 
 import torch
 
-from . import _hiplib
+from . import _hiplib, switches
 from ._hiplib import BnSegment
-from .fused_attention import _gemm, _problem, _stream, rng_counter, _site, zeros
+from .fused_attention import _gemm, _problem, _slabbed, _stream, fold_scope, rng_counter, _site, zeros
 
 _lib = _hiplib.load()
-_FOLD_BN = [__import__("os").environ.get("BUTD_FOLD_BN", "1") != "0"]     # A/B switch of the in-product BatchNorm bookkeeping
+_FOLD_BN = [switches.flag("mlp_fold_bn", True)]     # A/B switch of the in-product BatchNorm bookkeeping
 
 
-_FUSE_STATS = [os.environ.get("BUTD_MLP_FUSE_STATS", "1") != "0"]
-_FUSE_DROP = [os.environ.get("BUTD_MLP_FUSE_STATS", "1") != "nodrop"]      # "nodrop": only chains without a Dropout (A/B)
+_FUSE_STATS = [switches.flag("mlp_fuse_stats", True)]
+_FUSE_DROP = [True]      # False: only chains without a Dropout (round 4's A/B: 23.42 -> 23.31 ms with it)
 
 
 def set_fuse_stats(flag):
@@ -145,6 +145,7 @@ class _MlpChains(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @fold_scope
     def backward(ctx, *d_outs):
         spec, p = ctx.spec, ctx.p
         G, nh, Hs = spec.G, spec.nh, spec.Hs
@@ -186,14 +187,14 @@ class _MlpChains(torch.autograd.Function):
             """dw[N,K] += dy[P,N]^T @ input_of_layer_l[P,K]  (+ db = column sums of dy)."""
             a, lda, b_aff, b_drop = operand(l, i)
             K = Cin if l == 0 else Hs[l - 1]
-            return _problem(dy, a, dw, N, K, P, (1, ldy), (1, lda), K, bias_grad=db,
-                            ones_col=db is not None, accumulate=True, split_k=_split(P),
-                            b_affine=b_aff, b_drop=b_drop)
+            return _slabbed(_problem(dy, a, dw, N, K, P, (1, ldy), (1, lda), K, bias_grad=db,
+                                     ones_col=db is not None, accumulate=True, split_k=_split(P),
+                                     b_affine=b_aff, b_drop=b_drop), dw, db)
 
         # The product that CREATES the gradient arriving at layer l's BatchNorm + ReLU applies the ReLU gate and leaves the
         # two column sums of the BatchNorm backward behind (butd_gemm_problem.c_bn_*): butd_mlp_mask_stats then has
         # nothing left to do for that layer (a dropout behind the activation included: the same counter hash).  Not for the
-        # gradient that arrives from outside (a BatchNorm + ReLU tail).  BUTD_MLP_FUSE_STATS=0: round 3's launches.
+        # gradient that arrives from outside (a BatchNorm + ReLU tail).  BUTD_AB=mlp_fuse_stats=0: round 3's launches.
         p_of = lambda l: 0.0 if (spec.tail and l == nh - 1) else float(p)
         fused_stats = lambda l: _FUSE_STATS[0] and (_FUSE_DROP[0] or p_of(l) == 0.0)
 

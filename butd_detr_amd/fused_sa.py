@@ -10,8 +10,8 @@ import os
 
 import torch
 
-from . import _hiplib
-from .fused_attention import _dgrad, _fwd, _gemm, _wgrad, zeros
+from . import _hiplib, switches
+from .fused_attention import _dgrad, _flush_folds, _fwd, _gemm, _pending_folds, _wgrad, fold_scope, zeros
 
 _lib = _hiplib.load()
 
@@ -31,17 +31,18 @@ def _call(name, ref, *args):
 
 
 # Training-mode backward of the last layer + max-pool by linearity (include/butd_sa.h, butd_sa_last_bwd): no dense dZ3,
-# half the matrix work, 3.25 -> 1.34 GB at SA1.  BUTD_SA_LAST_BWD=0 keeps the dense path (A/B switch, and the path of
+# half the matrix work, 3.25 -> 1.34 GB at SA1.  BUTD_AB=sa_last_bwd=0 keeps the dense path (A/B switch, and the path of
 # widths / nsample the kernel has no instance for).
-_LAST_LIN = [os.environ.get("BUTD_SA_LAST_BWD", "1") != "0"]
-_LAST_FWD = [os.environ.get("BUTD_SA_LAST_FWD", "1") != "0"]      # ... and the forward that does not write Z3
-_FIRST_LIN = [os.environ.get("BUTD_SA_FIRST_BWD", "1") != "0"]     # ... and the first layer's, where no input gradient is wanted
-_MID_FIRST = [os.environ.get("BUTD_SA_MID_BWD", "1") != "0"]       # ... with layer 2's backward in the same pass (64-wide levels)
+_LAST_LIN = [switches.flag("sa_last_bwd", True)]
+_LAST_FWD = [switches.flag("sa_last_fwd", True)]      # ... and the forward that does not write Z3
+_FIRST_LIN = [switches.flag("sa_first_bwd", True)]     # ... and the first layer's, where no input gradient is wanted
+_MID_FIRST = [switches.flag("sa_mid_bwd", True)]       # ... with layer 2's backward in the same pass (64-wide levels)
 # ... and SA1's forward never writing Z1 (butd_sa_first_two_fwd): layer 1's BatchNorm sums from the 8 x 8 moments of X, z1
 # formed on the matrix cores by layer 2's kernel and, with the same instructions, by the backward.  23.64 -> 23.44 ms
 # (4 x 60 steps), and the SA1 gradients move 4-5x CLOSER to a float64 run (closer than stock torch's):
 # profiles/r04_sa_last_layer.txt.  (A first version that recomputed z1 with scalar code from the LDS X tile was neutral.)
-_NO_Z1 = [os.environ.get("BUTD_SA_NO_Z1", "1") != "0"]
+_NO_Z1 = [switches.flag("sa_no_z1", True)]
+_FUSED_EVAL = [switches.flag("sa_fused_eval", True)]     # inference: a whole level as one kernel (sa_fused_eval)
 _scratch_sizes = {}
 _sched = {}
 
@@ -62,7 +63,7 @@ def set_last_layer_linear(flag):
     return prev
 
 
-_LAST_MIN_ROWS = [int(os.environ.get("BUTD_SA_LAST_MIN_ROWS", "0"))]
+_LAST_MIN_ROWS = [0]
 
 
 def _last_lin_ok(training, ns, C2, C3, P=1 << 30):
@@ -81,8 +82,8 @@ def _last_scratch(P, C2, C3):
     return _scratch_sizes[key]
 
 
-_FUSE_STATS = [os.environ.get("BUTD_SA_FUSE_STATS", "1") != "0"]   # layer 1's gate + BatchNorm-backward sums in the epilogue of the product that creates dH1
-_GATHER = [os.environ.get("BUTD_SA_GATHER", "1") != "0"]      # feature gradient as a gather over the inverted neighbour lists
+_FUSE_STATS = [switches.flag("sa_fuse_stats", True)]   # layer 1's gate + BatchNorm-backward sums in the epilogue of the product that creates dH1
+_GATHER = [switches.flag("sa_gather", True)]      # feature gradient as a gather over the inverted neighbour lists
 
 
 def inverse_index(idx, N):
@@ -151,7 +152,7 @@ class _SAMlpPool(torch.autograd.Function):
         # ends in 1 024 double atomics per column address otherwise (65536x128x128: 64.9 -> 51.3 us).  (256
         # copies were measured for the 10^6-row layers: the per-tile epilogue work costs more than the
         # separate chunked pass.)
-        SLOTS = int(os.environ.get("BUTD_SA_SLOTS", "16"))
+        SLOTS = 16
         stats = zeros((3, SLOTS, 2, Cm), dtype=torch.float64, device=dev)
         aff = torch.empty((3, 4, max(C1, C2, C3)), device=dev)  # per layer: mean, rstd, scale, shift
         layers = ((g1, b1, rm1, rv1, nbt1, eps1), (g2, b2, rm2, rv2, nbt2, eps2),
@@ -202,7 +203,7 @@ class _SAMlpPool(torch.autograd.Function):
                 # BatchNorm sums straight from the GEMM epilogue while the row count is moderate (every tile
                 # ends in 2 double atomics per column); the last layer's pass also takes the pooling extrema
                 # (limit measured in the step, round 4: up to 131 072 rows 25.62 ms, 262 144 rows 25.40, 1 048 576 rows 25.51)
-                in_gemm_stats = training and not last and P <= int(os.environ.get("BUTD_SA_INGEMM_MAX", "262144"))
+                in_gemm_stats = training and not last and P <= 262144
                 thin = li == 0 and Kp == 8      # SA1: xyz + colour -> one HBM pass does the product AND the sums
                 if thin:
                     _call("butd_sa_thin_conv", xyz, P, Cl, Kp, X.data_ptr(), Kp, w.data_ptr(), Z.data_ptr(),
@@ -240,6 +241,7 @@ class _SAMlpPool(torch.autograd.Function):
         return out_cm, out_pm
 
     @staticmethod
+    @fold_scope
     def backward(ctx, d_cm, d_pm):
         X, Z1, Z2, Z3, idx, aff, zsel, asel, w1, w2, w3, g1, g2, g3 = ctx.saved_tensors
         B, N, np_, ns, C, training, need_dfeat, s1, s2, s3, Cin, lin = ctx.cfg
@@ -354,6 +356,8 @@ class _SAMlpPool(torch.autograd.Function):
 
     @staticmethod
     def _finish(ctx, S, dW1, dW2, dW3, d_feats, widths, shapes, Cin):
+        if _pending_folds:          # (dW1 is re-laid out below: the split-K slabs of the dense path have to be folded first)
+            _flush_folds(S)
         C1, C2, C3 = widths
         s1, s2, s3 = shapes
         dW1 = dW1[:, :Cin]
@@ -389,7 +393,7 @@ def fused_eval_supported(module):
     """butd_sa_fused_eval: hidden widths <= 128, output <= 256, all multiples of 32, nsample 16 / 32 / 64."""
     cs = [l.conv.out_channels for l in module.mlp_module]
     return (module.nsample in (16, 32, 64) and all(c % 32 == 0 for c in cs) and cs[0] <= 128 and cs[1] <= 128
-            and cs[2] <= 256 and os.environ.get("BUTD_SA_FUSED_EVAL", "1") != "0")
+            and cs[2] <= 256 and _FUSED_EVAL[0])
 
 
 def sa_fused_eval(module, xyz, new_xyz, idx, features_pm=None, feat_offset=0):

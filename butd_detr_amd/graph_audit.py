@@ -67,3 +67,26 @@ def make_safe(cuda_graph):
         raise RuntimeError(f"{left} memset node(s) left in a captured graph: replaying it is unsafe on this ROCm "
                            "(butd_detr_amd/graph_audit.py)")
     return n.value
+
+
+_OWN_STREAMS = {}
+
+
+def own_stream(device=None, role="side", priority=0):
+    """A stream of our own (``butd_stream_create``) wrapped as ``torch.cuda.ExternalStream`` -- NOT a member of torch's
+    round-robin pool of 32, which RCCL's stream and torch's default capture stream come from too (include/butd_graph.h).
+    Everything the captured step forks, captures on or uploads through is created here.  One stream per (device, role)
+    and process, never destroyed: torch's caching allocator keeps per-stream state keyed by the raw handle (block
+    pools, record_stream events), so a destroyed handle would be touched again by a later empty_cache()."""
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, role)
+    stream = _OWN_STREAMS.get(key)
+    if stream is None:
+        handle = ctypes.c_void_p(0)
+        with torch.cuda.device(dev):
+            _hiplib.check(_hiplib.load().butd_stream_create(int(priority), ctypes.byref(handle)), "butd_stream_create")
+            stream = _OWN_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=dev)
+    return stream

@@ -554,8 +554,13 @@ class GraphedTrainStep:
         cache = getattr(self._module(), "text_cache", None)
         self.text_outside = bool(self.prefetch_text and cache is not None and cache.cache_in_training)
         self.token_bucket = token_bucket
-        self.max_slots = int(os.environ.get("BUTD_MAX_SLOTS", "8")) if max_slots is None else max_slots
+        self.max_slots = 8 if max_slots is None else max_slots
         self.verbose = verbose or os.environ.get("BUTD_STEP_VERBOSE", "0") == "1"
+        self.step_sync = False
+        # where the two prefetch branches are forked inside the captured step: "start" | "encoder" | "decoder" | "loss"
+        # (measured, round 4: the language model's 2.3 ms of chip-wide stock kernels next to the launch-bound decoder,
+        # 25.13 -> 24.99 ms; the sampling chain at the start)
+        self.fps_fork_at, self.text_fork_at = "start", "decoder"
         self.arena = None
         from . import attention_blocks
         if zero_arena and attention_blocks.get_backend() == "hip":   # only the fused blocks draw from it
@@ -638,6 +643,8 @@ class GraphedTrainStep:
         def fork(where, fn):
             """Run ``fn`` (which forks a side stream off the CURRENT point of the main stream) now, or when the forward
             pass reaches the encoder / decoder (BeaUTyDETR._stage_hook)."""
+            if where not in ("start", "encoder", "decoder", "loss"):    # (an unknown stage would never fire: the branch
+                raise ValueError(f"fork point {where!r}: start | encoder | decoder | loss")   # would silently not run)
             if where == "start":
                 fn()
             else:
@@ -652,7 +659,7 @@ class GraphedTrainStep:
                 s.sample_stream.wait_stream(torch.cuda.current_stream())   # fork: next batch's chain on 8 CUs
                 with torch.cuda.stream(s.sample_stream):
                     self._sample_into_next()
-            fork(os.environ.get("BUTD_FPS_FORK_AT", "start"), fork_sampling)
+            fork(self.fps_fork_at, fork_sampling)
         if self.prefetch_text and not self.text_outside:
             s.text_cur.copy_(s.text_next)                    # this batch's language features
 
@@ -663,7 +670,7 @@ class GraphedTrainStep:
             # forked where the decoder starts, not at the start of the step: the language model's 2.3 ms of chip-wide stock
             # kernels then run next to the launch-bound decoder / criterion instead of next to the HBM-bound set
             # abstraction (measured, 4 runs each of 60 steps: 25.13 -> 24.99 ms; "loss" = after the forward pass)
-            fork(os.environ.get("BUTD_TEXT_FORK_AT", "decoder"), fork_text)
+            fork(self.text_fork_at, fork_text)
         s.inputs["_stage_hooks"] = hooks
         try:
             end_points = self.model.forward_tokenized(s.inputs, s.tok)
@@ -824,7 +831,7 @@ class GraphedTrainStep:
             s.inputs["backbone_plan"] = self._plan_from_pieces(cur_views)
             n_inds = sum(t.numel() for t in pieces[:4])
             s.inds_cur = s.plan_cur[:4 * n_inds].view(torch.int32)    # the concatenated sample lists of the current batch
-            s.sample_stream = torch.cuda.Stream()
+            s.sample_stream = self._own_stream("sample")
             for src, dst in zip(pieces, s.plan_next_views):   # prime with THIS batch
                 dst.copy_(src)
             torch.cuda.synchronize()
@@ -833,10 +840,10 @@ class GraphedTrainStep:
             s.text_next = self._module().encode_text(s.tok_next, inputs.get("text")).clone()   # THIS batch
             s.text_cur = s.text_next.clone()
             s.inputs["text_encoder_output"] = s.text_cur
-            s.text_stream = torch.cuda.Stream()
+            s.text_stream = self._own_stream("text")
             torch.cuda.synchronize()
         snap = self._snapshot()
-        side = torch.cuda.Stream()
+        side = self._own_stream("warmup")
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.warmup):
@@ -853,26 +860,24 @@ class GraphedTrainStep:
         # nodes are unreliable on ROCm 7.2 (graph_audit.py)
         from . import graph_audit
         s.graphs = {}
+        cap = self._own_stream("capture")     # (torch's default capture stream is a pool stream too)
         if self.split:
             s.g_stage1 = s.graphs["stage1"] = graph_audit.new_graph()
-            with torch.cuda.graph(s.g_stage1, capture_error_mode=self._capture_mode):
+            with torch.cuda.graph(s.g_stage1, capture_error_mode=self._capture_mode, stream=cap):
                 s.loss = self._stage1()
             s.g_stage2 = s.graphs["stage2"] = graph_audit.new_graph()
-            with torch.cuda.graph(s.g_stage2, pool=s.g_stage1.pool(), capture_error_mode=self._capture_mode):
+            with torch.cuda.graph(s.g_stage2, pool=s.g_stage1.pool(), capture_error_mode=self._capture_mode, stream=cap):
                 self._stage2()
             pool = s.g_stage1.pool()
         else:
             s.g_fwd_bwd = s.graphs["fwd_bwd"] = graph_audit.new_graph()
-            with torch.cuda.graph(s.g_fwd_bwd, capture_error_mode=self._capture_mode):
+            with torch.cuda.graph(s.g_fwd_bwd, capture_error_mode=self._capture_mode, stream=cap):
                 s.loss = self._fwd_bwd()
             pool = s.g_fwd_bwd.pool()
         s.g_update = s.graphs["update"] = graph_audit.new_graph()
-        with torch.cuda.graph(s.g_update, pool=pool, capture_error_mode=self._capture_mode):
+        with torch.cuda.graph(s.g_update, pool=pool, capture_error_mode=self._capture_mode, stream=cap):
             self._update()
-        if os.environ.get("BUTD_GRAPH_REWRITE", "1") == "0":      # debug hook: leave the memset nodes in place
-            s.memset_nodes_rewritten = {k: 0 for k in s.graphs}
-        else:
-            s.memset_nodes_rewritten = {k: graph_audit.make_safe(g) for k, g in s.graphs.items()}
+        s.memset_nodes_rewritten = {k: graph_audit.make_safe(g) for k, g in s.graphs.items()}
         s.node_inventory = {k: dict(graph_audit.inventory(g)) for k, g in s.graphs.items()}
         for g in s.graphs.values():
             g.instantiate()
@@ -909,9 +914,15 @@ class GraphedTrainStep:
             out[k] = torch.nn.functional.pad(v, (0, want - length), value=fill)
         return BatchEncoding(out)
 
+    def _own_stream(self, name, dev=None):
+        """The step's streams are its own HIP streams, one per role and shared by all captured signatures -- never members
+        of torch's pool of 32, which RCCL's stream is drawn from as well (graph_audit.own_stream)."""
+        from . import graph_audit
+        return graph_audit.own_stream(dev, role="step." + name)
+
     def _upload_stream(self, dev):
         if getattr(self, "_up", None) is None:
-            self._up = torch.cuda.Stream(dev)
+            self._up = self._own_stream("upload", dev)
             self._up_done = torch.cuda.Event()
             self._up_pinned = {}
         return self._up
@@ -946,11 +957,10 @@ class GraphedTrainStep:
         return self._pad_tokens(BatchEncoding(out))
 
     def __call__(self, inputs, targets, next_inputs=None):
-        # BUTD_STEP_SYNC=1 (debug hook): wait for the previous step before enqueueing this one.  Round 2 needed it for
-        # the two-piece step; the cause was a replayed MEMSET node (torch's vector_norm semaphore) -- gone since the
-        # clip coefficient is butd_clip_coefficient and captured graphs are scrubbed of memset nodes (graph_audit.py),
-        # pinned by tests/test_gpu_free_running.py.
-        if os.environ.get("BUTD_STEP_SYNC") == "1":
+        # step_sync (debug hook, tests/test_gpu_free_running.py): wait for the previous step before enqueueing this one.
+        # Round 2 needed it for the two-piece step; the cause was a replayed MEMSET node (torch's vector_norm semaphore)
+        # -- gone since the clip coefficient is butd_clip_coefficient and captured graphs are scrubbed of memset nodes.
+        if self.step_sync:
             torch.cuda.current_stream().synchronize()
         # host work stays in the step; a batch announced by the previous call was tokenised then
         cache = getattr(self, "_tok_cache", None)

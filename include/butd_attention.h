@@ -115,6 +115,24 @@ typedef struct {
   long c_bn_ld;
   float c_bn_drop_p;
   uint32_t c_bn_drop_site;
+  /* Deterministic split-K (round 5): with c_partial != NULL an accumulate != 0 problem issues NO atomics.  Slice s of its
+   * split_k slices stores its share with plain (float4) stores at c_partial + s * c_partial_stride, laid out dense
+   * [M][N] with the ones-column's results (the bias gradient, M floats) behind it at offset M * N; c and bias_grad are
+   * not touched.  Every slice must own at least one 32-deep slab of the contraction (the caller passes the effective
+   * slice count); no bias / relu / output dropout.  c_partial 16-byte aligned, c_partial_stride a multiple of 4.
+   * Device-scope float atomics are served by the memory side on this part (eight L2s, one per XCD): ~25 ns per
+   * thousand and a 32-byte request each -- a 288 x 288 weight gradient in 8 slices was 0.67 M of them. */
+  float *c_partial;
+  long c_partial_stride;
+  /* A FOLD problem (fold_src != NULL; M, N, K, a, b are ignored): the sum, in slice order (bit-reproducible), of
+   * fold_count partial slabs that an EARLIER launch on the same stream wrote as above:
+   *   c[i]         (=|+=, c_add)  sum_s fold_src[s * fold_stride + i],              0 <= i < fold_len   (fold_len % 4 == 0)
+   *   bias_grad[j] (=|+=, c_add)  sum_s fold_src[s * fold_stride + fold_len + j],   0 <= j < fold_len2  (bias_grad may be NULL)
+   * As one more problem of a grouped launch it costs no launch of its own ("ride along", as the LayerNorm backward's
+   * column sums): an element-wise pass of ceil((fold_len + fold_len2) / 2048) workgroups. */
+  const float *fold_src;
+  int fold_count;
+  long fold_stride, fold_len, fold_len2;
 } butd_gemm_problem;
 
 /* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).

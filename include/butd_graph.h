@@ -33,6 +33,16 @@ int butd_timeline_mark(unsigned long long *slots, int slot, void *stream);
  * seen on HIP runtime 7.2, torch 2.10.0+rocm7.0; tests/test_gpu_runtime_probe.py reports whether it is still there). */
 int butd_runtime_versions(int *runtime, int *driver);
 
+/* A HIP stream that belongs to the caller alone (hipStreamCreateWithPriority, non-blocking; priority 0 = default,
+ * negative = higher).  torch.cuda.Stream() hands out the members of a fixed pool of 32 streams per priority round-robin,
+ * the pool RCCL's own stream (ProcessGroupNCCL) and torch's default graph-capture stream come from too: the 33rd
+ * "new" stream of a process IS one of the first 32 again.  A forked branch of a captured step that lands on RCCL's stream
+ * puts that stream into capture mode while the process group's watchdog thread polls events recorded on it -> the
+ * process aborts with hipErrorCapturedEvent (round 4, DESIGN.md 7.4 #6b; reproducer: scratch/stream_alias_probe.py).
+ * The step's streams therefore never come from the pool (butd_detr_amd/graph_audit.py: own_stream). */
+int butd_stream_create(int priority, void **stream);
+int butd_stream_destroy(void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -13,7 +13,7 @@ then never wrote its result, the clip coefficient became 1.0 and the update went
   wait before every step and the eager packed-optimizer run end (fp32 atomics make trajectories chaotic at the
   1 % level -- measured spread of identical runs: +-1.6 % -- so the bound is 5 % on the mean of the last
   two visits of every batch; an unclipped update moved it by 8-18 %),
-for {single graph, two-piece overlapped exchange} x {BUTD_FAN_OUT 1, 0} x {prefetch branches on, off}."""
+for {single graph, two-piece overlapped exchange} x {fan_out on, off} x {prefetch branches on, off}."""
 import gc
 import os
 import warnings
@@ -113,9 +113,11 @@ def _run(step, batches, n, counter_base, pin_per_batch):
 def test_free_running_step(split, fan_out, prefetch, batches, process_group, eager_tail):
     from butd_detr_amd import attention_blocks
     from butd_detr_amd.train_step import FlatAdamW, GraphedTrainStep, HungarianCriterion
-    env = {"BUTD_FAN_OUT": fan_out, "BUTD_STEP_SYNC": "0", "BUTD_FORCE_COLLECTIVE": "1" if split else "0"}
+    from butd_detr_amd import fan_out as fan_out_mod
+    env = {"BUTD_FORCE_COLLECTIVE": "1" if split else "0"}
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
+    prev_fan = fan_out_mod.set_enabled(fan_out == "1")
     model = step = None
     try:
         model = _model()
@@ -150,12 +152,13 @@ def test_free_running_step(split, fan_out, prefetch, batches, process_group, eag
             step._restore(snap)
             for g, (lr, wd) in zip(opt.param_groups, lrs):
                 g["lr"], g["weight_decay"] = lr, wd
-            os.environ["BUTD_STEP_SYNC"] = sync
+            step.step_sync = sync == "1"
             torch.cuda.synchronize()
             tails[mode] = float(_run(step, batches, STEPS, 5000, pin_per_batch=False)[-2 * NB:, 0].mean())
         assert abs(tails["free"] - tails["synced"]) <= 0.05 * tails["synced"], (tails, eager_tail)
         assert abs(tails["free"] - eager_tail) <= 0.05 * eager_tail, (tails, eager_tail)
     finally:
+        fan_out_mod.set_enabled(prev_fan)
         for k, v in saved.items():
             if v is None:
                 os.environ.pop(k, None)

@@ -107,48 +107,3 @@ def test_config0_one_cloud_one_query_eight_tokens():
         assert float((g_h - g_t).abs().max() / g_t.abs().max()) <= 5e-3
     finally:
         attention_blocks.set_backend("torch")
-
-
-def test_decoder_memory_kv_fork_equals_the_in_block_projections(monkeypatch):
-    """BUTD_DECODER_KV_FORK=1: the decoder's key / value projections of the constant memories as MemoryKV nodes on a
-    forked stream (their backward owns the in-projection weight gradients, incl. the deferred query side) against the
-    default, where every block projects its own memory: same outputs, same gradients (train mode, dropout 0)."""
-    from butd_detr_amd import attention_blocks
-    from butd_detr_amd.bdetr import BeaUTyDETR
-    from butd_detr_amd.offline_text import offline_factory
-    from butd_detr_amd.train_step import surrogate_loss, synthetic_batch
-    from tests.golden.cases import zero_dropout
-    cfg = dict(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=64, num_decoder_layers=3,
-               num_encoder_layers=1, self_position_embedding="loc_learned", contrastive_align_loss=True,
-               butd=True, self_attend=True, text_encoder_factory=offline_factory(0))
-    try:
-        attention_blocks.set_backend("hip")
-        torch.manual_seed(2)
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            a = BeaUTyDETR(**cfg).cuda()
-        zero_dropout(a.train())
-        b = copy.deepcopy(a)
-        inputs, targets = synthetic_batch(2, torch.device("cuda", 0), seed=6, n_points=4096, tokens=24)
-        out = {}
-        for name, model, fork in (("in-block", a, "0"), ("forked", b, "1")):
-            monkeypatch.setenv("BUTD_DECODER_KV_FORK", fork)
-            ep = model(inputs)
-            loss = surrogate_loss(ep, targets)
-            loss.backward()
-            torch.cuda.synchronize()
-            out[name] = (ep, float(loss.detach()))
-        assert abs(out["forked"][1] - out["in-block"][1]) <= 1e-5 * max(abs(out["in-block"][1]), 1.0)
-        for key in ("last_center", "last_sem_cls_scores", "last_proj_queries"):
-            np.testing.assert_allclose(out["forked"][0][key].detach().cpu().numpy(),
-                                       out["in-block"][0][key].detach().cpu().numpy(), rtol=0, atol=1e-5)
-        top = max(float(q.grad.abs().max()) for q in a.parameters() if q.grad is not None)
-        for (n, p), (_, q) in zip(b.named_parameters(), a.named_parameters()):
-            if q.grad is None:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
-                continue
-            # (a convolution bias in front of a BatchNorm has a zero gradient: both runs hold rounding noise there)
-            scale = max(float(q.grad.abs().max()), 1e-3 * top)
-            assert float((p.grad - q.grad).abs().max()) <= 2e-4 * scale, n
-    finally:
-        attention_blocks.set_backend("torch")

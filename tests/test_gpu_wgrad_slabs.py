@@ -1,0 +1,135 @@
+"""-m gpu: deterministic split-K of the weight-gradient products (include/butd_attention.h: c_partial / fold_src).
+
+Round 4's split-K products added their slices into dW / db with device-scope float atomics: 0.67 M of them for one
+288 x 288 gradient in 8 slices, served by the memory side of this part (~25 ns per thousand, a 32-byte request each: the
+2.03x wasted traffic of gemm_kernel) and summed in arrival order.  Now every slice stores its share into its own slab and
+a FOLD problem -- an element-wise rider of the next grouped launch of the same backward function, or of one small launch
+before that function returns -- adds the slabs in slice order: no atomics, bit-reproducible."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu().numpy(), b.double().cpu().numpy()
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-6))
+
+
+SHAPES = [(2048, 288, 288, True), (640, 288, 288, True), (8192, 288, 256, True), (8192, 256, 288, False),
+          (100, 36, 64, True), (257, 132, 100, True), (5000, 64, 8, False), (33, 4, 4, True), (65536, 128, 64, False),
+          (2048, 576, 288, True)]
+
+
+@pytest.mark.parametrize("M,N,K,with_bias", SHAPES)
+def test_slabs_equal_atomics_and_are_bit_reproducible(M, N, K, with_bias):
+    from butd_detr_amd import fused_attention as fa
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(M + N + K)
+    dy, x = torch.randn(M, N, device=dev, generator=g), torch.randn(M, K, device=dev, generator=g)
+    ref_w, ref_b = dy.double().t() @ x.double(), dy.double().sum(0)
+    out = {}
+    for name, slabs in (("atomics", False), ("slabs", True), ("slabs again", True)):
+        prev = fa.set_wgrad_slabs(slabs)
+        try:
+            # slabs STORE (garbage in the targets must not matter); atomics accumulate into zeros
+            dw = torch.full((N, K), float("nan"), device=dev) if slabs else torch.zeros(N, K, device=dev)
+            db = torch.full((N,), float("nan"), device=dev) if slabs else torch.zeros(N, device=dev)
+            prob = fa._wgrad(dy, x, dw, db if with_bias else None, M, N, K)
+            assert (getattr(prob, "_fold", None) is not None) == slabs
+            fa._gemm([prob], dy)               # outside a backward pass: the fold is launched at once
+            assert not fa._pending_folds
+            torch.cuda.synchronize()
+            out[name] = (dw, db)
+        finally:
+            fa.set_wgrad_slabs(prev)
+    for name, (dw, db) in out.items():
+        assert _rel(dw, ref_w) <= 2e-5, name
+        if with_bias:
+            assert _rel(db, ref_b) <= 2e-5, name
+    assert torch.equal(out["slabs"][0], out["slabs again"][0])
+    if with_bias:
+        assert torch.equal(out["slabs"][1], out["slabs again"][1])
+
+
+@pytest.fixture
+def slabs_on():
+    from butd_detr_amd import fused_attention as fa
+    prev = fa.set_wgrad_slabs(True)        # (off by default: measured 0.8 ms slower per step than the float atomics)
+    yield
+    fa.set_wgrad_slabs(prev)
+
+
+def test_strided_gradient_and_operand_effects(slabs_on):
+    """The packed [dq | dk | dv] gradient read in place (rows 3E floats apart) and a BatchNorm + ReLU folded into the
+    activation operand: the slab form of the products the attention / set-abstraction blocks issue."""
+    from butd_detr_amd import fused_attention as fa
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(3)
+    M, E = 2048, 288
+    G, x = torch.randn(M, 3 * E, device=dev, generator=g), torch.randn(M, E, device=dev, generator=g)
+    dw, db = torch.empty(2 * E, E, device=dev), torch.empty(2 * E, device=dev)
+    prob = fa._xwgrad(G, 3 * E, x, dw, db, M, 2 * E, E)
+    assert prob._fold is not None
+    fa._gemm([prob], x)
+    torch.cuda.synchronize()
+    assert _rel(dw, G[:, :2 * E].double().t() @ x.double()) <= 2e-5
+    assert _rel(db, G[:, :2 * E].double().sum(0)) <= 2e-5
+    P, C3, C2 = 65536, 128, 64
+    dz, z2 = torch.randn(P, C3, device=dev, generator=g), torch.randn(P, C2, device=dev, generator=g)
+    sc, sh = torch.rand(C2, device=dev, generator=g) + 0.5, torch.randn(C2, device=dev, generator=g)
+    dw3 = torch.empty(C3, C2, device=dev)
+    fa._gemm([fa._wgrad(dz, z2, dw3, None, P, C3, C2, b_affine=(sc, sh))], dz)
+    torch.cuda.synchronize()
+    assert _rel(dw3, dz.double().t() @ torch.relu(z2 * sc + sh).double()) <= 2e-5
+
+
+def test_riders_and_the_final_flush_inside_a_backward_pass():
+    """A chain of blocks on the fused backend: every weight gradient is complete when its backward function returns
+    (folds ride in the function's later launches, the rest goes out before it returns: AccumulateGrad may clone a
+    gradient at once), equals the atomic path's and is bit-identical between two runs -- dropout on (same counter),
+    LayerNorm fold on."""
+    from butd_detr_amd import attention_blocks as ab, fused_attention as fa
+    from butd_detr_amd.encoder_decoder_layers import BiDecoderLayer
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    layer = BiDecoderLayer(288, 8, dim_feedforward=256, dropout=0.1, butd=True).to(dev).train()
+    B, Q = 4, 256
+    query, vis, lang, det = (torch.randn(B, n, 288, device=dev) for n in (Q, 1024, 80, 132))
+    qpos = torch.rand(B, Q, 6, device=dev)
+    probe = torch.randn(B, Q, 288, device=dev)
+    tmask = torch.zeros(B, 80, dtype=torch.bool, device=dev)
+    tmask[:, 60:] = True
+    ctr = fa.rng_counter(dev)
+
+    def run(slabs):
+        prev = fa.set_wgrad_slabs(slabs)
+        ab.set_backend("hip")
+        try:
+            ctr.fill_(77)
+            fa._site[0] = 0
+            for p in layer.parameters():
+                p.grad = None
+            q = query.clone().requires_grad_(True)
+            out = layer(q, vis, lang, qpos, None, tmask, detected_feats=det, detected_mask=None)
+            (out * probe).sum().backward()
+            assert not fa._pending_folds
+            torch.cuda.synchronize()
+            return {n: p.grad.clone() for n, p in layer.named_parameters() if p.grad is not None}, q.grad.clone()
+        finally:
+            ab.set_backend("torch")
+            fa.set_wgrad_slabs(prev)
+
+    atom, q_atom = run(False)
+    a, q_a = run(True)
+    b, q_b = run(True)
+    assert set(a) == set(atom) and len(a) > 30
+    top = max(float(t.abs().max()) for t in atom.values())
+    for n in a:
+        # (a convolution bias in front of a BatchNorm has a zero gradient: both runs hold rounding noise there)
+        scale = max(float(atom[n].abs().max()), 1e-3 * top)
+        assert float((a[n] - atom[n]).abs().max()) <= 2e-5 * scale, n
+        if not n.startswith("self_posembed"):      # (the Conv + BatchNorm chain's products are fused_mlp's)
+            assert torch.equal(a[n], b[n]), n      # bit-reproducible (the atomic path is not)
+    assert torch.equal(q_a, q_b)
