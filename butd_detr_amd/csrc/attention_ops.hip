@@ -555,8 +555,11 @@ __device__ unsigned long long g_attn_prof[8];
 #define PROF_T(x)
 #endif
 
+#ifndef ATTN_FWD_WAVES       // (ablation hook: minimum waves per SIMD the forward kernels are compiled for)
+#define ATTN_FWD_WAVES 1
+#endif
 template <int NS, int NT, int NG, bool BF = false>
-__global__ __launch_bounds__(kAttnThreads * NG) void attn_fwd_kernel(
+__global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
     float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
@@ -1516,32 +1519,715 @@ int launch_smallk(int B, int H, int Lq, int Lk, int D, const float *q, const flo
   return (int)hipGetLastError();
 }
 
+
+// =====================================================================================================================
+// bf16 operating point (BASELINE configs[3]), round 5: bf16 LDS IMAGES.
+// Round 2's bf16 kernels kept the fp32 images and rounded every operand to bf16 in registers at each use: 57 + 117 vector
+// instructions around the 24 matrix instructions of a forward key tile (v_cvt_pk / v_perm / v_alignbit, the head dimension
+// 36 = 9 per lane group does not cut into quartets), i.e. the kernel was bound by its conversions (96 us where the fp32
+// kernel takes 142 with a 16x slower matrix instruction).  The bf16 matrix instruction DOES run next to vector work
+// (profiles/r05_mfma_valu_interleave.txt), so the win is in the vector count: here every staged element is rounded ONCE,
+// on its way into LDS, the images are laid out in the fragments' own shape (a lane's share of a row: 8 or 16 bf16, zero
+// padded: ds_read_b128; transposed images: four consecutive rows of one head-dim element: one ds_read_b64), and only
+// the probabilities / dS (produced in registers) are rounded per tile (2 v_cvt_pk per 16 x 16).  All products use
+// v_mfma_f32_16x16x32_bf16 (the full-rate shape of this part; round 2 used the K = 16 one, whose matrix pipe time was
+// still 45 % of the kernel: gpurun_out/r05/attn_pmc_bf16.txt): the head dimension 36 is padded to 64 (two instructions
+// per 16 x 16 score tile instead of three), the key / query contractions take two 16-row tiles per instruction (a
+// contraction index may be permuted freely as long as both operands use the same permutation).
+// Global tensors stay fp32; softmax statistics, exponentials and accumulators stay fp32.
+// =====================================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int NS>
+struct ImgH {
+  static constexpr int NSP = (NS + 7) / 8 * 8;    // slots per lane group: whole 8-element operands of the K = 32 instruction
+  static constexpr int NV = NSP / 8;              // ... how many of them
+  static constexpr int LD = 4 * NSP + 8;          // halfs per row (72 for head_dim 36: 144 B, rows 36 banks apart)
+  static __device__ inline int col(int d) {
+    const int g = d / NS;
+    return g * NSP + (d - g * NS);
+  }
+};
+template <int NT>
+struct TImgH {
+  static constexpr int ROWS = NT * 16;
+  static constexpr int LD = 64 + 8;               // halfs per row (144 B)
+};
+template <int NS, int NT>
+struct StageH {
+  using I = ImgH<NS>;
+  static constexpr int kVec = (64 * NS + kAttnThreads - 1) / kAttnThreads;
+  int goff[kVec], row[kVec], koff[kVec][4], toff[kVec];
+  __device__ inline void init(int tid, int D, long E) {
+    const int vpr = D >> 2;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      const int f = tid + j * kAttnThreads;
+      const int r = vpr == NS ? f / NS : f / vpr, c4 = f - r * vpr;
+      const bool ok = r < 64;
+      row[j] = ok ? r : 64;
+      goff[j] = ok ? (int)(r * E) + c4 * 4 : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) koff[j][i] = ok ? r * I::LD + I::col(c4 * 4 + i) : 0;
+      toff[j] = ok ? (c4 * 4) * TImgH<NT>::LD + r : 0;
+    }
+  }
+  __device__ inline void fetch(float4 (&v)[kVec], const float *__restrict__ tile, int nrows) const {
+    if (nrows >= 64) {
+#pragma unroll
+      for (int j = 0; j < kVec; ++j)
+        if (row[j] < 64) v[j] = *reinterpret_cast<const float4 *>(tile + goff[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < kVec; ++j)
+        v[j] = row[j] < nrows ? *reinterpret_cast<const float4 *>(tile + goff[j]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ inline void commit_frag(__bf16 *img, const float4 (&v)[kVec], float scale = 1.f) const {
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+      if (row[j] < 64) {
+        img[koff[j][0]] = (__bf16)(v[j].x * scale); img[koff[j][1]] = (__bf16)(v[j].y * scale);
+        img[koff[j][2]] = (__bf16)(v[j].z * scale); img[koff[j][3]] = (__bf16)(v[j].w * scale);
+      }
+  }
+  __device__ inline void commit_t(__bf16 *timg, const float4 (&v)[kVec]) const {
+    constexpr int LD = TImgH<NT>::LD;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+      if (row[j] < 64) {
+        __bf16 *p = timg + toff[j];
+        p[0] = (__bf16)v[j].x; p[LD] = (__bf16)v[j].y; p[2 * LD] = (__bf16)v[j].z; p[3 * LD] = (__bf16)v[j].w;
+      }
+  }
+};
+// one lane's share of a head-dimension operand: NV x 8 bf16 (d = g * NS + s at slot s, zero beyond NS)
+template <int NS>
+struct HFrag {
+  bf16x8 v[ImgH<NS>::NV];
+};
+// ... of image row `rowp` (= &img[row * LD]), lane group g: NV ds_read_b128
+template <int NS>
+__device__ inline HFrag<NS> frag_h(const __bf16 *rowp, int g) {
+  HFrag<NS> r;
+#pragma unroll
+  for (int m = 0; m < ImgH<NS>::NV; ++m)
+    r.v[m] = *reinterpret_cast<const bf16x8 *>(rowp + g * ImgH<NS>::NSP + 8 * m);
+  return r;
+}
+// ... of a row held in registers (the query / key of this lane), rounded once per kernel
+template <int NS>
+__device__ inline HFrag<NS> make_hfrag(const float (&f)[NS]) {
+  HFrag<NS> r;
+#pragma unroll
+  for (int m = 0; m < ImgH<NS>::NV; ++m)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[m][i] = (8 * m + i < NS) ? (__bf16)f[8 * m + i] : (__bf16)0.f;
+  return r;
+}
+template <int NS>
+__device__ inline f32x4 mma_h(const HFrag<NS> &a, const HFrag<NS> &b, f32x4 acc) {
+#pragma unroll
+  for (int m = 0; m < ImgH<NS>::NV; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v[m], b.v[m], acc, 0, 0, 0);
+  return acc;
+}
+// two 16-row tiles of a contraction over rows (keys / queries) as ONE K = 32 operand: this lane's rows 4g .. 4g+3 of
+// tile t (elements 0..3) and of tile t + 1 (elements 4..7) -- registers (probabilities, dS) ...
+__device__ inline bf16x8 pack8(const f32x4 &p, const f32x4 &q) {
+  return (bf16x8){(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3], (__bf16)q[0], (__bf16)q[1], (__bf16)q[2], (__bf16)q[3]};
+}
+// ... or a transposed image row (`p` -> element 4g of tile t; tile t + 1 is 16 columns on)
+__device__ inline bf16x8 pair8(const __bf16 *p) {
+  const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(p), hi = *reinterpret_cast<const bf16x4 *>(p + 16);
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__device__ inline f32x4 mma32(const bf16x8 &a, const bf16x8 &b, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+}
+template <int N>
+__device__ inline void zero_halfs(__bf16 *p, int tid) {      // N halfs (a multiple of 2), by 32-bit words
+  uint32_t *w = reinterpret_cast<uint32_t *>(p);
+  for (int e = tid; e < N / 2; e += kAttnThreads) w[e] = 0u;
+}
+
+template <int NS, int NT, int NG>
+__global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_kernel(
+    int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
+    float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  using I = ImgH<NS>;
+  using T = TImgH<NT>;
+  constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD;
+  __shared__ __attribute__((aligned(16))) __bf16 KimgG[NG][2][kImg];
+  __shared__ __attribute__((aligned(16))) __bf16 VtG[NG][2][kTimg];
+  __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
+  const int grp = threadIdx.x / kAttnThreads;
+  __bf16(*Kimg)[kImg] = KimgG[grp];
+  __bf16(*Vt)[kTimg] = VtG[grp];
+  float(*Bias)[64] = BiasG[grp];
+  const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const TileId wg = tile_id();
+  const int b = wg.b, h = wg.h;
+  const long E = (long)H * D;
+  const int q0 = wg.t * 64 + wave * 16;
+  const bool live = q0 < Lq;
+  const float *qb = q + (long)b * Lq * E + h * D;
+  const float *kb = k + (long)b * Lk * E + h * D;
+  const float *vb = v + (long)b * Lk * E + h * D;
+  const uint8_t *mb = mask ? mask + (long)b * Lk : nullptr;
+  const bool drop = p_drop > 0.f;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
+  const int qi = q0 + fr;
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+  const uint32_t pair_row = (uint32_t)(((long)b * H + h) * Lq + qi) * LkP + (uint32_t)fg * 2u;
+
+  float qf[NS];
+  load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
+  const HFrag<NS> qF = make_hfrag<NS>(qf);
+  float m = kNegInf, l = 0.f;
+  f32x4 o[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  StageH<NS, NT> sg;
+  sg.init(tid, D, E);
+  // pads of the fragment rows and rows D.. of the transposed images: zero, once (the commits never write them)
+  zero_halfs<2 * kImg>(&Kimg[0][0], tid);
+  zero_halfs<2 * kTimg>(&Vt[0][0], tid);
+  __syncthreads();
+
+  const int iters = ((Lk + 63) / 64 + NG - 1) / NG;
+  float4 kr[StageH<NS, NT>::kVec], vr[StageH<NS, NT>::kVec];
+  float br = 0.f;
+  {
+    const int key0 = grp * 64;
+    sg.fetch(kr, kb + (long)key0 * E, Lk - key0);
+    sg.fetch(vr, vb + (long)key0 * E, Lk - key0);
+    if (tid < 64) br = key_bias(mb, key0 + tid, Lk);
+    sg.commit_frag(Kimg[0], kr);
+    sg.commit_t(Vt[0], vr);
+    if (tid < 64) Bias[0][tid] = br;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int key0 = (it * NG + grp) * 64;
+    const bool more = it + 1 < iters;
+    if (more) {
+      const int nk = key0 + NG * 64;
+      sg.fetch(kr, kb + (long)nk * E, Lk - nk);
+      sg.fetch(vr, vb + (long)nk * E, Lk - nk);
+      if (tid < 64) br = key_bias(mb, nk + tid, Lk);
+    }
+    if (live) {
+      f32x4 st[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        st[t] = mma_h<NS>(frag_h<NS>(&Kimg[cur][(t * 16 + fr) * I::LD], fg), qF, (f32x4){0.f, 0.f, 0.f, 0.f});
+      // the first V operands (keys of tiles 0 and 1) travel while the softmax runs
+      bf16x8 va[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) va[nt] = pair8(&Vt[cur][(nt * 16 + fr) * T::LD + fg * 4]);
+
+      const bool masked_tile = mb != nullptr || key0 + 64 > Lk;
+      float m_new, alpha, m2;
+      if (masked_tile) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 bb = *reinterpret_cast<const float4 *>(&Bias[cur][t * 16 + fg * 4]);
+          st[t][0] += bb.x; st[t][1] += bb.y; st[t][2] += bb.z; st[t][3] += bb.w;
+        }
+      }
+      float tmax = fmaxf(fmaxf(st[0][0], st[0][1]), fmaxf(st[0][2], st[0][3]));
+#pragma unroll
+      for (int t = 1; t < 4; ++t) tmax = fmaxf(tmax, fmaxf(fmaxf(st[t][0], st[t][1]), fmaxf(st[t][2], st[t][3])));
+      tmax = quad_max(tmax);
+      m_new = fmaxf(m, tmax);
+      m2 = m_new * kLog2e;
+      alpha = __builtin_amdgcn_exp2f(__builtin_fmaf(m, kLog2e, -m2));
+      if (masked_tile) {
+        const bool dead = m_new == kNegInf;
+        m2 = dead ? 0.f : m2;
+        alpha = dead ? 1.f : alpha;
+      }
+      float psum = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][i], kLog2e, -m2));
+          psum += p;
+          st[t][i] = p;
+        }
+      if (drop) {
+        const uint32_t pair0 = pair_row + (uint32_t)(key0 >> 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const uint32_t h0 = pair_hash(hkey, pair0 + t * 8), h1 = pair_hash(hkey, pair0 + t * 8 + 1);
+          st[t][0] = (h0 & 0xffffu) >= thr ? st[t][0] : 0.f;
+          st[t][1] = (h0 >> 16) >= thr ? st[t][1] : 0.f;
+          st[t][2] = (h1 & 0xffffu) >= thr ? st[t][2] : 0.f;
+          st[t][3] = (h1 >> 16) >= thr ? st[t][3] : 0.f;
+        }
+      }
+      l = l * alpha + psum;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) o[nt] *= alpha;
+      {   // O^T[n][q] += V^T[n][key] P^T[key][q]: two instructions per head-dim tile and 64 keys
+        bf16x8 vb[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) vb[nt] = pair8(&Vt[cur][(nt * 16 + fr) * T::LD + 32 + fg * 4]);
+        const bf16x8 p01 = pack8(st[0], st[1]), p23 = pack8(st[2], st[3]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = mma32(va[nt], p01, o[nt]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = mma32(vb[nt], p23, o[nt]);
+      }
+      m = m_new;
+    }
+    if (more) {
+      sg.commit_frag(Kimg[cur ^ 1], kr);
+      sg.commit_t(Vt[cur ^ 1], vr);
+      if (tid < 64) Bias[cur ^ 1][tid] = br;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if constexpr (NG == 2) {
+    constexpr int kX = 4 * NT + 2;
+    __shared__ float xch[256 * kX];
+    if (grp == 1 && live) {
+      float *px = xch + (wave * 64 + lane) * kX;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) px[nt * 4 + i] = o[nt][i];
+      px[4 * NT] = m;
+      px[4 * NT + 1] = l;
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    if (live) {
+      const float *px = xch + (wave * 64 + lane) * kX;
+      const float m1 = px[4 * NT], l1 = px[4 * NT + 1];
+      const float m_new = fmaxf(m, m1);
+      const bool dead = m_new == kNegInf;
+      const float a0 = dead ? 1.f : __expf(m - m_new), a1 = dead ? 1.f : __expf(m1 - m_new);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[nt][i] = o[nt][i] * a0 + px[nt * 4 + i] * a1;
+      l = l * a0 + l1 * a1;
+      m = m_new;
+    }
+  }
+  if (live) {
+    l = quad_sum(l);
+    if (qi < Lq) {
+      const float inv_l = (drop ? 1.f / (1.f - p_drop) : 1.f) / l;
+      float *ob = out + ((long)b * Lq + qi) * E + h * D;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = nt * 16 + fg * 4 + i;
+          if (n < D) ob[n] = o[nt][i] * inv_l;
+        }
+      if (fg == 0) lse[((long)b * H + h) * Lq + qi] = m + __logf(l);
+    }
+  }
+}
+
+template <int NS, int NT, int NG>
+__global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_h_kernel(
+    int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
+    const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
+    float *__restrict__ dq, long ldo, float dq_scale,
+    float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  using I = ImgH<NS>;
+  using T = TImgH<NT>;
+  constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD;
+  __shared__ __attribute__((aligned(16))) __bf16 KimgG[NG][2][kImg];
+  __shared__ __attribute__((aligned(16))) __bf16 VimgG[NG][2][kImg];
+  __shared__ __attribute__((aligned(16))) __bf16 KtG[NG][2][kTimg];
+  __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
+  const int grp = threadIdx.x / kAttnThreads;
+  __bf16(*Kimg)[kImg] = KimgG[grp];
+  __bf16(*Vimg)[kImg] = VimgG[grp];
+  __bf16(*Kt)[kTimg] = KtG[grp];
+  float(*Bias)[64] = BiasG[grp];
+  const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const TileId wg = tile_id();
+  const int b = wg.b, h = wg.h;
+  const long E = (long)H * D;
+  const int q0 = wg.t * 64 + wave * 16;
+  const bool live = q0 < Lq;
+  const float *qb = q + (long)b * Lq * E + h * D;
+  const float *gb = dout + (long)b * Lq * E + h * D;
+  const float *kb = k + (long)b * Lk * E + h * D;
+  const float *vb = v + (long)b * Lk * E + h * D;
+  const uint8_t *mb = mask ? mask + (long)b * Lk : nullptr;
+  const bool drop = p_drop > 0.f;
+  const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
+  const int qi = q0 + fr;
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+  const uint32_t pair_row = (uint32_t)(((long)b * H + h) * Lq + qi) * LkP + (uint32_t)fg * 2u;
+
+  float qf[NS], gf[NS];
+  load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
+  load_row_frag<NS>(gf, gb, E, qi, Lq, fg, D);
+  const float my_lse = qi < Lq ? lse[((long)b * H + h) * Lq + qi] : INFINITY;
+  const float lse2 = my_lse * kLog2e;
+  float my_delta;
+  {
+    float of[NS];
+    load_row_frag<NS>(of, out + (long)b * Lq * E + h * D, E, qi, Lq, fg, D);
+    float part = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) part += gf[s] * of[s];
+    my_delta = quad_sum(part);
+    if (grp == 0 && fg == 0 && qi < Lq) delta[((long)b * H + h) * Lq + qi] = my_delta;
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) gf[s] *= inv_keep;
+  const HFrag<NS> qF = make_hfrag<NS>(qf), gF = make_hfrag<NS>(gf);
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  StageH<NS, NT> sg;
+  sg.init(tid, D, E);
+  zero_halfs<2 * kImg>(&Kimg[0][0], tid);
+  zero_halfs<2 * kImg>(&Vimg[0][0], tid);
+  zero_halfs<2 * kTimg>(&Kt[0][0], tid);
+  __syncthreads();
+
+  const int iters = ((Lk + 63) / 64 + NG - 1) / NG;
+  float4 kr[StageH<NS, NT>::kVec], vr[StageH<NS, NT>::kVec];
+  float br = 0.f;
+  {
+    const int key0 = grp * 64;
+    sg.fetch(kr, kb + (long)key0 * E, Lk - key0);
+    sg.fetch(vr, vb + (long)key0 * E, Lk - key0);
+    if (tid < 64) br = key_bias(mb, key0 + tid, Lk);
+    sg.commit_frag(Kimg[0], kr);
+    sg.commit_t(Kt[0], kr);
+    sg.commit_frag(Vimg[0], vr);
+    if (tid < 64) Bias[0][tid] = br;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int key0 = (it * NG + grp) * 64;
+    const bool more = it + 1 < iters;
+    if (more) {
+      const int nk = key0 + NG * 64;
+      sg.fetch(kr, kb + (long)nk * E, Lk - nk);
+      sg.fetch(vr, vb + (long)nk * E, Lk - nk);
+      if (tid < 64) br = key_bias(mb, nk + tid, Lk);
+    }
+    if (live) {
+      const bool masked_tile = mb != nullptr || key0 + 64 > Lk;
+      f32x4 ds[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 st = mma_h<NS>(frag_h<NS>(&Kimg[cur][(t * 16 + fr) * I::LD], fg), qF, zero);   // S^T
+        f32x4 dp = mma_h<NS>(frag_h<NS>(&Vimg[cur][(t * 16 + fr) * I::LD], fg), gF, zero);   // dP^T
+        if (masked_tile) {
+          const float4 bb = *reinterpret_cast<const float4 *>(&Bias[cur][t * 16 + fg * 4]);
+          st[0] += bb.x; st[1] += bb.y; st[2] += bb.z; st[3] += bb.w;
+        }
+        if (drop) {
+          const uint32_t pair0 = pair_row + (uint32_t)(key0 >> 1) + t * 8;
+          const uint32_t h0 = pair_hash(hkey, pair0), h1 = pair_hash(hkey, pair0 + 1);
+          dp[0] = (h0 & 0xffffu) >= thr ? dp[0] : 0.f;
+          dp[1] = (h0 >> 16) >= thr ? dp[1] : 0.f;
+          dp[2] = (h1 & 0xffffu) >= thr ? dp[2] : 0.f;
+          dp[3] = (h1 >> 16) >= thr ? dp[3] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lse2));
+          ds[t][i] = p * (dp[i] - my_delta);
+        }
+      }
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bf16x8 db = pack8(ds[2 * u], ds[2 * u + 1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[nt] = mma32(pair8(&Kt[cur][(nt * 16 + fr) * T::LD + u * 32 + fg * 4]), db, acc[nt]);
+      }
+    }
+    if (more) {
+      sg.commit_frag(Kimg[cur ^ 1], kr);
+      sg.commit_t(Kt[cur ^ 1], kr);
+      sg.commit_frag(Vimg[cur ^ 1], vr);
+      if (tid < 64) Bias[cur ^ 1][tid] = br;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if constexpr (NG == 2) {
+    __shared__ float xch[256 * 4 * NT];
+    if (grp == 1 && live) {
+      float *px = xch + (wave * 64 + lane) * (4 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) px[nt * 4 + i] = acc[nt][i];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    if (live) {
+      const float *px = xch + (wave * 64 + lane) * (4 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[nt][i] += px[nt * 4 + i];
+    }
+  }
+  if (live && qi < Lq) {
+    float *ob = dq + ((long)b * Lq + qi) * ldo + h * D;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int d = nt * 16 + fg * 4 + i;
+        if (d < D) ob[d] = acc[nt][i] * dq_scale;
+      }
+  }
+}
+
+template <int NS, int NT, int NG>
+__global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_h_kernel(
+    int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ dout,
+    const float *__restrict__ lse, const float *__restrict__ delta, float *__restrict__ dk,
+    float *__restrict__ dv, long ldo, float p_drop, uint32_t site,
+    const uint64_t *__restrict__ rng_counter) {
+  using I = ImgH<NS>;
+  using T = TImgH<NT>;
+  constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD;
+  __shared__ __attribute__((aligned(16))) __bf16 QimgG[NG][2][kImg];
+  __shared__ __attribute__((aligned(16))) __bf16 GimgG[NG][2][kImg];
+  __shared__ __attribute__((aligned(16))) __bf16 QtG[NG][2][kTimg];     // Q, dO transposed: the dK^T / dV^T products' operands
+  __shared__ __attribute__((aligned(16))) __bf16 GtG[NG][2][kTimg];
+  __shared__ __attribute__((aligned(16))) float LseG[NG][2][64];
+  __shared__ __attribute__((aligned(16))) float DelG[NG][2][64];
+  const int grp = threadIdx.x / kAttnThreads;
+  __bf16(*Qimg)[kImg] = QimgG[grp];
+  __bf16(*Gimg)[kImg] = GimgG[grp];
+  __bf16(*Qt)[kTimg] = QtG[grp];
+  __bf16(*Gt)[kTimg] = GtG[grp];
+  float(*Lse)[64] = LseG[grp];
+  float(*Del)[64] = DelG[grp];
+  const int tid = threadIdx.x % kAttnThreads, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const TileId wg = tile_id();
+  const int b = wg.b, h = wg.h;
+  const long E = (long)H * D;
+  const int k0 = wg.t * 64 + wave * 16;
+  const bool live = k0 < Lk;
+  const float *qb = q + (long)b * Lq * E + h * D;
+  const float *gb = dout + (long)b * Lq * E + h * D;
+  const float *kb = k + (long)b * Lk * E + h * D;
+  const float *vb = v + (long)b * Lk * E + h * D;
+  const float *lb = lse + ((long)b * H + h) * Lq;
+  const float *db = delta + ((long)b * H + h) * Lq;
+  const bool drop = p_drop > 0.f;
+  const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+  const int ki = k0 + fr;
+  const float my_bias = key_bias(mask ? mask + (long)b * Lk : nullptr, ki, Lk);
+  const bool wave_masked = __any(my_bias != 0.f);
+  const uint32_t pair_col = (uint32_t)(((long)b * H + h) * Lq) * LkP + (uint32_t)(ki >> 1);
+  const uint32_t field_shift = (uint32_t)(ki & 1) * 16u;
+
+  float kf[NS], vf[NS];
+  load_row_frag<NS>(kf, kb, E, ki, Lk, fg, D);
+  load_row_frag<NS>(vf, vb, E, ki, Lk, fg, D);
+#pragma unroll
+  for (int s = 0; s < NS; ++s) vf[s] *= inv_keep;
+  const HFrag<NS> kF = make_hfrag<NS>(kf), vF = make_hfrag<NS>(vf);
+  f32x4 ak[NT], av[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    ak[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    av[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  StageH<NS, NT> sg;
+  sg.init(tid, D, E);
+  zero_halfs<2 * kImg>(&Qimg[0][0], tid);
+  zero_halfs<2 * kImg>(&Gimg[0][0], tid);
+  zero_halfs<2 * kTimg>(&Qt[0][0], tid);
+  zero_halfs<2 * kTimg>(&Gt[0][0], tid);
+  __syncthreads();
+  float4 qr[StageH<NS, NT>::kVec], gr[StageH<NS, NT>::kVec];
+  float sr = 0.f;
+  auto fetch_stats = [&](int qs) {
+    if (tid < 64) sr = (qs + tid < Lq) ? lb[qs + tid] * kLog2e : INFINITY;
+    else if (tid < 128) sr = (qs + tid - 64 < Lq) ? db[qs + tid - 64] : 0.f;
+  };
+  auto commit_stats = [&](int buf) {
+    if (tid < 64) Lse[buf][tid] = sr;
+    else if (tid < 128) Del[buf][tid - 64] = sr;
+  };
+  const int iters = ((Lq + 63) / 64 + NG - 1) / NG;
+  {
+    const int qs = grp * 64;
+    sg.fetch(qr, qb + (long)qs * E, Lq - qs);
+    sg.fetch(gr, gb + (long)qs * E, Lq - qs);
+    fetch_stats(qs);
+    sg.commit_frag(Qimg[0], qr);
+    sg.commit_t(Qt[0], qr);
+    sg.commit_frag(Gimg[0], gr);
+    sg.commit_t(Gt[0], gr);
+    commit_stats(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int qs = (it * NG + grp) * 64;
+    const bool more = it + 1 < iters;
+    if (more) {
+      const int nq = qs + NG * 64;
+      sg.fetch(qr, qb + (long)nq * E, Lq - nq);
+      sg.fetch(gr, gb + (long)nq * E, Lq - nq);
+      fetch_stats(nq);
+    }
+    if (live) {
+      const uint32_t pair_tile = pair_col + (uint32_t)(qs + fg * 4) * LkP;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {       // two 16-query tiles per K = 32 instruction of the transposed products
+        f32x4 pd2[2], ds2[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int t = 2 * u + w;
+          const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+          f32x4 st = mma_h<NS>(frag_h<NS>(&Qimg[cur][(t * 16 + fr) * I::LD], fg), kF, zero);   // S[q][key]
+          f32x4 dp = mma_h<NS>(frag_h<NS>(&Gimg[cur][(t * 16 + fr) * I::LD], fg), vF, zero);   // dP[q][key] / (1 - p)
+          const float4 l4 = *reinterpret_cast<const float4 *>(&Lse[cur][t * 16 + fg * 4]);
+          const float4 d4 = *reinterpret_cast<const float4 *>(&Del[cur][t * 16 + fg * 4]);
+          const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+          if (wave_masked) {
+            st[0] += my_bias; st[1] += my_bias; st[2] += my_bias; st[3] += my_bias;
+          }
+          f32x4 pd, ds;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pd[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lq[i]));
+          if (drop) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t hh = pair_hash(hkey, pair_tile + (uint32_t)(t * 16 + i) * LkP);
+              const bool keep = ((hh >> field_shift) & 0xffffu) >= thr;
+              ds[i] = pd[i] * ((keep ? dp[i] : 0.f) - dq4[i]);
+              pd[i] = keep ? pd[i] : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ds[i] = pd[i] * (dp[i] - dq4[i]);
+          }
+          pd2[w] = pd;
+          ds2[w] = ds;
+        }
+        const bf16x8 pb = pack8(pd2[0], pd2[1]), sb = pack8(ds2[0], ds2[1]);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {   // rows n of dO^T / Q^T at the queries of tiles 2u, 2u + 1
+          av[nt] = mma32(pair8(&Gt[cur][(nt * 16 + fr) * T::LD + u * 32 + fg * 4]), pb, av[nt]);
+          ak[nt] = mma32(pair8(&Qt[cur][(nt * 16 + fr) * T::LD + u * 32 + fg * 4]), sb, ak[nt]);
+        }
+      }
+    }
+    if (more) {
+      sg.commit_frag(Qimg[cur ^ 1], qr);
+      sg.commit_t(Qt[cur ^ 1], qr);
+      sg.commit_frag(Gimg[cur ^ 1], gr);
+      sg.commit_t(Gt[cur ^ 1], gr);
+      commit_stats(cur ^ 1);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) av[nt] *= inv_keep;
+  if constexpr (NG == 2) {
+    __shared__ float xch[256 * 8 * NT];
+    if (grp == 1 && live) {
+      float *px = xch + (wave * 64 + lane) * (8 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          px[nt * 8 + i] = ak[nt][i];
+          px[nt * 8 + 4 + i] = av[nt][i];
+        }
+    }
+    __syncthreads();
+    if (grp == 1) return;
+    if (live) {
+      const float *px = xch + (wave * 64 + lane) * (8 * NT);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ak[nt][i] += px[nt * 8 + i];
+          av[nt][i] += px[nt * 8 + 4 + i];
+        }
+    }
+  }
+  if (live && ki < Lk) {
+    float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
+    float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = nt * 16 + fg * 4 + i;
+        if (n < D) {
+          okp[n] = ak[nt][i];
+          ovp[n] = av[nt][i];
+        }
+      }
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
 // kernels with the key-group parameter: NG = 2 for grids that leave the SIMDs a single wave each;
 // BF: the bf16 matrix steps
-#define ATTN_DISPATCH_GB(KERNEL, split, BFV, grid, ...)                                             \
+#define ATTN_DISPATCH_K(KERNEL, split, grid, ...)                                                   \
   do {                                                                                              \
     if (split) {                                                                                    \
       const dim3 blk(kAttnThreads * 2);                                                             \
-      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);        \
-      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
-      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
-      else hipLaunchKernelGGL((KERNEL<12, 3, 2, BFV>), grid, blk, 0, s, __VA_ARGS__);               \
+      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 2>), grid, blk, 0, s, __VA_ARGS__);             \
+      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 2>), grid, blk, 0, s, __VA_ARGS__);        \
+      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 2>), grid, blk, 0, s, __VA_ARGS__);        \
+      else hipLaunchKernelGGL((KERNEL<12, 3, 2>), grid, blk, 0, s, __VA_ARGS__);                    \
     } else {                                                                                        \
       const dim3 blk(kAttnThreads);                                                                 \
-      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);        \
-      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
-      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);   \
-      else hipLaunchKernelGGL((KERNEL<12, 3, 1, BFV>), grid, blk, 0, s, __VA_ARGS__);               \
+      if (D <= 16) hipLaunchKernelGGL((KERNEL<4, 1, 1>), grid, blk, 0, s, __VA_ARGS__);             \
+      else if (D <= 32) hipLaunchKernelGGL((KERNEL<8, 2, 1>), grid, blk, 0, s, __VA_ARGS__);        \
+      else if (D <= 36) hipLaunchKernelGGL((KERNEL<9, 3, 1>), grid, blk, 0, s, __VA_ARGS__);        \
+      else hipLaunchKernelGGL((KERNEL<12, 3, 1>), grid, blk, 0, s, __VA_ARGS__);                    \
     }                                                                                               \
   } while (0)
-#define ATTN_DISPATCH_G(KERNEL, split, grid, ...)                                                   \
+// (f32: the exact fp32 kernels; bf16: the kernels with bf16 LDS images)
+#define ATTN_DISPATCH_G(KERNEL, KERNEL_H, split, grid, ...)                                         \
   do {                                                                                              \
-    if (bf16) ATTN_DISPATCH_GB(KERNEL, split, true, grid, __VA_ARGS__);                             \
-    else ATTN_DISPATCH_GB(KERNEL, split, false, grid, __VA_ARGS__);                                 \
+    if (bf16) ATTN_DISPATCH_K(KERNEL_H, split, grid, __VA_ARGS__);                                  \
+    else ATTN_DISPATCH_K(KERNEL, split, grid, __VA_ARGS__);                                         \
   } while (0)
 static bool split_keys(const dim3 &g, int Lk) {
   static const int forced = getenv("BUTD_ATTN_SPLIT") ? atoi(getenv("BUTD_ATTN_SPLIT")) : -1;
@@ -1558,7 +2244,7 @@ static int attention_fwd_impl(bool bf16, int B, int H, int Lq, int Lk, int D, co
   if (D <= 0 || D > 48 || (D & 3) || Lk <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid((Lq + 63) / 64, H, B);
-  ATTN_DISPATCH_G(attn_fwd_kernel, split_keys(grid, Lk), grid, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p,
+  ATTN_DISPATCH_G(attn_fwd_kernel, attn_fwd_h_kernel, split_keys(grid, Lk), grid, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p,
                 dropout_site, rng_counter);
   return (int)hipGetLastError();
 }
@@ -1575,9 +2261,9 @@ static int attention_bwd_impl(bool bf16, int B, int H, int Lq, int Lk, int D, co
   if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const dim3 gq((Lq + 63) / 64, H, B), gk((Lk + 63) / 64, H, B);
-  ATTN_DISPATCH_G(attn_bwd_dq_kernel, split_keys(gq, Lk), gq, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq,
+  ATTN_DISPATCH_G(attn_bwd_dq_kernel, attn_bwd_dq_h_kernel, split_keys(gq, Lk), gq, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, delta, dq,
                 ld_dq, dq_scale, dropout_p, dropout_site, rng_counter);
-  ATTN_DISPATCH_G(attn_bwd_dkv_kernel, split_keys(gk, Lq), gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
+  ATTN_DISPATCH_G(attn_bwd_dkv_kernel, attn_bwd_dkv_h_kernel, split_keys(gk, Lq), gk, H, Lq, Lk, D, q, k, v, key_padding_mask, dout, lse, delta,
                 dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter);
   return (int)hipGetLastError();
 }

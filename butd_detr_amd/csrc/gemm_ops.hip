@@ -1100,9 +1100,12 @@ void choose(const butd_gemm_problem *problems, const int *index, int count, bool
     cfg = max_k_acc >= 32768 ? kCfg64x64 : (max_m_plain > 0 && max_m_plain <= 2048) ? kCfg32x32 : kCfg96x32;
     return;
   }
+  static const int abl = getenv("BUTD_GEMM_CHOOSE") ? atoi(getenv("BUTD_GEMM_CHOOSE")) : 3;   // (A/B hook of the round-5 rules)
   if (max_m_plain >= 32768) {
+    // round 5 (accumulators in VGPRs, profiles/r05_gemm_tiles.txt): 64 x 64 one-ahead beats 128 x 64 on every tall
+    // set-abstraction forward product (1M x 128 x 64: 276 vs 308 us, 256k x 128 x 128: 114 vs 125, 64k x 256 x 128: 60 vs 65)
     pipe = 0;
-    cfg = kCfg128x64;
+    cfg = (abl & 1) ? kCfg64x64 : kCfg128x64;
     return;
   }
   if (tiles32 <= 1200 || (count > 1 && tiles32 <= 3000 && max_m_plain > 2048)) {
@@ -1114,6 +1117,7 @@ void choose(const butd_gemm_problem *problems, const int *index, int count, bool
   } else {
     pipe = 2;
     cfg = tiles32 <= 3000 ? kCfg32x96 : kCfg64x96;
+    if (tiles32 > 3000 && (abl & 2)) pipe = 0;   // round 5: 3 x (8192 x 288 x 288): 51.4 us one-ahead, 53.6 two-ahead
   }
 }
 

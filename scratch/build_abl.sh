@@ -8,7 +8,7 @@ OBJS=$(ls butd_detr_amd/lib/obj/*.o | grep -v /$U.o)
 args=("$@")
 for ((i=0; i<${#args[@]}; i+=2)); do
   t=${args[i]}; f=${args[i+1]}
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude $f -c butd_detr_amd/csrc/$U.hip -o scratch/exp/${U}_abl_$t.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -mllvm -amdgpu-mfma-vgpr-form=1 $f -c butd_detr_amd/csrc/$U.hip -o scratch/exp/${U}_abl_$t.o &
 done
 wait
 for ((i=0; i<${#args[@]}; i+=2)); do

@@ -22,15 +22,43 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_fused_gradients_against_float64_truth():
+def _fusions(on):
+    """The epilogue / ride-along fusions of rounds 4 and 5 on (the product) or off (round 3's launches: atomic LayerNorm
+    backward, separate mask / statistics passes, dense set-abstraction backward, pairwise gradient sums)."""
+    from butd_detr_amd import fan_out, fused_attention as fa, fused_mlp, fused_sa
+    prev = (fa.set_ln_fold(on), fused_mlp.set_fuse_stats(on), fan_out.set_enabled(on),
+            [f[0] for f in (fused_sa._LAST_LIN, fused_sa._LAST_FWD, fused_sa._FIRST_LIN, fused_sa._MID_FIRST, fused_sa._NO_Z1,
+                            fused_sa._FUSE_STATS, fused_sa._GATHER)])
+    for f in (fused_sa._LAST_LIN, fused_sa._LAST_FWD, fused_sa._FIRST_LIN, fused_sa._MID_FIRST, fused_sa._NO_Z1,
+              fused_sa._FUSE_STATS, fused_sa._GATHER):
+        f[0] = on
+    return prev
+
+
+def _restore_fusions(prev):
+    from butd_detr_amd import fan_out, fused_attention as fa, fused_mlp, fused_sa
+    fa.set_ln_fold(prev[0]); fused_mlp.set_fuse_stats(prev[1]); fan_out.set_enabled(prev[2])
+    for f, v in zip((fused_sa._LAST_LIN, fused_sa._LAST_FWD, fused_sa._FIRST_LIN, fused_sa._MID_FIRST, fused_sa._NO_Z1,
+                     fused_sa._FUSE_STATS, fused_sa._GATHER), prev[3]):
+        f[0] = v
+
+
+@pytest.mark.parametrize("fusions", [True, False], ids=["product path", "round-3 launches (every later fusion off)"])
+def test_fused_gradients_against_float64_truth(fusions):
+    """``fusions=False`` (round 4's review): the same budget holds with the LayerNorm fold, the in-epilogue mask / statistics
+    passes, the linear set-abstraction backward and the one-launch gradient fan-in switched OFF -- the gate / arg-max
+    flips are a property of the fp32 forward's rounding, not of those fusions (a lifetime bug in one of them would
+    show up as a difference between the two runs' budgets)."""
     from butd_detr_amd import attention_blocks, pointnet2_ext, pointnet2_utils
     from tests import grad_truth
+    prev = _fusions(fusions)
     try:
         grad_truth.FIXED.clear()
         truth, _ = grad_truth.run("cpu", torch.float64, "torch")
         torch32, _ = grad_truth.run("cuda", torch.float32, "torch")
         hip32, ep = grad_truth.run("cuda", torch.float32, "hip")
     finally:
+        _restore_fusions(prev)
         attention_blocks.set_backend("torch")
         pointnet2_utils._ext = pointnet2_ext
     top = max(float(t.abs().max()) for t in truth.values())
