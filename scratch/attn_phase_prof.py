@@ -1,6 +1,6 @@
 """Where the cycles of a key tile of attn_fwd_kernel go (one wave: wave 0 of workgroup 0), from s_memtime stamps compiled in
 with -DATTN_PROF (scratch/build_abl.sh attention_ops prof "-DATTN_PROF"; BUTD_HIP_LIB=scratch/exp/libabl_prof.so).
-s_memtime ticks at 100 MHz on this part: 1 tick = 24 shader cycles at 2.4 GHz."""
+The unit is what s_memtime counts on this part while the wave runs (compare the columns with each other, not with wall time)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -30,5 +30,5 @@ for (B, Lq, Lk) in ((2, 1024, 1024), (4, 1024, 1024), (6, 1024, 1024), (8, 1024,
         tiles = buf[5]
         per = [buf[i] / tiles for i in range(5)]
         print(f"B={B} {Lq}x{Lk} p={p}: {e0.elapsed_time(e1) / 10 * 1e3:7.1f} us/launch, workgroups {B * H * ((Lq + 63) // 64)}; "
-              f"per key tile of one wave (s_memtime ticks; x24 = cycles at 2.4 GHz): "
-              + ", ".join(f"{n} {t:.1f}" for n, t in zip(names, per)) + f"; total {sum(per):.1f} ticks = {sum(per) * 24:.0f} cycles")
+              f"per key tile of one wave (s_memtime ticks): "
+              + ", ".join(f"{n} {t:.1f}" for n, t in zip(names, per)) + f"; total {sum(per):.1f} ticks")

@@ -28,7 +28,7 @@ def tg(fn, reps=5):
     return e0.elapsed_time(e1) / reps * 1e3
 with torch.no_grad():
     one = lambda: fused_sa.sa_fused_eval(m, xyz, new_xyz, idx, pc, 3)
-    os.environ["BUTD_SA_FUSED_EVAL"] = "0"
+    fused_sa._FUSED_EVAL[0] = False
     many = lambda: fused_sa.sa_mlp_pool(m, xyz, new_xyz, idx, pc, 3)
     a, b = one()[0], many()[0]
     print("max |one - many| / scale:", float((a - b).abs().max() / b.abs().max()))

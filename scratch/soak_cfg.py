@@ -37,4 +37,4 @@ for it in range(int(os.environ.get("STEPS", "90"))):
         torch.cuda.empty_cache()                     # cached free blocks of the default pool go back to the driver:
         print("empty_cache released MB:", (before - torch.cuda.memory_reserved()) / 1e6)   # a baked-in stale address would fault
     if it % 10 == 9: losses.append(round(float(loss), 2))
-print(kw, {k: os.environ.get(k) for k in ("BUTD_ENCODER_FORK", "BUTD_TEXT_OVERLAP")}, losses)
+print(kw, {"BUTD_AB": os.environ.get("BUTD_AB")}, losses)
