@@ -233,8 +233,7 @@ namespace {
 // 576 addresses; two rows per wave halve them there: 21.2 -> 18.4 us.  Folding private copies with a
 // last-workgroup ticket needs an agent-scope release per workgroup = an L2 write-back each: 159 us.)
 inline int ln_bwd_rows_per_wave(int rows) {
-  static const int forced = getenv("BUTD_LN_RPW") ? atoi(getenv("BUTD_LN_RPW")) : 0;
-  return forced ? forced : (rows >= 65536 ? kLnRowsPerWave : rows >= 8192 ? 2 : 1);
+  return rows >= 65536 ? kLnRowsPerWave : rows >= 8192 ? 2 : 1;      // (measured: profiles/r04_small_kernels.txt)
 }
 inline int ln_bwd_blocks(int rows) {
   const int rows_per_block = (kLnBwdThreads / 64) * ln_bwd_rows_per_wave(rows);
@@ -2230,10 +2229,7 @@ extern "C" {
     else ATTN_DISPATCH_K(KERNEL, split, grid, __VA_ARGS__);                                         \
   } while (0)
 static bool split_keys(const dim3 &g, int Lk) {
-  static const int forced = getenv("BUTD_ATTN_SPLIT") ? atoi(getenv("BUTD_ATTN_SPLIT")) : -1;
-  if (forced >= 0) return forced != 0 && Lk > 64;
-  static const long limit = getenv("BUTD_ATTN_SPLIT_MAX") ? atol(getenv("BUTD_ATTN_SPLIT_MAX")) : 512;
-  return (long)g.x * g.y * g.z <= limit && Lk >= 128;
+  return (long)g.x * g.y * g.z <= 512 && Lk >= 128;     // (<= 512 workgroups: round 1's measurement, -23 % on 256 x 1024)
 }
 
 static int attention_fwd_impl(bool bf16, int B, int H, int Lq, int Lk, int D, const float *q, const float *k,

@@ -1100,12 +1100,11 @@ void choose(const butd_gemm_problem *problems, const int *index, int count, bool
     cfg = max_k_acc >= 32768 ? kCfg64x64 : (max_m_plain > 0 && max_m_plain <= 2048) ? kCfg32x32 : kCfg96x32;
     return;
   }
-  static const int abl = getenv("BUTD_GEMM_CHOOSE") ? atoi(getenv("BUTD_GEMM_CHOOSE")) : 3;   // (A/B hook of the round-5 rules)
   if (max_m_plain >= 32768) {
     // round 5 (accumulators in VGPRs, profiles/r05_gemm_tiles.txt): 64 x 64 one-ahead beats 128 x 64 on every tall
     // set-abstraction forward product (1M x 128 x 64: 276 vs 308 us, 256k x 128 x 128: 114 vs 125, 64k x 256 x 128: 60 vs 65)
     pipe = 0;
-    cfg = (abl & 1) ? kCfg64x64 : kCfg128x64;
+    cfg = kCfg64x64;                    // (A/B in the step: profiles/r05_gemm_choose.txt)
     return;
   }
   if (tiles32 <= 1200 || (count > 1 && tiles32 <= 3000 && max_m_plain > 2048)) {
@@ -1117,7 +1116,7 @@ void choose(const butd_gemm_problem *problems, const int *index, int count, bool
   } else {
     pipe = 2;
     cfg = tiles32 <= 3000 ? kCfg32x96 : kCfg64x96;
-    if (tiles32 > 3000 && (abl & 2)) pipe = 0;   // round 5: 3 x (8192 x 288 x 288): 51.4 us one-ahead, 53.6 two-ahead
+    if (tiles32 > 3000) pipe = 0;   // round 5: 3 x (8192 x 288 x 288): 51.4 us one-ahead, 53.6 two-ahead
   }
 }
 

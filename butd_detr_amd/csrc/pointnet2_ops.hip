@@ -453,20 +453,6 @@ int butd_furthest_point_sampling(int b, int n, int m, const float *dataset, floa
   const int log2bs = ilog2_floor((unsigned)butd_opt_n_threads(n));
 #define FPS_LAUNCH(T, P) \
   hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), 0, s, n, m, log2bs, dataset, idxs)
-  const char *cfg = getenv("BUTD_FPS_CFG");  // tuning hook: "threads,ppt"
-  int ct = 0, cp = 0;
-  if (cfg && sscanf(cfg, "%d,%d", &ct, &cp) == 2 && (long long)ct * cp >= n) {
-    if (ct == 256 && cp == 2) FPS_LAUNCH(256, 2);
-    else if (ct == 256 && cp == 4) FPS_LAUNCH(256, 4);
-    else if (ct == 256 && cp == 8) FPS_LAUNCH(256, 8);
-    else if (ct == 512 && cp == 1) FPS_LAUNCH(512, 1);
-    else if (ct == 512 && cp == 2) FPS_LAUNCH(512, 2);
-    else if (ct == 512 && cp == 4) FPS_LAUNCH(512, 4);
-    else if (ct == 1024 && cp == 1) FPS_LAUNCH(1024, 1);
-    else if (ct == 1024 && cp == 2) FPS_LAUNCH(1024, 2);
-    else return (int)hipErrorInvalidValue;
-    return launch_status();
-  }
   if (n <= 256) FPS_LAUNCH(256, 1);
   else if (n <= 512) FPS_LAUNCH(256, 2);
   else if (n <= 1024) FPS_LAUNCH(256, 4);

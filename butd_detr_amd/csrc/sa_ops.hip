@@ -61,8 +61,6 @@ constexpr int kChunkRowsSmall = 64;  // otherwise: four times the workgroups (a 
                                      // workgroups of 256 rows, and every thread then walks 16-64 rows of
                                      // dependent load -> store: 100 us where the data takes 25)
 inline int chunk_rows(long P) {
-  static const int forced = getenv("BUTD_SA_CHUNK") ? atoi(getenv("BUTD_SA_CHUNK")) : 0;  // tuning hook
-  if (forced > 0 && P >= (1L << 19)) return forced;
   return P >= (1L << 19) ? kChunkRows : kChunkRowsSmall;
 }
 
