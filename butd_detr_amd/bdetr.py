@@ -227,10 +227,17 @@ class BeaUTyDETR(nn.Module):
         end_points.update(text_out)
         return end_points
 
-    def _generate_queries(self, xyz, features, end_points, features_pm=None):
+    def _generate_queries(self, xyz, features, end_points, features_pm=None, forced_seeds=None):
+        """bdetr.py:238-249.  ``forced_seeds`` (B, num_queries) int (``inputs["query_seed_inds"]``, not in the reference):
+        the seeds to use as queries instead of the top-k by objectness -- a parity hook: it pins the one discrete choice
+        of the forward pass, so that a reduced-precision run can be compared query by query with the reference's vectors
+        (tests/test_gpu_golden_modules.py)."""
         logits = self.points_obj_cls(features, features_pm=features_pm)
         end_points["seeds_obj_cls_logits"] = logits
-        sample_inds = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int()
+        if forced_seeds is not None:
+            sample_inds = forced_seeds.to(device=logits.device, dtype=torch.int32).contiguous()
+        else:
+            sample_inds = torch.topk(torch.sigmoid(logits).squeeze(1), self.num_queries)[1].int()
         xyz, features, sample_inds = self.gsample_module(xyz, features, sample_inds)
         end_points["query_points_xyz"] = xyz
         end_points["query_points_feature"] = features
@@ -295,7 +302,8 @@ class BeaUTyDETR(nn.Module):
             from .rowwise import l2_normalize
             end_points["proj_tokens"] = l2_normalize(self._proj_mlp(self.contrastive_align_projection_text, text_feats))
 
-        end_points = self._generate_queries(points_xyz, points_features, end_points, features_pm=vis)
+        end_points = self._generate_queries(points_xyz, points_features, end_points, features_pm=vis,
+                                            forced_seeds=inputs.get("query_seed_inds"))
         cluster_feature = end_points["query_points_feature"]     # (B, d, Q)
         cluster_xyz = end_points["query_points_xyz"]             # (B, Q, 3)
         if (self._fused(cluster_feature) and self.decoder_query_proj.in_channels % 4 == 0

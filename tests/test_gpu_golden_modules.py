@@ -384,3 +384,53 @@ def test_bdetr_train_six_layers_golden_bf16(bf16_mode):
     # 0.70 - 0.83, encoder and embeddings > 0.9.  The bound is a direction check (gross breakage gives ~0).
     bad = {k: c for k, c in cosines.items() if c <= 0.6}
     assert not bad, bad
+
+
+def test_bdetr_train_six_layers_golden_bf16_same_queries(bf16_mode):
+    """The parity check proper of configs[3]'s arithmetic (round 4's review: the test above is a direction check because ~9 %
+    of its queries are other seeds than the reference's).  Here the one discrete choice of the forward pass is pinned:
+    the model is handed the reference's 82 query seeds (``inputs["query_seed_inds"]``), so every per-query output and every
+    gradient is comparable with the reference's fp32 vectors and the only difference left is bf16 rounding of the
+    attention / FFN operands: head outputs within 0.4 of the tensor's scale (max) and 3.5e-2 (mean), gradient cosines >= 0.88 (observed 0.90 .. 0.998)."""
+    import warnings
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from tests.golden.cases import PREFIXES, TRAIN_GRAD_KEYS, by_seed, train_loss, zero_dropout
+    g = load("bdetr_4096_train6.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=82,
+                           num_decoder_layers=6, self_position_embedding="loc_learned",
+                           contrastive_align_loss=True, butd=True, pointnet_ckpt=None, self_attend=True,
+                           text_encoder_factory=text_stub.factory,
+                           class_embeddings_path="/nonexistent/class_embeddings3d.npy")
+    weights.fill_(model, seed=15, skip_prefixes=("text_encoder.",))
+    zero_dropout(model.cuda().train())
+    inputs = cuda(bdetr_inputs())
+    inputs["query_seed_inds"] = torch.from_numpy(g["query_seeds_sorted"].astype(np.int32)).cuda()
+    ep = model(inputs)
+    train_loss(ep).backward()
+    np.testing.assert_array_equal(ep["seed_inds"].cpu().numpy(), g["seed_inds"])
+    np.testing.assert_array_equal(torch.sort(ep["query_points_sample_inds"].long(), dim=1)[0].cpu().numpy(), g["query_seeds_sorted"])
+
+    def close(t, ref, name):
+        a = t.detach().float().cpu().numpy()
+        err = np.abs(a - ref) / max(float(np.abs(ref).max()), 1e-6)
+        _BF16_OBSERVED[f"train6_same/{name}"] = [float(err.max()), float(err.mean())]
+        # (observed, bf16-image kernels: max 0.04 .. 0.26 -- the BatchNorm1d of a head normalises over 2 x 82 samples and
+        #  amplifies single elements -- mean 0.004 .. 0.023; gpurun_out/bf16_golden_errors.json)
+        assert err.max() <= 0.4 and err.mean() <= 3.5e-2, (name, float(err.max()), float(err.mean()))
+
+    close(by_seed(ep, ep["last_proj_queries"]), g["last_proj_queries"], "last_proj_queries")
+    for pre in PREFIXES:
+        close(by_seed(ep, ep[pre + "center"]), g[pre + "center"], pre + "center")
+        close(by_seed(ep, ep[pre + "pred_size"]), g[pre + "pred_size"], pre + "pred_size")
+        close(by_seed(ep, ep[pre + "sem_cls_scores"])[:, :, :32], g[pre + "sem_cls_scores_head"], pre + "cls")
+    p = dict(model.named_parameters())
+    cosines = {}
+    for k in TRAIN_GRAD_KEYS:
+        a, b = p[k].grad.detach().double().cpu().numpy().ravel(), g["g_" + k].astype(np.float64).ravel()
+        cosines[k] = float((a * b).sum() / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-30))
+        _BF16_OBSERVED[f"train6_same/cos:{k}"] = [cosines[k]]
+    # observed: 0.903 (SA1's first convolution, behind everything) .. 0.998; the direction check above sees 0.70 .. 0.86
+    bad = {k: c for k, c in cosines.items() if c < 0.88}
+    assert not bad, bad
