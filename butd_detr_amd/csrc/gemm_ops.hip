@@ -1020,7 +1020,7 @@ struct TileCfg {
 // the menu (every entry is instantiated for FAST / PIPE 2, FAST / PIPE 0 and generic)
 constexpr TileCfg kMenu[] = {{32, 32}, {64, 64}, {32, 96}, {64, 96}, {96, 32}, {128, 64}, {128, 96}};
 constexpr int kMenuSize = sizeof(kMenu) / sizeof(kMenu[0]);
-constexpr int kCfg32x32 = 0, kCfg64x64 = 1, kCfg32x96 = 2, kCfg64x96 = 3, kCfg96x32 = 4, kCfg128x64 = 5;
+constexpr int kCfg32x32 = 0, kCfg64x64 = 1, kCfg32x96 = 2, kCfg64x96 = 3, kCfg96x32 = 4;   // (5 = 128 x 64, 6 = 128 x 96: forced tiles only)
 
 int g_forced_cfg = -1;   // butd_gemm_set_tile(): tuning hook
 

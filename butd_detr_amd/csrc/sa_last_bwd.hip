@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
     const float *__restrict__ W2, const float *__restrict__ W1, float *__restrict__ ws_w, float *__restrict__ ws,
     long ws_stride) {
   static_assert(C == 64, "SA1: 64-wide layers");
-  constexpr int KP = 8, NW = 4;
+  constexpr int KP = 8;
   constexpr int ST = C + 36, SO = C + 4, KG = C / 16, GN = C / 16, QN = C / 4, RP = 256 / QN, NP = kRows / RP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float *Dt = lds;                   // [64][ST]  dZ2
