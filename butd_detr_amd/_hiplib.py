@@ -104,6 +104,8 @@ SA_SYMBOLS = {
     "butd_sa_first_bwd_scratch": (_c_int, [_c_long, _c_int, _c_int, _P, _P]),
     "butd_sa_first_bwd": (_c_int, [_c_long, _c_int, _c_int] + [_P] * 13 + [_P]),
     "butd_sa_first_two_fwd": (_c_int, [_c_long, _c_int, _c_int] + [_P] * 11 + [_c_int, _P]),
+    "butd_sa_mid_wide_bwd_scratch": (_c_int, [_c_long, _c_int, _P, _P]),
+    "butd_sa_mid_wide_bwd": (_c_int, [_c_long, _c_int] + [_P] * 21 + [_P]),
     "butd_sa_mid_first_bwd_scratch": (_c_int, [_c_long, _c_int, _c_int, _P, _P]),
     "butd_sa_mid_first_bwd": (_c_int, [_c_long, _c_int, _c_int] + [_P] * 23 + [_P]),
     "butd_sa_last_bwd_scratch": (_c_int, [_c_long, _c_int, _c_int, _P, _P]),

@@ -1289,6 +1289,164 @@ __global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
   }
 }
 
+// ------------------------------------ SA2-4 (128-wide layers): layer 2's backward in one pass, only the gated gradient written
+// Round 5.  The levels with an input gradient keep layer 1's backward as it is, but everything between layer 2's gated
+// gradient g2 (what butd_sa_last_bwd wrote) and layer 1's gated gradient g1 happens per 32-row block without a dense dZ2 or
+// an ungated dH1 in memory:
+//   dZ2 = gamma2 rstd2 (g2 - S1_2/P - zhat2 S2_2/P)      -> LDS tile
+//   H1  = relu(scale1 Z1 + shift1)                         -> LDS tile
+//   dW2 += dZ2^T H1                                        (matrix cores; a wave owns 16 channels x all 128 columns)
+//   dH1 = dZ2 W2 -> g1 = dH1 gated by layer 1's ReLU       (matrix cores; W2^T fragments in registers) -> WRITTEN
+//   S1_1 += g1, S2_1 += g1 zhat1                           (per thread, per-workgroup partials, summed in double)
+// Replaces butd_sa_dz_mid (reads g2, Z2, writes dZ2), the layer's weight- / input-gradient product pair (reads dZ2 twice
+// and Z1 twice, writes dH1) and the statistics in that product's epilogue: 958 MB -> 537 MB at SA2, B = 8.
+// 512 threads = 8 waves (a wave: 16 of the 128 columns / channels), 59 KB of LDS: two workgroups per CU.
+constexpr int kRowsW = 32;
+template <int C>
+__global__ __launch_bounds__(512, 2) void sa_mid_wide_kernel(
+    long P, long nblk, const float *__restrict__ G2, const float *__restrict__ Z2, const float *__restrict__ Z1,
+    const float *__restrict__ gamma2, const float *__restrict__ sc2, const float *__restrict__ sh2,
+    const float *__restrict__ mean2, const float *__restrict__ rstd2, const double *__restrict__ S1_2,
+    const double *__restrict__ S2_2, const float *__restrict__ sc1, const float *__restrict__ sh1,
+    const float *__restrict__ mean1, const float *__restrict__ rstd1, const float *__restrict__ W2,
+    float *__restrict__ G1, float *__restrict__ ws_w, float *__restrict__ ws) {
+  static_assert(C == 128, "SA2-4: 128-wide layers");
+  constexpr int NT = 512;
+  constexpr int ST = C + 36, SO = C + 4, KG = C / 16, GN = C / 16, QN = C / 4, RP = NT / QN, NP = kRowsW / RP;
+  static_assert(NP * RP == kRowsW, "row passes");
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *Dt = lds;                    // [32][ST]  dZ2
+  float *Ht = Dt + kRowsW * ST;       // [32][ST]  H1
+  float *Os = Ht + kRowsW * ST;       // [32][SO]  dH1
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lm = lane & 15, lq = lane >> 4;
+  const int q = tid % QN, rsub = tid / QN;
+  const int n0 = wave * 16;
+  // dH1^T tile = W2^T (A operand: rows = columns k of W2, contraction over c) x dZ2^T
+  f4 areg[KG];
+#pragma unroll
+  for (int g = 0; g < KG; ++g)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) areg[g][i] = W2[(long)(16 * g + 4 * lq + i) * C + n0 + lm];
+  f4 wacc[GN];                        // dW2 rows n0 .. n0 + 16 (channels c of layer 2), all 128 columns
+#pragma unroll
+  for (int n = 0; n < GN; ++n) wacc[n] = f4{0.f, 0.f, 0.f, 0.f};
+  const double invP = 1.0 / (double)P;
+  f4 ga, s2c, h2c, mu2, rs2, a1, a2, s1c, h1c, mu1, rs1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int c = 4 * q + e;
+    ga[e] = gamma2[c]; s2c[e] = sc2[c]; h2c[e] = sh2[c]; mu2[e] = mean2[c]; rs2[e] = rstd2[c];
+    a1[e] = (float)(S1_2[c] * invP); a2[e] = (float)(S2_2[c] * invP);
+    s1c[e] = sc1[c]; h1c[e] = sh1[c]; mu1[e] = mean1[c]; rs1[e] = rstd1[c];
+  }
+  f4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f4 gn[NP], z2n[NP], z1n[NP];
+  auto fetch = [&](long b) {
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const long p = b * kRowsW + rsub + ps * RP;
+      const bool in = p < P;
+      gn[ps] = in ? *reinterpret_cast<const f4 *>(G2 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+      z2n[ps] = in ? *reinterpret_cast<const f4 *>(Z2 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+      z1n[ps] = in ? *reinterpret_cast<const f4 *>(Z1 + p * C + 4 * q) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  long blk = blockIdx.x;
+  if (blk < nblk) fetch(blk);
+  for (; blk < nblk; blk += gridDim.x) {
+    f4 zk1[NP];
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const bool in = blk * kRowsW + r < P;
+      zk1[ps] = z1n[ps];
+      f4 d, h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float gv = s2c[e] * z2n[ps][e] + h2c[e] > 0.f ? gn[ps][e] : 0.f;      // (idempotent: g2 arrives gated)
+        d[e] = in ? ga[e] * rs2[e] * (gv - a1[e] - (z2n[ps][e] - mu2[e]) * rs2[e] * a2[e]) : 0.f;
+        h[e] = in ? fmaxf(s1c[e] * zk1[ps][e] + h1c[e], 0.f) : 0.f;
+      }
+      *reinterpret_cast<f4 *>(Dt + r * ST + 4 * q) = d;
+      *reinterpret_cast<f4 *>(Ht + r * ST + 4 * q) = h;
+    }
+    __syncthreads();
+    if (blk + gridDim.x < nblk) fetch(blk + gridDim.x);
+    // ---- dH1^T tiles (16 columns of this wave x 16 rows) -> LDS
+#pragma unroll
+    for (int rt = 0; rt < kRowsW / 16; ++rt) {
+      f4 oacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < KG; ++g) {
+        const f4 dv = *reinterpret_cast<const f4 *>(Dt + (16 * rt + lm) * ST + 16 * g + 4 * lq);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc = mfma4(areg[g][i], dv[i], oacc);
+      }
+      *reinterpret_cast<f4 *>(Os + (16 * rt + lm) * SO + n0 + 4 * lq) = oacc;
+    }
+    // ---- dW2[c = n0 + .., k] += sum_r dZ2[r, c] H1[r, k]
+#pragma unroll 4
+    for (int s = 0; s < kRowsW / 4; ++s) {
+      const float a = Dt[(4 * s + lq) * ST + n0 + lm];
+      const float *hrow = Ht + (4 * s + lq) * ST + lm;
+      float b[GN];
+#pragma unroll
+      for (int n = 0; n < GN; ++n) b[n] = hrow[16 * n];
+#pragma unroll
+      for (int n = 0; n < GN; ++n) wacc[n] = mfma4(a, b[n], wacc[n]);
+    }
+    __syncthreads();
+    // ---- g1 = dH1 gated -> memory; layer-1 sums
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) {
+      const int r = rsub + ps * RP;
+      const long p = blk * kRowsW + r;
+      if (p < P) {
+        const f4 o = *reinterpret_cast<const f4 *>(Os + r * SO + 4 * q);
+        f4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          g[e] = s1c[e] * zk1[ps][e] + h1c[e] > 0.f ? o[e] : 0.f;
+          s1[e] += g[e];
+          s2[e] += g[e] * (zk1[ps][e] - mu1[e]) * rs1[e];
+        }
+        *reinterpret_cast<f4 *>(G1 + p * C + 4 * q) = g;
+      }
+    }
+    // (the next block's tiles are written after this point only by threads that have left the loop body above; its
+    //  matrix phase starts behind the next barrier: Os is not touched before every thread is through its gating pass)
+  }
+  __syncthreads();
+  // ---- partials: dW2 (C x C) per workgroup, then [S1 | S2] (2 C)
+  float *ow = ws_w + (long)blockIdx.x * C * C;
+#pragma unroll
+  for (int n = 0; n < GN; ++n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ow[(long)(n0 + 4 * lq + i) * C + 16 * n + lm] = wacc[n][i];
+  float *red = lds;                                  // [RP][2][C] = 16 * 256 floats
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[(rsub * 2 + 0) * C + 4 * q + e] = s1[e];
+    red[(rsub * 2 + 1) * C + 4 * q + e] = s2[e];
+  }
+  __syncthreads();
+  float *out = ws + (long)blockIdx.x * 2 * C;
+  for (int i = tid; i < 2 * C; i += NT) {
+    float a = 0.f;
+    for (int t = 0; t < RP; ++t) a += red[(long)t * 2 * C + i];
+    out[i] = a;
+  }
+}
+
+// tot = [dW2 C*C | S1 C | S2 C] (double) -> dW2 (float), S1 / S2 (double: what butd_sa_dz_mid reads)
+__global__ void sa_mid_wide_finish_kernel(int C, const double *__restrict__ tot, float *__restrict__ dW2,
+                                          double *__restrict__ S1, double *__restrict__ S2) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x, nw = (long)C * C;
+  if (i < nw) dW2[i] = (float)tot[i];
+  else if (i < nw + C) S1[i - nw] = tot[i];
+  else if (i < nw + 2 * C) S2[i - nw - C] = tot[i];
+}
+
 __global__ void sa_d2f_kernel(const double *__restrict__ src, float *__restrict__ dst, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];
@@ -1447,6 +1605,38 @@ int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z
                      grid, ws_d);
   hipLaunchKernelGGL(sa_d2f_kernel, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, st, ws_d, dW2, nw);
   hipLaunchKernelGGL(sa_first_dw_kernel<8>, dim3(C), dim3(Kp), 0, st, C, P, Kp, W1, scale1, rstd1, ws_d + nw, dW1, S1_1, S2_1);
+  return (int)hipGetLastError();
+}
+
+int butd_sa_mid_wide_bwd_scratch(long P, int C, long *ws_floats, long *ws_doubles) {
+  if (P <= 0 || !ws_floats || !ws_doubles || C != 128) return (int)hipErrorInvalidValue;
+  *ws_floats = 512L * ((long)C * C + 2 * C);
+  *ws_doubles = (long)C * C + 2 * C;
+  return 0;
+}
+
+int butd_sa_mid_wide_bwd(long P, int C, const float *G2, const float *Z2, const float *Z1, const float *gamma2,
+                         const float *scale2, const float *shift2, const float *mean2, const float *rstd2,
+                         const double *S1_2, const double *S2_2, const float *scale1, const float *shift1,
+                         const float *mean1, const float *rstd1, const float *W2, float *G1, float *dW2, double *S1_1,
+                         double *S2_1, float *ws_f, double *ws_d, butd_stream_t stream) {
+  if (P <= 0) return 0;
+  if (C != 128 || !G2 || !Z2 || !Z1 || !G1 || !dW2 || !ws_f || !ws_d) return (int)hipErrorInvalidValue;
+  constexpr size_t lds = (size_t)(2 * kRowsW * (128 + 36) + kRowsW * (128 + 4)) * sizeof(float);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_mid_wide_kernel<128>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return (int)attr;
+  hipStream_t st = (hipStream_t)stream;
+  const long nblk = (P + kRowsW - 1) / kRowsW;
+  const int grid = (int)(nblk < 512 ? nblk : 512);
+  const long nw = (long)C * C, per = 2L * C;
+  float *ws_w = ws_f, *ws_p = ws_f + (long)grid * nw;
+  hipLaunchKernelGGL((sa_mid_wide_kernel<128>), dim3(grid), dim3(512), lds, st, P, nblk, G2, Z2, Z1, gamma2, scale2, shift2, mean2,
+                     rstd2, S1_2, S2_2, scale1, shift1, mean1, rstd1, W2, G1, ws_w, ws_p);
+  hipLaunchKernelGGL(sa_last_reduce_kernel, dim3((unsigned)((nw + per + 15) / 16)), dim3(256), 0, st, ws_w, nw, grid, ws_p, per,
+                     grid, ws_d);
+  hipLaunchKernelGGL(sa_mid_wide_finish_kernel, dim3((unsigned)((nw + per + 255) / 256)), dim3(256), 0, st, C, ws_d, dW2, S1_1,
+                     S2_1);
   return (int)hipGetLastError();
 }
 

@@ -37,6 +37,8 @@ _LAST_LIN = [switches.flag("sa_last_bwd", True)]
 _LAST_FWD = [switches.flag("sa_last_fwd", True)]      # ... and the forward that does not write Z3
 _FIRST_LIN = [switches.flag("sa_first_bwd", True)]     # ... and the first layer's, where no input gradient is wanted
 _MID_FIRST = [switches.flag("sa_mid_bwd", True)]       # ... with layer 2's backward in the same pass (64-wide levels)
+# SA2-4 (128-wide layers, input gradient wanted): layer 2's backward in one pass that writes only layer 1's gated gradient
+_MID_WIDE = [switches.flag("sa_mid_wide", True)]
 # ... and SA1's forward never writing Z1 (butd_sa_first_two_fwd): layer 1's BatchNorm sums from the 8 x 8 moments of X, z1
 # formed on the matrix cores by layer 2's kernel and, with the same instructions, by the backward.  23.64 -> 23.44 ms
 # (4 x 60 steps), and the SA1 gradients move 4-5x CLOSER to a float64 run (closer than stock torch's):
@@ -105,6 +107,17 @@ def _mid_scratch(P, C, Kp):
         nf, nd = ctypes.c_long(0), ctypes.c_long(0)
         _hiplib.check(_lib.butd_sa_mid_first_bwd_scratch(P, C, Kp, ctypes.byref(nf), ctypes.byref(nd)),
                       "butd_sa_mid_first_bwd_scratch")
+        _scratch_sizes[key] = (nf.value, nd.value)
+    return _scratch_sizes[key]
+
+
+def _wide_scratch(P, C):
+    key = ("wide", P, C)
+    if key not in _scratch_sizes:
+        import ctypes
+        nf, nd = ctypes.c_long(0), ctypes.c_long(0)
+        _hiplib.check(_lib.butd_sa_mid_wide_bwd_scratch(P, C, ctypes.byref(nf), ctypes.byref(nd)),
+                      "butd_sa_mid_wide_bwd_scratch")
         _scratch_sizes[key] = (nf.value, nd.value)
     return _scratch_sizes[key]
 
@@ -305,20 +318,33 @@ class _SAMlpPool(torch.autograd.Function):
                   rstd(0).data_ptr(), w2.data_ptr(), w1.data_ptr(), dW2.data_ptr(), dW1.data_ptr(), S[0, 0].data_ptr(),
                   S[0, 1].data_ptr(), ws_f.data_ptr(), ws_d.data_ptr())
             return _SAMlpPool._finish(ctx, S, dW1, dW2, dW3, None, (C1, C2, C3), (s1, s2, s3), Cin)
-        _call("butd_sa_dz_mid", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), g2.data_ptr(), scale(1).data_ptr(),
-              shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
-        dZ2 = dH2
         dH1 = torch.empty((P, C1), device=dev)
+        mid_wide = lin and training and not first_lin and C1 == 128 and C2 == 128 and _MID_WIDE[0]
+        if mid_wide:
+            # layer 2 in one pass over (g2, Z2, Z1): dW2, layer 1's GATED gradient and its sums; no dZ2, no ungated dH1
+            nf, nd = _wide_scratch(P, C2)
+            ws_f = torch.empty(nf, device=dev)
+            ws_d = torch.empty(nd, dtype=torch.float64, device=dev)
+            _call("butd_sa_mid_wide_bwd", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), Z1.data_ptr(), g2.data_ptr(),
+                  scale(1).data_ptr(), shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(),
+                  S[1, 1].data_ptr(), scale(0).data_ptr(), shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(),
+                  w2.data_ptr(), dH1.data_ptr(), dW2.data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), ws_f.data_ptr(),
+                  ws_d.data_ptr())
+        else:
+            _call("butd_sa_dz_mid", X, P, C2, dH2.data_ptr(), Z2.data_ptr(), g2.data_ptr(), scale(1).data_ptr(),
+                  shift(1).data_ptr(), mean(1).data_ptr(), rstd(1).data_ptr(), S[1, 0].data_ptr(), S[1, 1].data_ptr(), tr)
+        dZ2 = dH2
         # butd_sa_mask_stats of layer 1 as an epilogue mode of the product that writes dH1 (butd_gemm_problem.c_bn_*); the
         # 10^3..10^4 row tiles of a column add into 16 private copies of the sums (col_slots), folded below
-        fuse1 = _FUSE_STATS[0] and not first_lin and C1 % 4 == 0
+        fuse1 = _FUSE_STATS[0] and not first_lin and C1 % 4 == 0 and not mid_wide
         if fuse1:
             Sx = zeros((16, 2, C1), dtype=torch.float64, device=dev)
             bn1 = dict(c_bn=(Z1, aff[0, 0], aff.stride(1), 0.0, 0), col_stats=(Sx[0, 0], Sx[0, 1]), col_slots=(16, 2 * C1))
         else:
             bn1 = {}
-        _gemm([_wgrad(dZ2, Z1, dW2, None, P, C2, C1, b_affine=(scale(0), shift(0))),
-               _dgrad(dZ2, w2, dH1, P, C2, C1, **bn1)], X)
+        if not mid_wide:
+            _gemm([_wgrad(dZ2, Z1, dW2, None, P, C2, C1, b_affine=(scale(0), shift(0))),
+                   _dgrad(dZ2, w2, dH1, P, C2, C1, **bn1)], X)
         # ---- layer 1
         if first_lin:
             # no input gradient wanted (SA1): the sums and dW1 from one pass over (dH1, Z1, X) -- no dZ1, no thin product
@@ -331,7 +357,7 @@ class _SAMlpPool(torch.autograd.Function):
         else:
             if fuse1:
                 S[0, :, :C1] = Sx.sum(0)
-            else:
+            elif not mid_wide:
                 _call("butd_sa_mask_stats", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), scale(0).data_ptr(),
                       shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
                       S[0, 1].data_ptr())

@@ -20,6 +20,7 @@ KNOWN = {
     "sa_last_fwd":      "set abstraction: last layer forward without writing Z3 (fused_sa)",
     "sa_first_bwd":     "SA1: first layer backward without dZ1 (fused_sa)",
     "sa_mid_bwd":       "SA1: layer 2 + layer 1 backward in one pass (fused_sa)",
+    "sa_mid_wide":      "SA2-4: layer 2 backward in one pass, only the gated gradient written (fused_sa)",
     "sa_no_z1":         "SA1: forward without Z1 (fused_sa)",
     "sa_fuse_stats":    "SA2-4: layer 1's gate + BatchNorm sums in the epilogue of the product that writes dH1 (fused_sa)",
     "sa_gather":        "SA2-4: feature gradient as a gather over inverted neighbour lists (fused_sa)",

@@ -138,6 +138,20 @@ int butd_sa_mid_first_bwd(long P, int C, int Kp, const float *G2, const float *Z
                           float *dW2, float *dW1, double *S1_1, double *S2_1, float *ws_f, double *ws_d,
                           butd_stream_t stream);
 
+/* SA2-4 (128-wide layers, training mode): layer 2's backward from layer 2's gated gradient G2 (what butd_sa_last_bwd wrote)
+ * in ONE pass over (G2, Z2, Z1) per 32-row block (round 5):
+ *   dZ2 = gamma2 rstd2 (g2 - S1_2/P - zhat2 S2_2/P);  dW2 (C x C, written) = dZ2^T relu(scale1 Z1 + shift1);
+ *   G1 (P x C, written) = (dZ2 W2) gated by layer 1's ReLU;  S1_1[c] = sum G1, S2_1[c] = sum G1 zhat1 (written, double).
+ * Replaces butd_sa_dz_mid + the layer's weight- / input-gradient product pair with its statistics epilogue (no dense dZ2,
+ * no ungated dH1: 958 MB -> 537 MB at SA2, B = 8); layer 1's backward (butd_sa_dz_mid on G1 + its product pair) follows
+ * unchanged.  Partials per workgroup, summed in double: no atomics.  C = 128. */
+int butd_sa_mid_wide_bwd_scratch(long P, int C, long *ws_floats, long *ws_doubles);
+int butd_sa_mid_wide_bwd(long P, int C, const float *G2, const float *Z2, const float *Z1, const float *gamma2,
+                         const float *scale2, const float *shift2, const float *mean2, const float *rstd2,
+                         const double *S1_2, const double *S2_2, const float *scale1, const float *shift1,
+                         const float *mean1, const float *rstd1, const float *W2, float *G1, float *dW2, double *S1_1,
+                         double *S2_1, float *ws_f, double *ws_d, butd_stream_t stream);
+
 /* SA1's first two layers FORWARD without writing Z1 (C = 64, 8 grouped input columns).  Z1 = X W1^T is linear in X, so
  * layer 1's BatchNorm sums follow from the moments of X:  phase 0 -- mom (72 doubles, zero on entry) <- [column sums of X |
  * X^T X], sum1[c] = W1[c] . SX, sumsq1[c] = W1[c]^T XX W1[c] (written; the caller then runs butd_sa_bn_finalize as usual).

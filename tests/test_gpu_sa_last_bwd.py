@@ -241,3 +241,31 @@ def test_feature_gradient_as_gather_equals_scatter(cfg):
     per = flat.shape[1]
     assert np.array_equal(owner, (lst // per) * cfg["N"] + flat.reshape(-1)[lst])
     assert all((np.diff(lst[a:b]) > 0).all() for a, b in zip(start[:-1], start[1:]))      # ascending slices: unique result
+
+
+@pytest.mark.parametrize("cfg", CFGS[1:4] + [dict(B=8, N=2048, C=128, npoint=1024, radius=0.4, nsample=32, mlp=[128, 128, 128, 256])])
+def test_wide_middle_layer_in_one_pass(cfg):
+    """SA2-4 (128-wide layers, input gradient wanted): butd_sa_mid_wide_bwd (dW2, layer 1's gated gradient and its sums
+    from one pass over (g2, Z2, Z1)) vs butd_sa_dz_mid + the product pair with the statistics epilogue: same forward, so
+    every gradient agrees to fp32 rounding; the one-pass kernel has no atomics: bit-reproducible dW2."""
+    from butd_detr_amd import fused_sa
+    m = _module(cfg, 41)
+    torch.manual_seed(43)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    outs = {}
+    for key, wide in (("pair", False), ("wide", True), ("wide again", True)):
+        prev = fused_sa._MID_WIDE[0]
+        fused_sa._MID_WIDE[0] = wide
+        try:
+            state = {k: v.clone() for k, v in m.state_dict().items()}
+            outs[key] = _run(m, xyz, feats, probe, linear=True)
+            m.load_state_dict(state)
+        finally:
+            fused_sa._MID_WIDE[0] = prev
+    assert torch.equal(outs["wide"][0], outs["pair"][0])
+    assert _err(outs["wide"][1], outs["pair"][1]) < 2e-5, _err(outs["wide"][1], outs["pair"][1])
+    for n in outs["pair"][2]:
+        assert _err(outs["wide"][2][n], outs["pair"][2][n]) < 2e-5, (n, _err(outs["wide"][2][n], outs["pair"][2][n]))
+    assert torch.equal(outs["wide"][2]["mlp_module.layer1.conv.weight"], outs["wide again"][2]["mlp_module.layer1.conv.weight"])
