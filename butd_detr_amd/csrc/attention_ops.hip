@@ -1519,6 +1519,286 @@ int launch_smallk(int B, int H, int Lq, int Lk, int D, const float *q, const flo
 }
 
 
+// ---- single-pass backward for LONG KEY SETS (round 5) ---------------------------------------------------------------
+// The two-kernel backward computes S and dP once per kernel (72 matrix instructions per 16 x 16 score tile: 30 in the dQ
+// walk, 42 in the dK / dV walk) and runs the exponentials and the dropout hashes twice; matrix and vector instructions
+// do not overlap on this part (profiles/r05_mfma_valu_interleave.txt), so both counts are time.  Here a workgroup of
+// EIGHT waves owns a chunk of 256 keys (a wave: two 16-key sub-tiles, K / V fragments, K^T operands and the dK / dV
+// accumulators in registers for the whole kernel) and walks the queries 64 at a time through LDS images of Q and dO
+// exactly like attn_bwd_dkv_kernel; per score tile it also transposes dS through a wave-private 16 x 16 LDS patch
+// (attn_bwd_smallk_kernel's step) and forms dQ^T += K^T dS^T over its 32 keys: 54 matrix instructions per tile, one
+// softmax pass.  The eight waves' dQ shares of a query tile are summed through LDS (one 64 x D tile per wave, read
+// back linearly) and stored to the chunk's slab of a workspace; a small element-wise launch adds the Lk / 256 slabs
+// in chunk order and applies dq_scale: no atomics, bit-reproducible.
+// delta = rowsum(dO o O) is formed while the query tile is staged (the staged dO float4s times the same float4s of O; a
+// row's quartets sit in 16 consecutive lanes: four xor-shuffles), so no kernel has to run before this one.
+constexpr int kLongWaves = 8;
+constexpr int kLongSub = 2;                                   // 16-key sub-tiles per wave
+constexpr int kLongChunk = kLongWaves * kLongSub * 16;        // keys per workgroup
+constexpr int kLongThreads = kLongWaves * 64;
+
+template <int NS>
+constexpr int longk_lds_floats(int D) {
+  return 2 * 64 * Img<NS>::LD + 64 + 64 + kLongWaves * 16 * 20 + kLongWaves * 64 * D;
+}
+
+template <int NS, int NT>
+__global__ __launch_bounds__(kLongThreads) void attn_bwd_longk_kernel(
+    int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
+    const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ dq_out, long ld_dq,
+    long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, float p_drop,
+    uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  using I = Img<NS>;
+  constexpr int LDX = 20;
+  constexpr int kVec = 64 * 16 / kLongThreads;         // staging: 16 lanes per query row, the first D / 4 hold a quartet
+  static_assert(NS <= 16, "a row's quartets fit 16 lanes");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float(*Qimg)[I::LD] = reinterpret_cast<float(*)[I::LD]>(smem);
+  float(*Gimg)[I::LD] = Qimg + 64;
+  float *Lse = reinterpret_cast<float *>(Gimg + 64);   // [64]  lse * log2(e)
+  float *Del = Lse + 64;                               // [64]
+  float *X = Del + 64;                                 // [waves][16][LDX]
+  float *Red = X + kLongWaves * 16 * LDX;              // [waves][64][D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const TileId wg = tile_id();
+  const int b = wg.b, h = wg.h;
+  const long E = (long)H * D;
+  const int k0 = wg.t * kLongChunk + wave * (kLongSub * 16);
+  const float *qb = q + (long)b * Lq * E + h * D;
+  const float *gb = dout + (long)b * Lq * E + h * D;
+  const float *ob = out + (long)b * Lq * E + h * D;
+  const float *kb = k + (long)b * Lk * E + h * D;
+  const float *vb = v + (long)b * Lk * E + h * D;
+  const float *lb = lse + ((long)b * H + h) * Lq;
+  float *dqb = dq_out + (long)wg.t * chunk_stride + (long)b * Lq * ld_dq + h * D;
+  const bool drop = p_drop > 0.f;
+  const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+  const uint32_t field_shift = (uint32_t)(fr & 1) * 16u;      // (k0 and the sub-tile offsets are even)
+
+  // ---- this wave's keys: fragments (S, dP), transposed operands (dQ), masks; all for the whole kernel
+  float kf[kLongSub][NS], vf[kLongSub][NS], my_bias[kLongSub];
+  f32x4 ka[kLongSub][NT];
+  uint32_t pair_col[kLongSub];
+  bool any_bias = false;
+#pragma unroll
+  for (int j = 0; j < kLongSub; ++j) {
+    const int ki = k0 + j * 16 + fr;
+    load_row_frag<NS>(kf[j], kb, E, ki, Lk, fg, D);
+    load_row_frag<NS>(vf[j], vb, E, ki, Lk, fg, D);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vf[j][s] *= inv_keep;        // dP is only ever used as keep * dP / (1 - p)
+    my_bias[j] = key_bias(mask ? mask + (long)b * Lk : nullptr, ki, Lk);
+    any_bias = any_bias || my_bias[j] != 0.f;
+    pair_col[j] = (uint32_t)(((long)b * H + h) * Lq) * LkP + (uint32_t)(ki >> 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int key = k0 + j * 16 + fg * 4 + s, d = nt * 16 + fr;
+        ka[j][nt][s] = (key < Lk && d < D) ? kb[(long)key * E + d] : 0.f;
+      }
+  }
+  const bool wave_masked = __any(any_bias);
+  constexpr int kZeroSlot = 4 * I::NSP;
+  int ncol[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = nt * 16 + fr;
+    ncol[nt] = n < D ? I::col(n) : kZeroSlot;
+  }
+  f32x4 ak[kLongSub][NT], av[kLongSub][NT];
+#pragma unroll
+  for (int j = 0; j < kLongSub; ++j)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      ak[j][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      av[j][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  if (tid < 64) {
+    Qimg[tid][kZeroSlot] = 0.f;
+    Gimg[tid][kZeroSlot] = 0.f;
+  }
+
+  // ---- staging of a 64-query tile: this thread's float4s (row, column quartet) and where they land in the images
+  const int vpr = D >> 2;
+  int s_row[kVec], s_goff[kVec], s_koff[kVec][4];      // (s_row = 64: this lane holds no quartet)
+#pragma unroll
+  for (int j = 0; j < kVec; ++j) {
+    const int f = tid + j * kLongThreads;
+    const int r = f >> 4, c4 = f & 15;
+    const bool ok = c4 < vpr;
+    s_row[j] = ok ? r : 64;
+    s_goff[j] = ok ? (int)(r * E) + c4 * 4 : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_koff[j][i] = ok ? r * I::LD + I::col(c4 * 4 + i) : 0;
+  }
+  float4 qr[kVec], gr[kVec], orr[kVec];
+  float sr = 0.f;
+  auto fetch = [&](int qs) {
+    const int nrows = Lq - qs;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      const bool ok = s_row[j] < 64 && s_row[j] < nrows;
+      const long o = (long)qs * E + s_goff[j];
+      qr[j] = ok ? *reinterpret_cast<const float4 *>(qb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gr[j] = ok ? *reinterpret_cast<const float4 *>(gb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      orr[j] = ok ? *reinterpret_cast<const float4 *>(ob + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 64) sr = (qs + tid < Lq) ? lb[qs + tid] * kLog2e : INFINITY;     // +inf -> probability 0
+  };
+  auto commit = [&]() {
+    float *qi_ = &Qimg[0][0], *gi_ = &Gimg[0][0];
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      // (lanes without a quartet fetched zeros)
+      float part = gr[j].x * orr[j].x + gr[j].y * orr[j].y + gr[j].z * orr[j].z + gr[j].w * orr[j].w;
+      part += __shfl_xor(part, 8, 16);
+      part += __shfl_xor(part, 4, 16);
+      part += __shfl_xor(part, 2, 16);
+      part += __shfl_xor(part, 1, 16);
+      if (s_row[j] < 64) {
+        qi_[s_koff[j][0]] = qr[j].x; qi_[s_koff[j][1]] = qr[j].y; qi_[s_koff[j][2]] = qr[j].z; qi_[s_koff[j][3]] = qr[j].w;
+        gi_[s_koff[j][0]] = gr[j].x; gi_[s_koff[j][1]] = gr[j].y; gi_[s_koff[j][2]] = gr[j].z; gi_[s_koff[j][3]] = gr[j].w;
+      }
+      if (((tid + j * kLongThreads) & 15) == 0) Del[(tid + j * kLongThreads) >> 4] = part;
+    }
+    if (tid < 64) Lse[tid] = sr;
+  };
+  const int iters = (Lq + 63) / 64;
+  fetch(0);
+  __syncthreads();                                 // the zero slots are in place
+  commit();
+  __syncthreads();
+  float *Xw = X + wave * 16 * LDX, *Rw = Red + wave * 64 * D;
+  for (int it = 0; it < iters; ++it) {
+    const int qs = it * 64;
+    const bool more = it + 1 < iters;
+#pragma unroll 1
+    for (int t = 0; t < 4; ++t) {
+      float qf[NS], gf[NS];
+      I::frag(qf, Qimg, t * 16 + fr, fg);
+      I::frag(gf, Gimg, t * 16 + fr, fg);
+      // operands of the transposed products for these 16 queries
+      float ga[4][NT], qa[4][NT];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float *grow = Gimg[t * 16 + fg * 4 + s];
+        const float *qrow = Qimg[t * 16 + fg * 4 + s];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          ga[s][nt] = grow[ncol[nt]];
+          qa[s][nt] = qrow[ncol[nt]];
+        }
+      }
+      const float4 l4 = *reinterpret_cast<const float4 *>(Lse + t * 16 + fg * 4);
+      const float4 d4 = *reinterpret_cast<const float4 *>(Del + t * 16 + fg * 4);
+      const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+      f32x4 dqa[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dqa[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < kLongSub; ++j) {
+        f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          st = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[s], kf[j][s], st, 0, 0, 0);   // S[q][key]
+          dp = __builtin_amdgcn_mfma_f32_16x16x4f32(gf[s], vf[j][s], dp, 0, 0, 0);   // dP[q][key] / (1 - p)
+        }
+        if (wave_masked) {
+          st[0] += my_bias[j]; st[1] += my_bias[j]; st[2] += my_bias[j]; st[3] += my_bias[j];
+        }
+        f32x4 pd, ds;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pd[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lq[i]));
+        if (drop) {
+          const uint32_t pair_tile = pair_col[j] + (uint32_t)(qs + t * 16 + fg * 4) * LkP;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t hh = pair_hash(hkey, pair_tile + (uint32_t)i * LkP);
+            const bool keep = ((hh >> field_shift) & 0xffffu) >= thr;
+            ds[i] = pd[i] * ((keep ? dp[i] : 0.f) - dl[i]);
+            pd[i] = keep ? pd[i] : 0.f;                      // the 1/(1-p) of dV is applied once, at the end
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) ds[i] = pd[i] * (dp[i] - dl[i]);
+        }
+        // dS -> dS^T through the wave's LDS patch: element (q = 4g + i, key = fr) written, (q = fr, keys 4g ..) read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xw[(fg * 4 + i) * LDX + fr] = ds[i];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            av[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][nt], pd[s], av[j][nt], 0, 0, 0);
+            ak[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s][nt], ds[s], ak[j][nt], 0, 0, 0);
+          }
+        __builtin_amdgcn_wave_barrier();
+        const f32x4 dst = *reinterpret_cast<const f32x4 *>(Xw + fr * LDX + fg * 4);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            dqa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j][nt][s], dst[s], dqa[nt], 0, 0, 0);   // dQ^T[d][q]
+      }
+      // this wave's share of dQ for the 16 queries: row = query, D floats
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        if (nt * 16 + fg * 4 < D) *reinterpret_cast<f32x4 *>(Rw + (t * 16 + fr) * D + nt * 16 + fg * 4) = dqa[nt];
+    }
+    if (more) fetch(qs + 64);                      // in flight across the barrier and the sum below
+    __syncthreads();
+    // ---- dQ of the query tile: sum of the eight shares, linear in LDS
+    for (int e = tid; e < 64 * vpr; e += kLongThreads) {
+      f32x4 a = *reinterpret_cast<const f32x4 *>(Red + 4 * e);
+#pragma unroll
+      for (int w = 1; w < kLongWaves; ++w) a += *reinterpret_cast<const f32x4 *>(Red + w * 64 * D + 4 * e);
+      const int r = e / vpr, c4 = e - r * vpr;
+      if (qs + r < Lq) *reinterpret_cast<f32x4 *>(dqb + (long)(qs + r) * ld_dq + 4 * c4) = a * dq_scale;
+    }
+    if (more) commit();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < kLongSub; ++j) {
+    const int ki = k0 + j * 16 + fr;
+    if (ki < Lk) {
+      float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
+      float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = nt * 16 + fg * 4 + i;
+          if (n < D) {
+            okp[n] = ak[j][nt][i];
+            ovp[n] = av[j][nt][i] * inv_keep;
+          }
+        }
+    }
+  }
+}
+
+// dq = dq_scale * (slab 0 + slab 1 + ...), in this order; rows x E floats per slab, dq rows ld floats apart
+__global__ __launch_bounds__(256) void attn_dq_fold_kernel(int chunks, long rows, int E4, const float *__restrict__ ws,
+                                                           long chunk_stride, float *__restrict__ dq, long ld,
+                                                           float scale) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * E4) return;
+  const long r = i / E4;
+  const int c = (int)(i - r * E4);
+  f32x4 a = *reinterpret_cast<const f32x4 *>(ws + 4 * i);
+  for (int ch = 1; ch < chunks; ++ch) a += *reinterpret_cast<const f32x4 *>(ws + ch * chunk_stride + 4 * i);
+  *reinterpret_cast<f32x4 *>(dq + r * ld + 4 * c) = a * scale;
+}
+
+
 // =====================================================================================================================
 // bf16 operating point (BASELINE configs[3]), round 5: bf16 LDS IMAGES.
 // Round 2's bf16 kernels kept the fp32 images and rounded every operand to bf16 in registers at each use: 57 + 117 vector
@@ -2291,6 +2571,42 @@ int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const flo
   else SMALLK(12, 3);
 #undef SMALLK
   return 0;
+}
+
+/* (include/butd_attention.h) */
+long butd_attention_bwd_long_keys_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
+  if (D != 36 || Lk < 2 * kLongChunk) return -1;
+  if (ld_dq == 0) ld_dq = (long)H * D;
+  if (ld_dq & 3) return -1;
+  const long chunks = (Lk + kLongChunk - 1) / kLongChunk;
+  return chunks * B * Lq * H * D;
+}
+
+int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                 const float *v, const uint8_t *key_padding_mask, const float *out,
+                                 const float *dout, const float *lse, float *dq, float *dk, float *dv, long ld_dq,
+                                 long ld_dkv, float dq_scale, float dropout_p, uint32_t dropout_site,
+                                 const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream) {
+  const long need = butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ld_dq);
+  if (need < 0 || !ws || ws_floats < need) return (int)hipErrorInvalidValue;
+  if (ld_dq == 0) ld_dq = (long)H * D;
+  if (ld_dkv == 0) ld_dkv = (long)H * D;
+  if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t bytes = sizeof(float) * (size_t)longk_lds_floats<9>(36);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_longk_kernel<9, 3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return (int)attr;
+  const int chunks = (Lk + kLongChunk - 1) / kLongChunk;
+  const long E = (long)H * D, chunk_stride = (long)B * Lq * E;
+  hipLaunchKernelGGL((attn_bwd_longk_kernel<9, 3>), dim3(chunks, H, B), dim3(kLongThreads), bytes, s, H, Lq, Lk, D, q, k, v,
+                     key_padding_mask, out, dout, lse, ws, E, chunk_stride, 1.f, dk, dv, ld_dkv, dropout_p, dropout_site,
+                     rng_counter);
+  const long rows = (long)B * Lq, n4 = rows * (E / 4);
+  hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, chunks, rows, (int)(E / 4), ws,
+                     chunk_stride, dq, ld_dq, dq_scale);
+  return (int)hipGetLastError();
 }
 
 int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,

@@ -162,6 +162,43 @@ def _short_key_bwd(Lq, Lk):
     return Lq >= 512 and Lk <= 80
 
 
+_long_keys = [switches.flag("attn_long_keys", True)]
+
+
+def set_long_keys(flag):
+    """A/B switch (BUTD_AB=attn_long_keys=0): the one-pass backward for key sets of >= 512 rows."""
+    prev, _long_keys[0] = _long_keys[0], bool(flag)
+    return prev
+
+
+def _attention_backward(B, H, Lq, Lk, D, q, k, v, mask, att, d_att, lse, dq_ptr, dk_ptr, dv_ptr, ld_dq, ld_dkv, scale,
+                        p_attn, site_attn, short, ref):
+    """dq, dk, dv of one attention call (include/butd_attention.h): the one-pass kernel for long key sets (every score
+    tile once; dQ through per-chunk slabs), the short-key kernel where the caller chose it (dk / dv zero-filled), else
+    the two-kernel walk."""
+    dev = ref.device
+    ctr = rng_counter(dev).data_ptr()
+    with torch.cuda.device(dev):
+        need = -1
+        # a workgroup per 256 keys and head: serves where that fills the part (measured, 8 x 8 heads: 1024 x 1024
+        # 442 -> 306 us, 256 x 1024 135 -> 97, 80 x 1024 102 -> 63; 1024 x 512 -- 128 workgroups -- 254 -> 300)
+        if _long_keys[0] and not short and not _compute_bf16[0] and ((Lk + 255) // 256) * H * B >= 192:
+            need = int(_lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ld_dq))
+        if need >= 0:
+            ws = torch.empty(max(need, 1), device=dev)
+            err = _lib.butd_attention_bwd_long_keys(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask),
+                                                    att.data_ptr(), d_att.data_ptr(), lse.data_ptr(), dq_ptr, dk_ptr,
+                                                    dv_ptr, ld_dq, ld_dkv, scale, p_attn, site_attn, ctr, ws.data_ptr(),
+                                                    need, _stream(ref))
+        else:
+            delta = torch.empty((B, H, Lq), device=dev)
+            err = (_lib.butd_attention_bwd_short_keys if short else _attn_bwd())(
+                B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask), att.data_ptr(), d_att.data_ptr(),
+                lse.data_ptr(), delta.data_ptr(), dq_ptr, dk_ptr, dv_ptr, ld_dq, ld_dkv, scale, p_attn, site_attn, ctr,
+                _stream(ref))
+    _hiplib.check(err, "butd_attention_bwd")
+
+
 def get_compute_dtype():
     return "bf16" if _compute_bf16[0] else "f32"
 
@@ -440,15 +477,8 @@ class _AttentionBlock(torch.autograd.Function):
         dq = torch.empty((B, Lq, E), device=dev)
         dk = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
         dv = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
-        delta = torch.empty((B, H, Lq), device=dev)
-        with torch.cuda.device(dev):
-            err = (_lib.butd_attention_bwd_short_keys if short else _attn_bwd())(
-                                          B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                          _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
-                                          delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
-                                          0, 0, 1.0, p_attn, site_attn, rng_counter(dev).data_ptr(),
-                                          _stream(xq))
-        _hiplib.check(err, "butd_attention_bwd")
+        _attention_backward(B, H, Lq, Lk, D, q, k, v, mask, att, d_att, lse, dq.data_ptr(), dk.data_ptr(), dv.data_ptr(),
+                            0, 0, 1.0, p_attn, site_attn, short, xq)
         scale = math.sqrt(1.0 / float(D))
         d_xq = torch.empty((B, Lq, E), device=dev)
         d_xk = torch.empty((B, Lk, E), device=dev)
@@ -801,15 +831,9 @@ class _XpmBlock(torch.autograd.Function):
             ldg = 2 * E
             dq_ptr, dk_ptr, dv_ptr = dq.data_ptr(), G.data_ptr(), G.data_ptr() + 4 * E
             ld_dq = E
-        delta = torch.empty((B, H, Lq), device=dev)
         scale = math.sqrt(1.0 / float(D))
-        with torch.cuda.device(dev):
-            err = (_lib.butd_attention_bwd_short_keys if short else _attn_bwd())(
-                                          B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                          _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
-                                          delta.data_ptr(), dq_ptr, dk_ptr, dv_ptr, ld_dq, ldg, scale,
-                                          p_attn, site_attn, rng_counter(dev).data_ptr(), _stream(x))
-        _hiplib.check(err, "butd_attention_bwd")
+        _attention_backward(B, H, Lq, Lk, D, q, k, v, mask, att, d_att, lse, dq_ptr, dk_ptr, dv_ptr, ld_dq, ldg, scale,
+                            p_attn, site_attn, short, x)
         d_pos = d_mem = None
         if self_attn and has_pos:
             # d_pos = [dq|dk] W_in[:2E]  (also added into R);  R += dv Wv in a second launch (same target)

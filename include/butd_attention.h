@@ -178,6 +178,21 @@ int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const flo
                                   float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
                                   uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
 
+/* Backward of butd_attention_fwd for LONG KEY SETS (Lk >= 512: the 1024 seed points every encoder layer attends over and
+ * the decoder / text streams cross-attend to, models/encoder_decoder_layers.py:60-85,356-375) as ONE pass that computes every
+ * score tile once (54 matrix instructions per 16 x 16 tile instead of 72, one softmax / dropout pass instead of two): a
+ * workgroup owns 256 keys and walks all queries; its dQ shares go to one slab of `ws` per 256-key chunk and a small
+ * launch adds the slabs in chunk order (no atomics: bit-reproducible).  Same arguments and results as
+ * butd_attention_bwd (delta is formed inside).  fp32, head dimension 36.
+ *   butd_attention_bwd_long_keys_scratch: floats of `ws` this call needs, or -1 when the shape is not served
+ *   (the caller then uses butd_attention_bwd). */
+long butd_attention_bwd_long_keys_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq);
+int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                 const float *v, const uint8_t *key_padding_mask, const float *out,
+                                 const float *dout, const float *lse, float *dq, float *dk, float *dv, long ld_dq,
+                                 long ld_dkv, float dq_scale, float dropout_p, uint32_t dropout_site,
+                                 const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream);
+
 /* The same two entry points with the matrix steps on the bf16 matrix cores (BASELINE configs[3]: "bf16 attention"):
  * operands rounded to bf16 (nearest even) in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulation; scores'
  * statistics, exponentials, the (o, m, l) state, dropout masks and every tensor in memory are fp32 as above. */

@@ -27,3 +27,4 @@ for Lq,Lk in ((1024,1024),(256,1024),(256,256),(256,80),(1024,80),(80,1024),(102
         f=lambda: FWD(B,H,Lq,Lk,D,q.data_ptr(),k.data_ptr(),v.data_ptr(),None,out.data_ptr(),lse.data_ptr(),p,7,ctr,st())
         b=lambda: BWD(B,H,Lq,Lk,D,q.data_ptr(),k.data_ptr(),v.data_ptr(),None,out.data_ptr(),do.data_ptr(),lse.data_ptr(),delta.data_ptr(),dq.data_ptr(),dk.data_ptr(),dv.data_ptr(),0,0,1.0,p,7,ctr,st())
         print(f"Lq={Lq} Lk={Lk} p={p}: fwd {tg(f):.1f} us  bwd {tg(b):.1f} us")
+

@@ -432,6 +432,110 @@ def test_short_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, 
         _close(a, bq, 1e-5 if name != "padding" else 1e-12)
 
 
+@pytest.mark.parametrize("B,Lq,Lk,masked,p", [(8, 1024, 1024, False, 0.1), (8, 256, 1024, False, 0.1), (8, 80, 1024, True, 0.1),
+                                              (2, 1000, 1000, True, 0.1), (3, 70, 513, True, 0.0), (1, 200, 2048, False, 0.1),
+                                              (2, 1, 700, True, 0.1)])
+def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p):
+    """butd_attention_bwd_long_keys (one pass: a workgroup owns 256 keys and walks all queries, every score tile computed
+    once, dQ through per-chunk slabs folded in chunk order, delta formed while staging) against butd_attention_bwd on the
+    same saved forward: same dropout masks (same hash), equal to fp32 summation order (1e-5 of the scale; dV's order is
+    the same: bit-identical), padding columns of the packed gradients untouched, and bit-reproducible."""
+    _, fa, _, _ = mods
+    from butd_detr_amd import _hiplib
+    lib = _hiplib.load()
+    torch.manual_seed(Lq * 3 + Lk)
+    H, D = 8, 36
+    E = H * D
+    dev = "cuda"
+    q, do = torch.randn(B, Lq, E, device=dev) / 6, torch.randn(B, Lq, E, device=dev)
+    k, v = torch.randn(B, Lk, E, device=dev), torch.randn(B, Lk, E, device=dev)
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.uint8, device=dev)
+        for b in range(B):
+            mask[b, Lk - 1 - 40 * b:] = 1
+            mask[b, 100:100 + 150 * (b % 2)] = 1          # a whole 16-key sub-tile and more in the middle
+    out, lse = torch.empty_like(q), torch.empty(B, H, Lq, device=dev)
+    ctr = fa.rng_counter(torch.device("cuda", 0))
+    ctr.fill_(78)
+    st = torch.cuda.current_stream().cuda_stream
+    mp = mask.data_ptr() if mask is not None else None
+    assert lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
+                                  lse.data_ptr(), p, 5, ctr.data_ptr(), st) == 0
+    ldq, ldkv = E + 8, 2 * E + 4
+    need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ldq))
+    assert need == ((Lk + 255) // 256) * B * Lq * E
+    assert lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, 300, D, ldq) == -1       # short key sets: not served
+    assert lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, 32, ldq) == -1       # other head dimensions: not served
+    res = {}
+    for name in ("two", "one", "one again"):
+        dqb = torch.full((B, Lq, ldq), 7.0, device=dev)       # dq rows wider than E
+        G = torch.full((B, Lk, ldkv), 7.0, device=dev)        # dk | dv side by side, rows wider than 2E
+        if name == "two":
+            delta = torch.empty(B, H, Lq, device=dev)
+            assert lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
+                                          do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqb.data_ptr(), G.data_ptr(),
+                                          G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5, ctr.data_ptr(), st) == 0
+        else:
+            ws = torch.full((need,), float("nan"), device=dev)
+            assert lib.butd_attention_bwd_long_keys(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp,
+                                                    out.data_ptr(), do.data_ptr(), lse.data_ptr(), dqb.data_ptr(),
+                                                    G.data_ptr(), G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5,
+                                                    ctr.data_ptr(), ws.data_ptr(), need, st) == 0
+            assert lib.butd_attention_bwd_long_keys(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp,
+                                                    out.data_ptr(), do.data_ptr(), lse.data_ptr(), dqb.data_ptr(),
+                                                    G.data_ptr(), G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5,
+                                                    ctr.data_ptr(), ws.data_ptr(), need - 1, st) != 0      # workspace too small
+        torch.cuda.synchronize()
+        res[name] = (dqb[:, :, :E].clone(), G[:, :, :E].clone(), G[:, :, E:2 * E].clone(), dqb[:, :, E:].clone(),
+                     G[:, :, 2 * E:].clone())
+    for a, bq, name in zip(res["one"], res["two"], ("dq", "dk", "dv", "dq padding", "dkv padding")):
+        assert torch.isfinite(a).all(), name
+        if "padding" in name:
+            assert torch.equal(a, bq) and float(a.min()) == 7.0, name
+        else:
+            _close(a, bq, 1e-5)
+    for a, bq in zip(res["one"], res["one again"]):
+        assert torch.equal(a, bq)
+
+
+def test_long_key_backward_serves_the_blocks(mods):
+    """The structured block on 1024 keys takes the one-pass backward by default (BUTD_AB=attn_long_keys=0 is the A/B
+    switch) and its gradients equal the two-kernel walk's to fp32 summation order."""
+    ab, fa, _, _ = mods
+    from butd_detr_amd.encoder_decoder_layers import PosTransformerEncoderLayerNoFFN
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    layer = PosTransformerEncoderLayerNoFFN(288, 8, dropout=0.1).to(dev).train()
+    B, L = 8, 1024
+    x, pos, probe = (torch.randn(B, L, 288, device=dev) for _ in range(3))
+    ctr = fa.rng_counter(dev)
+
+    def run(flag):
+        prev = fa.set_long_keys(flag)
+        ab.set_backend("hip")
+        try:
+            ctr.fill_(5)
+            fa._site[0] = 0
+            for prm in layer.parameters():
+                prm.grad = None
+            xi = x.clone().requires_grad_(True)
+            out = layer(xi, pos)
+            (out * probe).sum().backward()
+            torch.cuda.synchronize()
+            return [xi.grad.clone()] + [prm.grad.clone() for prm in layer.parameters() if prm.grad is not None]
+        finally:
+            ab.set_backend("torch")
+            fa.set_long_keys(prev)
+
+    assert fa._long_keys[0]
+    one = run(True)
+    two = run(False)
+    assert len(one) == len(two) and len(one) > 4
+    for a, b in zip(one, two):
+        _close(a, b, 2e-5)
+
+
 @pytest.mark.parametrize("rows,E", [(2048, 288), (8192, 288), (640, 288), (64, 32), (2048, 64)])
 def test_layernorm_backward_partials_equal_the_atomic_kernel(mods, rows, E):
     """butd_add_dropout_layernorm_bwd_partial + the fold (ones . partials as one problem of the grouped product, what every
