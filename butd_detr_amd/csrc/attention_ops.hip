@@ -1532,24 +1532,22 @@ int launch_smallk(int B, int H, int Lq, int Lk, int D, const float *q, const flo
 // in chunk order and applies dq_scale: no atomics, bit-reproducible.
 // delta = rowsum(dO o O) is formed while the query tile is staged (the staged dO float4s times the same float4s of O; a
 // row's quartets sit in 16 consecutive lanes: four xor-shuffles), so no kernel has to run before this one.
-constexpr int kLongWaves = 8;
-constexpr int kLongSub = 2;                                   // 16-key sub-tiles per wave
-constexpr int kLongChunk = kLongWaves * kLongSub * 16;        // keys per workgroup
-constexpr int kLongThreads = kLongWaves * 64;
-
+// WAVES x SUB: waves per workgroup x 16-key sub-tiles per wave (8 x 2: the 256-key chunks above; 4 x 1: 64-key chunks for
+// key sets that would leave most of the part idle otherwise).
 template <int NS>
-constexpr int longk_lds_floats(int D) {
-  return 2 * 64 * Img<NS>::LD + 64 + 64 + kLongWaves * 16 * 20 + kLongWaves * 64 * D;
+constexpr int longk_lds_floats(int D, int waves) {
+  return 2 * 64 * Img<NS>::LD + 64 + 64 + waves * 16 * 20 + waves * 64 * D;
 }
 
-template <int NS, int NT>
-__global__ __launch_bounds__(kLongThreads) void attn_bwd_longk_kernel(
+template <int NS, int NT, int kLongWaves, int kLongSub>
+__global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ dq_out, long ld_dq,
     long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, float p_drop,
     uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
+  constexpr int kLongThreads = kLongWaves * 64, kLongChunk = kLongWaves * kLongSub * 16;
   constexpr int LDX = 20;
   constexpr int kVec = 64 * 16 / kLongThreads;         // staging: 16 lanes per query row, the first D / 4 hold a quartet
   static_assert(NS <= 16, "a row's quartets fit 16 lanes");
@@ -2480,6 +2478,20 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_h_kernel(
   }
 }
 
+template <int WAVES, int SUB>
+int launch_longk(int chunks, int B, int H, int Lq, int Lk, int D, const float *q, const float *k, const float *v,
+                        const uint8_t *mask, const float *out, const float *dout, const float *lse, float *ws, long E,
+                        long chunk_stride, float *dk, float *dv, long ld_dkv, float p, uint32_t site,
+                        const uint64_t *rng_counter, hipStream_t s) {
+  const size_t bytes = sizeof(float) * (size_t)longk_lds_floats<9>(36, WAVES);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_longk_kernel<9, 3, WAVES, SUB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((attn_bwd_longk_kernel<9, 3, WAVES, SUB>), dim3(chunks, H, B), dim3(WAVES * 64), bytes, s, H, Lq, Lk, D, q, k,
+                     v, mask, out, dout, lse, ws, E, chunk_stride, 1.f, dk, dv, ld_dkv, p, site, rng_counter);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2573,13 +2585,30 @@ int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const flo
   return 0;
 }
 
-/* (include/butd_attention.h) */
+/* (include/butd_attention.h)  Keys per workgroup, measured at 8 x 8 heads (scratch/attn_longk_bench.py, dropout 0.1, us:
+ * two kernels | 64-key chunks | 128 | 256):  1024 x 1024: 426 | 372 | 341 | 312;  256 x 1024: 135 | 109 | 108 | 100;
+ * 80 x 1024: 102 | 68 | 68 | 63;  256 x 256: 49 | 42 | 53 | 91;  256 x 132: 47 | 41 | 54 | 84;  80 x 80: 30 | 24 | 30 | 47;
+ * 256 x 80: 39 | 39 | 49 | 82;  1024 x 132: 126 | 126 | 168 | 298;  1024 x 80: 114 | 126 (short-key kernel: 90);  1024 x 512: 254 | . | . | 307.
+ * So: 256 keys (8 waves x 2 sub-tiles) where that gives >= 192 workgroups; else 64 keys (4 waves x 1) for <= 256 queries
+ * where THAT gives >= 128 workgroups; else not served.  g_longk_force: tuning hook (0 = the rule; 256 / 128 / 64). */
+static int g_longk_force = 0;
+int butd_attention_bwd_long_keys_set_chunk(int keys) { g_longk_force = keys; return 0; }   /* timing experiments only */
+static int longk_chunk(int B, int H, int Lq, int Lk, int D) {
+  if (D != 36) return 0;
+  if (g_longk_force) return g_longk_force;
+  const long bh = (long)B * H;
+  if ((long)((Lk + 255) / 256) * bh >= 192) return 256;
+  if (Lq <= 256 && (long)((Lk + 63) / 64) * bh >= 128) return 64;
+  return 0;
+}
+
 long butd_attention_bwd_long_keys_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
-  if (D != 36 || Lk < 2 * kLongChunk) return -1;
+  const int chunk = longk_chunk(B, H, Lq, Lk, D);
+  if (!chunk) return -1;
   if (ld_dq == 0) ld_dq = (long)H * D;
   if (ld_dq & 3) return -1;
-  const long chunks = (Lk + kLongChunk - 1) / kLongChunk;
+  const long chunks = (Lk + chunk - 1) / chunk;
   return chunks * B * Lq * H * D;
 }
 
@@ -2594,15 +2623,17 @@ int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const floa
   if (ld_dkv == 0) ld_dkv = (long)H * D;
   if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const size_t bytes = sizeof(float) * (size_t)longk_lds_floats<9>(36);
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_longk_kernel<9, 3>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr != hipSuccess) return (int)attr;
-  const int chunks = (Lk + kLongChunk - 1) / kLongChunk;
+  const int chunk = longk_chunk(B, H, Lq, Lk, D);
+  const int chunks = (Lk + chunk - 1) / chunk;
   const long E = (long)H * D, chunk_stride = (long)B * Lq * E;
-  hipLaunchKernelGGL((attn_bwd_longk_kernel<9, 3>), dim3(chunks, H, B), dim3(kLongThreads), bytes, s, H, Lq, Lk, D, q, k, v,
-                     key_padding_mask, out, dout, lse, ws, E, chunk_stride, 1.f, dk, dv, ld_dkv, dropout_p, dropout_site,
-                     rng_counter);
+  int err;
+#define LONGK(W, S) launch_longk<W, S>(chunks, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, ws, E, chunk_stride, dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter, s)
+  if (chunk == 256) err = LONGK(8, 2);
+  else if (chunk == 128) err = LONGK(8, 1);
+  else if (chunk == 64) err = LONGK(4, 1);
+  else return (int)hipErrorInvalidValue;
+#undef LONGK
+  if (err) return err;
   const long rows = (long)B * Lq, n4 = rows * (E / 4);
   hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, chunks, rows, (int)(E / 4), ws,
                      chunk_stride, dq, ld_dq, dq_scale);

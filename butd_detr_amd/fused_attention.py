@@ -180,9 +180,8 @@ def _attention_backward(B, H, Lq, Lk, D, q, k, v, mask, att, d_att, lse, dq_ptr,
     ctr = rng_counter(dev).data_ptr()
     with torch.cuda.device(dev):
         need = -1
-        # a workgroup per 256 keys and head: serves where that fills the part (measured, 8 x 8 heads: 1024 x 1024
-        # 442 -> 306 us, 256 x 1024 135 -> 97, 80 x 1024 102 -> 63; 1024 x 512 -- 128 workgroups -- 254 -> 300)
-        if _long_keys[0] and not short and not _compute_bf16[0] and ((Lk + 255) // 256) * H * B >= 192:
+        # (which shapes it serves, and with how many keys per workgroup: the library's measured rule, attention_ops.hip)
+        if _long_keys[0] and not short and not _compute_bf16[0]:
             need = int(_lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ld_dq))
         if need >= 0:
             ws = torch.empty(max(need, 1), device=dev)

@@ -178,11 +178,12 @@ int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const flo
                                   float *dv, long ld_dq, long ld_dkv, float dq_scale, float dropout_p,
                                   uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
 
-/* Backward of butd_attention_fwd for LONG KEY SETS (Lk >= 512: the 1024 seed points every encoder layer attends over and
- * the decoder / text streams cross-attend to, models/encoder_decoder_layers.py:60-85,356-375) as ONE pass that computes every
- * score tile once (54 matrix instructions per 16 x 16 tile instead of 72, one softmax / dropout pass instead of two): a
- * workgroup owns 256 keys and walks all queries; its dQ shares go to one slab of `ws` per 256-key chunk and a small
- * launch adds the slabs in chunk order (no atomics: bit-reproducible).  Same arguments and results as
+/* Backward of butd_attention_fwd as ONE pass that computes every score tile once (54 matrix instructions per 16 x 16
+ * tile instead of 72, one softmax / dropout pass instead of two), for LONG KEY SETS (the 1024 seed points every encoder
+ * layer attends over and the decoder / text streams cross-attend to, models/encoder_decoder_layers.py:60-85,356-375):
+ * a workgroup owns a chunk of 256 keys and walks all queries; its dQ shares go to one slab of `ws` per chunk and a small
+ * launch adds the slabs in chunk order (no atomics: bit-reproducible).  Also serves <= 256 queries over shorter key sets
+ * with 64-key chunks where that fills the part (the decoder's self-attention).  Same arguments and results as
  * butd_attention_bwd (delta is formed inside).  fp32, head dimension 36.
  *   butd_attention_bwd_long_keys_scratch: floats of `ws` this call needs, or -1 when the shape is not served
  *   (the caller then uses butd_attention_bwd). */

@@ -21,15 +21,22 @@ B, H, D = 8, 8, 36; E = H * D
 dev = torch.device("cuda", 0)
 ctr = fa.rng_counter(dev).data_ptr()
 st = lambda: torch.cuda.current_stream().cuda_stream
-for Lq, Lk, masked in ((1024, 1024, False), (256, 1024, False), (80, 1024, False), (1024, 512, False), (1000, 1000, True), (2048, 2048, False)):
+import os
+SHAPES = ((1024, 1024, False), (256, 1024, False), (80, 1024, False), (1024, 512, False), (1000, 1000, True), (2048, 2048, False))
+if os.environ.get("SHAPES") == "short":
+    SHAPES = ((256, 256, False), (256, 80, True), (256, 132, True), (1024, 132, True), (1024, 80, True), (80, 80, True),
+              (256, 1024, False), (80, 1024, False), (1024, 1024, False))
+CHUNKS = [int(c) for c in os.environ.get("CHUNKS", "0").split(",")]          # 0 = the library's rule
+for Lq, Lk, masked in SHAPES:
     torch.manual_seed(Lq + Lk)
     q, do = torch.randn(B, Lq, E, device=dev), torch.randn(B, Lq, E, device=dev)
     k, v = torch.randn(B, Lk, E, device=dev), torch.randn(B, Lk, E, device=dev)
     mask = None
     if masked:
         mask = torch.zeros(B, Lk, dtype=torch.uint8, device=dev)
-        mask[:, Lk - 77:] = 1
-        mask[1, 100:400] = 1
+        mask[:, Lk - min(77, Lk // 4):] = 1
+        if Lk >= 512:
+            mask[1, 100:400] = 1
     mp = mask.data_ptr() if mask is not None else None
     o, lse, delta = torch.empty_like(q), torch.empty(B, H, Lq, device=dev), torch.empty(B, H, Lq, device=dev)
     for p in (0.0, 0.1):
@@ -37,21 +44,29 @@ for Lq, Lk, masked in ((1024, 1024, False), (256, 1024, False), (80, 1024, False
         G, Gq = torch.empty(B, Lk, 3 * E, device=dev), torch.empty(B, Lq, 3 * E, device=dev)
         args = lambda: (B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), do.data_ptr(), lse.data_ptr())
         outs = lambda: (Gq.data_ptr(), G.data_ptr() + 4 * E, G.data_ptr() + 8 * E, 3 * E, 3 * E, 0.5, p, 5, ctr)
-        need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, 3 * E))
-        assert need >= 0
-        ws = torch.empty(max(need, 1), device=dev)
         two = lambda: lib.butd_attention_bwd(*args(), delta.data_ptr(), *outs(), st())
-        one = lambda: lib.butd_attention_bwd_long_keys(*args(), *outs(), ws.data_ptr(), need, st())
         assert two() == 0
         torch.cuda.synchronize(); ref, refq = G.clone(), Gq.clone()
-        G.fill_(float("nan")); Gq.fill_(float("nan"))
-        assert one() == 0
-        torch.cuda.synchronize()
-        errs = []
-        for name, t, rt, lo in (("dq", Gq, refq, 0), ("dk", G, ref, E), ("dv", G, ref, 2 * E)):
-            a, r = t[:, :, lo:lo + E].double(), rt[:, :, lo:lo + E].double()
-            errs.append(f"{name} {float((a - r).abs().max() / r.abs().max()):.1e}")
-        first, firstq = G.clone(), Gq.clone(); one(); torch.cuda.synchronize()
-        same = torch.equal(firstq[:, :, :E], Gq[:, :, :E]) and torch.equal(first[:, :, E:], G[:, :, E:])
-        print(f"  {Lq:5d} x {Lk:5d} p={p} mask={int(masked)}: two kernels {tg(two):7.1f} us   one pass {tg(one):7.1f} us   "
-              f"({', '.join(errs)}; repeat identical {same})", flush=True)
+        line = f"  {Lq:5d} x {Lk:5d} p={p} mask={int(masked)}: two kernels {tg(two):7.1f} us |"
+        if Lk <= 144:
+            G.zero_()
+            short = lambda: lib.butd_attention_bwd_short_keys(*args(), delta.data_ptr(), *outs(), st())
+            line += f" short-key kernel {tg(short):7.1f} us |"
+        for chunk in CHUNKS:
+            lib.butd_attention_bwd_long_keys_set_chunk(chunk)
+            need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, 3 * E))
+            if need < 0:
+                line += f" chunk {chunk}: not served |"
+                continue
+            ws = torch.empty(max(need, 1), device=dev)
+            one = lambda: lib.butd_attention_bwd_long_keys(*args(), *outs(), ws.data_ptr(), need, st())
+            G.fill_(float("nan")); Gq.fill_(float("nan"))
+            assert one() == 0
+            torch.cuda.synchronize()
+            worst = 0.0
+            for name, t, rt, lo in (("dq", Gq, refq, 0), ("dk", G, ref, E), ("dv", G, ref, 2 * E)):
+                a, r = t[:, :, lo:lo + E].double(), rt[:, :, lo:lo + E].double()
+                worst = max(worst, float((a - r).abs().max() / r.abs().max()))
+            line += f" chunk {chunk}: {tg(one):7.1f} us (err {worst:.0e}) |"
+        lib.butd_attention_bwd_long_keys_set_chunk(0)
+        print(line, flush=True)

@@ -434,12 +434,14 @@ def test_short_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, 
 
 @pytest.mark.parametrize("B,Lq,Lk,masked,p", [(8, 1024, 1024, False, 0.1), (8, 256, 1024, False, 0.1), (8, 80, 1024, True, 0.1),
                                               (2, 1000, 1000, True, 0.1), (3, 70, 513, True, 0.0), (1, 200, 2048, False, 0.1),
-                                              (2, 1, 700, True, 0.1)])
+                                              (2, 1, 700, True, 0.1), (8, 256, 256, False, 0.1), (8, 256, 132, True, 0.1),
+                                              (8, 80, 80, True, 0.1), (2, 256, 600, True, 0.0), (3, 33, 300, True, 0.1)])
 def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p):
     """butd_attention_bwd_long_keys (one pass: a workgroup owns 256 keys and walks all queries, every score tile computed
-    once, dQ through per-chunk slabs folded in chunk order, delta formed while staging) against butd_attention_bwd on the
-    same saved forward: same dropout masks (same hash), equal to fp32 summation order (1e-5 of the scale; dV's order is
-    the same: bit-identical), padding columns of the packed gradients untouched, and bit-reproducible."""
+    once, dQ through per-chunk slabs folded in chunk order, delta formed while staging; 64-key chunks for <= 256 queries
+    over shorter key sets) against butd_attention_bwd on the same saved forward: same dropout masks (same hash), equal
+    to fp32 summation order (1e-5 of the scale), padding columns of the packed gradients untouched, and
+    bit-reproducible."""
     _, fa, _, _ = mods
     from butd_detr_amd import _hiplib
     lib = _hiplib.load()
@@ -453,8 +455,9 @@ def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p
     if masked:
         mask = torch.zeros(B, Lk, dtype=torch.uint8, device=dev)
         for b in range(B):
-            mask[b, Lk - 1 - 40 * b:] = 1
-            mask[b, 100:100 + 150 * (b % 2)] = 1          # a whole 16-key sub-tile and more in the middle
+            mask[b, Lk - 1 - min(40 * b, Lk // 2):] = 1
+            if Lk >= 512:
+                mask[b, 100:100 + 150 * (b % 2)] = 1      # a whole 16-key sub-tile and more in the middle
     out, lse = torch.empty_like(q), torch.empty(B, H, Lq, device=dev)
     ctr = fa.rng_counter(torch.device("cuda", 0))
     ctr.fill_(78)
@@ -463,10 +466,19 @@ def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p
     assert lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
                                   lse.data_ptr(), p, 5, ctr.data_ptr(), st) == 0
     ldq, ldkv = E + 8, 2 * E + 4
-    need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ldq))
-    assert need == ((Lk + 255) // 256) * B * Lq * E
-    assert lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, 300, D, ldq) == -1       # short key sets: not served
+    assert lib.butd_attention_bwd_long_keys_scratch(8, H, 1024, 132, D, ldq) == -1     # many queries, few keys: not served
+    assert lib.butd_attention_bwd_long_keys_scratch(1, 1, 64, 64, D, ldq) == -1        # would leave the part idle
     assert lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, 32, ldq) == -1       # other head dimensions: not served
+    # the library's rule (attention_ops.hip, longk_chunk); shapes it leaves to the two kernels run here with a forced chunk
+    chunk = 256 if ((Lk + 255) // 256) * B * H >= 192 else 64 if (Lq <= 256 and ((Lk + 63) // 64) * B * H >= 128) else 0
+    need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ldq))
+    forced = chunk == 0
+    if forced:
+        assert need == -1
+        chunk = 256 if Lk >= 512 else 128 if Lk >= 200 else 64
+        lib.butd_attention_bwd_long_keys_set_chunk(chunk)
+        need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ldq))
+    assert need == ((Lk + chunk - 1) // chunk) * B * Lq * E
     res = {}
     for name in ("two", "one", "one again"):
         dqb = torch.full((B, Lq, ldq), 7.0, device=dev)       # dq rows wider than E
@@ -489,6 +501,7 @@ def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p
         torch.cuda.synchronize()
         res[name] = (dqb[:, :, :E].clone(), G[:, :, :E].clone(), G[:, :, E:2 * E].clone(), dqb[:, :, E:].clone(),
                      G[:, :, 2 * E:].clone())
+    lib.butd_attention_bwd_long_keys_set_chunk(0)
     for a, bq, name in zip(res["one"], res["two"], ("dq", "dk", "dv", "dq padding", "dkv padding")):
         assert torch.isfinite(a).all(), name
         if "padding" in name:
