@@ -564,6 +564,8 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
     float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
   using T = TImg<NT>;
+  // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
+  constexpr bool THIN = !BF && NT == 3 && NS == 9;
   __shared__ __attribute__((aligned(16))) float KimgG[NG][2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float VtG[NG][2][T::ROWS][T::LD];
   __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
@@ -594,6 +596,9 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
   const DFrag<NS, BF> qF = make_frag<NS, BF>(qf);
   float m = kNegInf, l = 0.f;
   f32x4 o[NT];
+  int vrow[NT];     // this lane's row of the transposed V image per output tile
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) vrow[nt] = (THIN && nt == 2) ? 32 + (fr & 3) : nt * 16 + fr;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) o[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
       // the first V operands travel while the softmax runs
       f32x4 va[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) va[nt] = *reinterpret_cast<const f32x4 *>(&Vt[cur][nt * 16 + fr][fg * 4]);
+      for (int nt = 0; nt < NT; ++nt) va[nt] = *reinterpret_cast<const f32x4 *>(&Vt[cur][vrow[nt]][fg * 4]);
 #ifdef ATTN_PROF
       asm volatile("s_nop 0" :: "v"(st[3][3]));      // (the last score accumulator has to be there)
       __builtin_amdgcn_sched_barrier(0);
@@ -714,7 +719,7 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
         if (t < 3) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            vn[nt] = *reinterpret_cast<const f32x4 *>(&Vt[cur][nt * 16 + fr][(t + 1) * 16 + fg * 4]);
+            vn[nt] = *reinterpret_cast<const f32x4 *>(&Vt[cur][vrow[nt]][(t + 1) * 16 + fg * 4]);
         }
         if constexpr (BF) {
 #pragma unroll
@@ -726,8 +731,10 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], st[t][s], o[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+              if (THIN && nt == 2) o[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(va[nt][s], st[t][s], o[nt], 0, 0, 0);
+              else o[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(va[nt][s], st[t][s], o[nt], 0, 0, 0);
+            }
         }
         if (t < 3) {
 #pragma unroll
@@ -793,6 +800,10 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
   }
   if (live) {
     l = quad_sum(l);
+    if constexpr (THIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[2][i] = quad_sum(o[2][i]);
+    }
     if (qi < Lq) {
       // l == 0 (every key masked) -> inf * 0 = NaN like torch's softmax; the dropout scale 1/(1-p) is applied here
       const float inv_l = (drop ? 1.f / (1.f - p_drop) : 1.f) / l;
@@ -821,6 +832,8 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
   using T = TImg<NT>;
+  // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
+  constexpr bool THIN = !BF && NT == 3 && NS == 9;
   __shared__ __attribute__((aligned(16))) float KimgG[NG][2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float VimgG[NG][2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float KtG[NG][2][T::ROWS][T::LD];   // K transposed: the dQ product's operand
@@ -871,6 +884,9 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
   for (int s = 0; s < NS; ++s) gf[s] *= inv_keep;
   const DFrag<NS, BF> qF = make_frag<NS, BF>(qf), gF = make_frag<NS, BF>(gf);
   f32x4 acc[NT];
+  int krow[NT];     // this lane's row of the transposed K image per output tile
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) krow[nt] = (THIN && nt == 2) ? 32 + (fr & 3) : nt * 16 + fr;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -947,14 +963,14 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
       f32x4 ka[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) ka[nt] = *reinterpret_cast<const f32x4 *>(&Kt[cur][nt * 16 + fr][fg * 4]);
+      for (int nt = 0; nt < NT; ++nt) ka[nt] = *reinterpret_cast<const f32x4 *>(&Kt[cur][krow[nt]][fg * 4]);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         f32x4 kn[NT];
         if (t < 3) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
-            kn[nt] = *reinterpret_cast<const f32x4 *>(&Kt[cur][nt * 16 + fr][(t + 1) * 16 + fg * 4]);
+            kn[nt] = *reinterpret_cast<const f32x4 *>(&Kt[cur][krow[nt]][(t + 1) * 16 + fg * 4]);
         }
         if constexpr (BF) {
 #pragma unroll
@@ -966,8 +982,10 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][s], ds[t][s], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+              if (THIN && nt == 2) acc[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(ka[nt][s], ds[t][s], acc[nt], 0, 0, 0);
+              else acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][s], ds[t][s], acc[nt], 0, 0, 0);
+            }
         }
         if (t < 3) {
 #pragma unroll
@@ -1004,6 +1022,12 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
         for (int i = 0; i < 4; ++i) acc[nt][i] += px[nt * 4 + i];
     }
   }
+  if constexpr (THIN) {
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[2][i] = quad_sum(acc[2][i]);
+    }
+  }
   if (live && qi < Lq) {
     float *ob = dq + ((long)b * Lq + qi) * ldo + h * D;
 #pragma unroll
@@ -1030,6 +1054,8 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
     float *__restrict__ dv, long ldo, float p_drop, uint32_t site,
     const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
+  // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
+  constexpr bool THIN = !BF && NT == 3 && NS == 9;
   __shared__ __attribute__((aligned(16))) float QimgG[NG][2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float GimgG[NG][2][64][I::LD];
   __shared__ __attribute__((aligned(16))) float LseG[NG][2][64];   // lse * log2(e)
@@ -1077,7 +1103,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
   int ncol[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + fr;
+    const int n = (THIN && nt == 2) ? 32 + (fr & 3) : nt * 16 + fr;
     ncol[nt] = n < D ? I::col(n) : kZeroSlot;
   }
   f32x4 ak[NT], av[NT];
@@ -1190,8 +1216,13 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
           for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-              av[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][nt], pd[s], av[nt], 0, 0, 0);
-              ak[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s][nt], ds[s], ak[nt], 0, 0, 0);
+              if (THIN && nt == 2) {
+                av[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(ga[s][nt], pd[s], av[nt], 0, 0, 0);
+                ak[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[s][nt], ds[s], ak[nt], 0, 0, 0);
+              } else {
+                av[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][nt], pd[s], av[nt], 0, 0, 0);
+                ak[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s][nt], ds[s], ak[nt], 0, 0, 0);
+              }
             }
         }
       }
@@ -1232,6 +1263,15 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
         }
     }
   }
+  if constexpr (THIN) {
+    if (live) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ak[2][i] = quad_sum(ak[2][i]);
+        av[2][i] = quad_sum(av[2][i]);
+      }
+    }
+  }
   if (live && ki < Lk) {
     float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
     float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
@@ -1267,6 +1307,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
     float *__restrict__ dq, float *__restrict__ dk, float *__restrict__ dv, long ld_dq, long ld_dkv, float dq_scale,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
+  // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
+  constexpr bool THIN = NT == 3 && NS == 9;
   constexpr int KR = NKT * 16;    // staged key rows
   constexpr int LDT = KR + 4;     // row stride of the transposed K image
   constexpr int LDX = 20;         // row stride of a wave's transpose patch (conflict-free for both access patterns)
@@ -1366,7 +1408,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
     float qT[NT][4], gT[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int n = nt * 16 + fr;
+      const int n = (THIN && nt == 2) ? 32 + (fr & 3) : nt * 16 + fr;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int qq = q0 + fg * 4 + s;
@@ -1405,7 +1447,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
         f32x4 ka[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          ka[nt] = *reinterpret_cast<const f32x4 *>(Kt + (nt * 16 + fr) * LDT + t * 16 + fg * 4);
+          ka[nt] = *reinterpret_cast<const f32x4 *>(Kt + ((THIN && nt == 2) ? 32 + (fr & 3) : nt * 16 + fr) * LDT + t * 16 + fg * 4);
         if (wave_masked) {
           st[0] += bias_t[t]; st[1] += bias_t[t]; st[2] += bias_t[t]; st[3] += bias_t[t];
         }
@@ -1431,8 +1473,13 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            av[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gT[nt][s], pd[s], av[t][nt], 0, 0, 0);
-            ak[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qT[nt][s], ds[s], ak[t][nt], 0, 0, 0);
+            if (THIN && nt == 2) {
+              av[t][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(gT[nt][s], pd[s], av[t][nt], 0, 0, 0);
+              ak[t][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(qT[nt][s], ds[s], ak[t][nt], 0, 0, 0);
+            } else {
+              av[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(gT[nt][s], pd[s], av[t][nt], 0, 0, 0);
+              ak[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qT[nt][s], ds[s], ak[t][nt], 0, 0, 0);
+            }
           }
         __builtin_amdgcn_wave_barrier();
         const f32x4 dst = *reinterpret_cast<const f32x4 *>(Xw + fr * LDX + fg * 4);
@@ -1440,9 +1487,15 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            dqa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][s], dst[s], dqa[nt], 0, 0, 0);   // dQ^T[d][q]
+          for (int nt = 0; nt < NT; ++nt) {
+            if (THIN && nt == 2) dqa[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(ka[nt][s], dst[s], dqa[nt], 0, 0, 0);
+            else dqa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[nt][s], dst[s], dqa[nt], 0, 0, 0);   // dQ^T[d][q]
+          }
       }
+    }
+    if constexpr (THIN) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dqa[2][i] = quad_sum(dqa[2][i]);
     }
     if (qi < Lq) {
       float *op = dq + ((long)b * Lq + qi) * ld_dq + h * D;
@@ -1459,6 +1512,15 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
 #ifdef ATTN_SK_ABL
   if ((ATTN_SK_ABL & 1) && ak[0][0][0] != 12345.678f) return;
 #endif
+  if constexpr (THIN) {
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ak[t][2][i] = quad_sum(ak[t][2][i]);
+        av[t][2][i] = quad_sum(av[t][2][i]);
+      }
+  }
   // ---- dK, dV: sum of the four waves' shares through LDS (the key images are dead), one atomic per element
   __syncthreads();
   float *Rd = smem;     // [4 waves][8 * NT values][64 lanes]
@@ -1547,6 +1609,13 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
     long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, float p_drop,
     uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
+  // head dimension 36 = two full 16-row tiles + FOUR rows: the third tile of the dV / dK / dQ products as
+  // v_mfma_f32_4x4x1 (16 independent 4 x 4 blocks; ~10 cycles where the 16 x 16 x 4 instruction takes ~34,
+  // scratch/ubench/mfma_4x4.hip).  Block (g, c / 4) of lane (c, g) multiplies rows 32 + (c & 3) of the A side with the
+  // lane's own B value, so the B operands -- the score-tile registers -- are used as they are, and the accumulator of a
+  // lane holds rows 32..35 of its column as a partial sum over ITS contraction group g: summed over the four groups once
+  // (dK, dV: at the end of the kernel; dQ: per query tile, two lane swaps per value).
+  constexpr bool THIN = NT == 3 && NS == 9;
   constexpr int kLongThreads = kLongWaves * 64, kLongChunk = kLongWaves * kLongSub * 16;
   constexpr int LDX = 20;
   constexpr int kVec = 64 * 16 / kLongThreads;         // staging: 16 lanes per query row, the first D / 4 hold a quartet
@@ -1597,7 +1666,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const int key = k0 + j * 16 + fg * 4 + s, d = nt * 16 + fr;
+        const int key = k0 + j * 16 + fg * 4 + s, d = (THIN && nt == 2) ? 32 + (fr & 3) : nt * 16 + fr;
         ka[j][nt][s] = (key < Lk && d < D) ? kb[(long)key * E + d] : 0.f;
       }
   }
@@ -1606,7 +1675,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
   int ncol[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    const int n = nt * 16 + fr;
+    const int n = (THIN && nt == 2) ? 32 + (fr & 3) : nt * 16 + fr;
     ncol[nt] = n < D ? I::col(n) : kZeroSlot;
   }
   f32x4 ak[kLongSub][NT], av[kLongSub][NT];
@@ -1733,8 +1802,13 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
         for (int s = 0; s < 4; ++s)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            av[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][nt], pd[s], av[j][nt], 0, 0, 0);
-            ak[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s][nt], ds[s], ak[j][nt], 0, 0, 0);
+            if (THIN && nt == 2) {
+              av[j][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(ga[s][nt], pd[s], av[j][nt], 0, 0, 0);
+              ak[j][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(qa[s][nt], ds[s], ak[j][nt], 0, 0, 0);
+            } else {
+              av[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[s][nt], pd[s], av[j][nt], 0, 0, 0);
+              ak[j][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[s][nt], ds[s], ak[j][nt], 0, 0, 0);
+            }
           }
         __builtin_amdgcn_wave_barrier();
         const f32x4 dst = *reinterpret_cast<const f32x4 *>(Xw + fr * LDX + fg * 4);
@@ -1742,8 +1816,14 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            dqa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j][nt][s], dst[s], dqa[nt], 0, 0, 0);   // dQ^T[d][q]
+          for (int nt = 0; nt < NT; ++nt) {
+            if (THIN && nt == 2) dqa[nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(ka[j][nt][s], dst[s], dqa[nt], 0, 0, 0);
+            else dqa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ka[j][nt][s], dst[s], dqa[nt], 0, 0, 0);   // dQ^T[d][q]
+          }
+      }
+      if constexpr (THIN) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dqa[2][i] = quad_sum(dqa[2][i]);
       }
       // this wave's share of dQ for the 16 queries: row = query, D floats
 #pragma unroll
@@ -1762,6 +1842,15 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
     }
     if (more) commit();
     __syncthreads();
+  }
+  if constexpr (THIN) {
+#pragma unroll
+    for (int j = 0; j < kLongSub; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ak[j][2][i] = quad_sum(ak[j][2][i]);
+        av[j][2][i] = quad_sum(av[j][2][i]);
+      }
   }
 #pragma unroll
   for (int j = 0; j < kLongSub; ++j) {

@@ -54,7 +54,7 @@ class Ext64:
 FIXED = {}
 
 
-def pinned_queries(self, xyz, features, end_points, features_pm=None):
+def pinned_queries(self, xyz, features, end_points, features_pm=None, forced_seeds=None):
     logits = self.points_obj_cls(features, features_pm=features_pm)
     end_points["seeds_obj_cls_logits"] = logits
     if "inds" not in FIXED:
