@@ -1606,8 +1606,8 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ dq_out, long ld_dq,
-    long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, float p_drop,
-    uint32_t site, const uint64_t *__restrict__ rng_counter) {
+    long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, long kv_stride,
+    int chunks, int q_tiles_per_wg, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = Img<NS>;
   // head dimension 36 = two full 16-row tiles + FOUR rows: the third tile of the dV / dK / dQ products as
   // v_mfma_f32_4x4x1 (16 independent 4 x 4 blocks; ~10 cycles where the 16 x 16 x 4 instruction takes ~34,
@@ -1632,14 +1632,19 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
   const TileId wg = tile_id();
   const int b = wg.b, h = wg.h;
   const long E = (long)H * D;
-  const int k0 = wg.t * kLongChunk + wave * (kLongSub * 16);
+  // grid.x = key chunks x query splits: workgroup (chunk, split) walks q_tiles_per_wg 64-query tiles; with more than one
+  // split its dK / dV are a share as well and go to the split's slab (kv_stride floats apart), folded like dQ's
+  const int chunk = wg.t % chunks, qsplit = wg.t / chunks;
+  const int k0 = chunk * kLongChunk + wave * (kLongSub * 16);
+  const bool wave_live = k0 < Lk;                       // (uniform) waves past the last key only help staging
+  const int live_waves = min(kLongWaves, (Lk - chunk * kLongChunk + kLongSub * 16 - 1) / (kLongSub * 16));
   const float *qb = q + (long)b * Lq * E + h * D;
   const float *gb = dout + (long)b * Lq * E + h * D;
   const float *ob = out + (long)b * Lq * E + h * D;
   const float *kb = k + (long)b * Lk * E + h * D;
   const float *vb = v + (long)b * Lk * E + h * D;
   const float *lb = lse + ((long)b * H + h) * Lq;
-  float *dqb = dq_out + (long)wg.t * chunk_stride + (long)b * Lq * ld_dq + h * D;
+  float *dqb = dq_out + (long)chunk * chunk_stride + (long)b * Lq * ld_dq + h * D;
   const bool drop = p_drop > 0.f;
   const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
   const uint32_t thr = drop_threshold(p_drop);
@@ -1736,15 +1741,17 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
     }
     if (tid < 64) Lse[tid] = sr;
   };
-  const int iters = (Lq + 63) / 64;
-  fetch(0);
+  const int tile0 = qsplit * q_tiles_per_wg;
+  const int iters = min(q_tiles_per_wg, (Lq + 63) / 64 - tile0);
+  fetch(tile0 * 64);
   __syncthreads();                                 // the zero slots are in place
   commit();
   __syncthreads();
   float *Xw = X + wave * 16 * LDX, *Rw = Red + wave * 64 * D;
   for (int it = 0; it < iters; ++it) {
-    const int qs = it * 64;
+    const int qs = (tile0 + it) * 64;
     const bool more = it + 1 < iters;
+    if (wave_live) {
 #pragma unroll 1
     for (int t = 0; t < 4; ++t) {
       float qf[NS], gf[NS];
@@ -1830,13 +1837,15 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
       for (int nt = 0; nt < NT; ++nt)
         if (nt * 16 + fg * 4 < D) *reinterpret_cast<f32x4 *>(Rw + (t * 16 + fr) * D + nt * 16 + fg * 4) = dqa[nt];
     }
+    }
     if (more) fetch(qs + 64);                      // in flight across the barrier and the sum below
     __syncthreads();
     // ---- dQ of the query tile: sum of the eight shares, linear in LDS
     for (int e = tid; e < 64 * vpr; e += kLongThreads) {
       f32x4 a = *reinterpret_cast<const f32x4 *>(Red + 4 * e);
 #pragma unroll
-      for (int w = 1; w < kLongWaves; ++w) a += *reinterpret_cast<const f32x4 *>(Red + w * 64 * D + 4 * e);
+      for (int w = 1; w < kLongWaves; ++w)
+        if (w < live_waves) a += *reinterpret_cast<const f32x4 *>(Red + w * 64 * D + 4 * e);
       const int r = e / vpr, c4 = e - r * vpr;
       if (qs + r < Lq) *reinterpret_cast<f32x4 *>(dqb + (long)(qs + r) * ld_dq + 4 * c4) = a * dq_scale;
     }
@@ -1856,8 +1865,8 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
   for (int j = 0; j < kLongSub; ++j) {
     const int ki = k0 + j * 16 + fr;
     if (ki < Lk) {
-      float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
-      float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
+      float *okp = dk + qsplit * kv_stride + ((long)b * Lk + ki) * ldo + h * D;
+      float *ovp = dv + qsplit * kv_stride + ((long)b * Lk + ki) * ldo + h * D;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -1872,19 +1881,34 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
   }
 }
 
-// dq = dq_scale * (slab 0 + slab 1 + ...), in this order; rows x E floats per slab, dq rows ld floats apart
-__global__ __launch_bounds__(256) void attn_dq_fold_kernel(int chunks, long rows, int E4, const float *__restrict__ ws,
-                                                           long chunk_stride, float *__restrict__ dq, long ld,
-                                                           float scale) {
+// dst = scale * (slab 0 + slab 1 + ...), in this order, for up to three tensors in one launch (dQ over the key chunks;
+// dK and dV over the query splits): rows x E floats per slab, dst rows ld floats apart
+struct FoldSeg {
+  const float *ws;
+  float *dst;
+  long slab_stride, rows, ld, first;     // first: index of the segment's first float4 in the launch
+  int slabs;
+  float scale;
+};
+struct FoldArgs {
+  FoldSeg seg[3];
+  int nseg, E4;
+  long total;
+};
+__global__ __launch_bounds__(256) void attn_dq_fold_kernel(FoldArgs args) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= rows * E4) return;
-  const long r = i / E4;
-  const int c = (int)(i - r * E4);
-  f32x4 a = *reinterpret_cast<const f32x4 *>(ws + 4 * i);
-  for (int ch = 1; ch < chunks; ++ch) a += *reinterpret_cast<const f32x4 *>(ws + ch * chunk_stride + 4 * i);
-  *reinterpret_cast<f32x4 *>(dq + r * ld + 4 * c) = a * scale;
+  if (i >= args.total) return;
+  int sgi = 0;
+  if (args.nseg > 1 && i >= args.seg[1].first) sgi = 1;
+  if (args.nseg > 2 && i >= args.seg[2].first) sgi = 2;
+  const FoldSeg &sg = args.seg[sgi];
+  const long j = i - sg.first;
+  const long r = j / args.E4;
+  const int c = (int)(j - r * args.E4);
+  f32x4 a = *reinterpret_cast<const f32x4 *>(sg.ws + 4 * j);
+  for (int ch = 1; ch < sg.slabs; ++ch) a += *reinterpret_cast<const f32x4 *>(sg.ws + ch * sg.slab_stride + 4 * j);
+  *reinterpret_cast<f32x4 *>(sg.dst + r * sg.ld + 4 * c) = a * sg.scale;
 }
-
 
 // =====================================================================================================================
 // bf16 operating point (BASELINE configs[3]), round 5: bf16 LDS IMAGES.
@@ -2568,16 +2592,17 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_h_kernel(
 }
 
 template <int WAVES, int SUB>
-int launch_longk(int chunks, int B, int H, int Lq, int Lk, int D, const float *q, const float *k, const float *v,
-                        const uint8_t *mask, const float *out, const float *dout, const float *lse, float *ws, long E,
-                        long chunk_stride, float *dk, float *dv, long ld_dkv, float p, uint32_t site,
-                        const uint64_t *rng_counter, hipStream_t s) {
+int launch_longk(int chunks, int q_splits, int q_tiles_per_wg, int B, int H, int Lq, int Lk, int D, const float *q,
+                 const float *k, const float *v, const uint8_t *mask, const float *out, const float *dout,
+                 const float *lse, float *dq_out, long ld_dq, long chunk_stride, float dq_scale, float *dk, float *dv,
+                 long ld_dkv, long kv_stride, float p, uint32_t site, const uint64_t *rng_counter, hipStream_t s) {
   const size_t bytes = sizeof(float) * (size_t)longk_lds_floats<9>(36, WAVES);
   static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_longk_kernel<9, 3, WAVES, SUB>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr != hipSuccess) return (int)attr;
-  hipLaunchKernelGGL((attn_bwd_longk_kernel<9, 3, WAVES, SUB>), dim3(chunks, H, B), dim3(WAVES * 64), bytes, s, H, Lq, Lk, D, q, k,
-                     v, mask, out, dout, lse, ws, E, chunk_stride, 1.f, dk, dv, ld_dkv, p, site, rng_counter);
+  hipLaunchKernelGGL((attn_bwd_longk_kernel<9, 3, WAVES, SUB>), dim3(chunks * q_splits, H, B), dim3(WAVES * 64), bytes, s, H, Lq,
+                     Lk, D, q, k, v, mask, out, dout, lse, dq_out, ld_dq, chunk_stride, dq_scale, dk, dv, ld_dkv, kv_stride,
+                     chunks, q_tiles_per_wg, p, site, rng_counter);
   return 0;
 }
 
@@ -2674,31 +2699,53 @@ int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const flo
   return 0;
 }
 
-/* (include/butd_attention.h)  Keys per workgroup, measured at 8 x 8 heads (scratch/attn_longk_bench.py, dropout 0.1, us:
- * two kernels | 64-key chunks | 128 | 256):  1024 x 1024: 426 | 372 | 341 | 312;  256 x 1024: 135 | 109 | 108 | 100;
- * 80 x 1024: 102 | 68 | 68 | 63;  256 x 256: 49 | 42 | 53 | 91;  256 x 132: 47 | 41 | 54 | 84;  80 x 80: 30 | 24 | 30 | 47;
- * 256 x 80: 39 | 39 | 49 | 82;  1024 x 132: 126 | 126 | 168 | 298;  1024 x 80: 114 | 126 (short-key kernel: 90);  1024 x 512: 254 | . | . | 307.
- * So: 256 keys (8 waves x 2 sub-tiles) where that gives >= 192 workgroups; else 64 keys (4 waves x 1) for <= 256 queries
- * where THAT gives >= 128 workgroups; else not served.  g_longk_force: tuning hook (0 = the rule; 256 / 128 / 64). */
-static int g_longk_force = 0;
-int butd_attention_bwd_long_keys_set_chunk(int keys) { g_longk_force = keys; return 0; }   /* timing experiments only */
-static int longk_chunk(int B, int H, int Lq, int Lk, int D) {
-  if (D != 36) return 0;
-  if (g_longk_force) return g_longk_force;
-  const long bh = (long)B * H;
-  if ((long)((Lk + 255) / 256) * bh >= 192) return 256;
-  if (Lq <= 256 && (long)((Lk + 63) / 64) * bh >= 128) return 64;
+/* (include/butd_attention.h)  The plan of a call: keys per workgroup and query splits.  Measured at 8 x 8 heads
+ * (scratch/attn_longk_bench.py, dropout 0.1, us).  Keys per workgroup, one split -- two kernels | 64 | 128 | 256:
+ *   1024 x 1024: 426 | 372 | 341 | 312;  256 x 1024: 135 | 109 | 108 | 100;  80 x 1024: 102 | 68 | 68 | 63;
+ *   256 x 256: 49 | 42 | 53 | 91;  256 x 132: 47 | 41 | 54 | 84;  1024 x 132: 126 | 126 | 168 | 298.
+ * Query splits with 64-key chunks -- two kernels (short-key kernel) | 1 | 2 | 4 | 8 | 16 splits:
+ *   1024 x 132: 118 (133) | 126 | 104 | 93 | 103 | 123;  1024 x 80: 108 (89) | 123 | 73 | 64 | 72 | 90;
+ *   256 x 80: 37 (60) | 41 | 29 | 30 | 30;  256 x 132: 45 (94) | 42 | 40 | 46;  256 x 256: 49 | 45 | 46 | 55;  80 x 80: 29 | 25 | 20 | 20.
+ * So: 256 keys (8 waves x 2 sub-tiles), one split, where that gives >= 192 workgroups; else 64 keys (4 waves x 1) with
+ * the queries split so that about 512 workgroups exist (dK / dV then go through per-split slabs like dQ).
+ * g_longk_force_*: tuning hook (0 = the rule). */
+struct LongkPlan { int chunk, chunks, q_splits, q_tiles_per_wg; };
+static int g_longk_force_chunk = 0, g_longk_force_splits = 0;
+int butd_attention_bwd_long_keys_set_chunk(int keys, int q_splits) {   /* timing experiments only */
+  g_longk_force_chunk = keys;
+  g_longk_force_splits = q_splits;
   return 0;
+}
+static LongkPlan longk_plan(int B, int H, int Lq, int Lk, int D) {
+  LongkPlan p = {0, 0, 1, 0};
+  if (D != 36) return p;
+  const long bh = (long)B * H;
+  const int tiles = (Lq + 63) / 64;
+  int want = 1;
+  if (g_longk_force_chunk) p.chunk = g_longk_force_chunk;
+  else if ((long)((Lk + 255) / 256) * bh >= 192) p.chunk = 256;
+  else {
+    p.chunk = 64;
+    const long x = (long)((Lk + 63) / 64) * bh;
+    want = (int)((512 + x - 1) / x);
+  }
+  if (g_longk_force_splits) want = g_longk_force_splits;
+  p.chunks = (Lk + p.chunk - 1) / p.chunk;
+  want = want < 1 ? 1 : (want > tiles ? tiles : want);
+  p.q_tiles_per_wg = (tiles + want - 1) / want;
+  p.q_splits = (tiles + p.q_tiles_per_wg - 1) / p.q_tiles_per_wg;
+  if (!g_longk_force_chunk && (long)p.chunks * p.q_splits * bh < 128) p.chunk = 0;     // would leave the part idle
+  return p;
 }
 
 long butd_attention_bwd_long_keys_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
-  const int chunk = longk_chunk(B, H, Lq, Lk, D);
-  if (!chunk) return -1;
+  const LongkPlan p = longk_plan(B, H, Lq, Lk, D);
+  if (!p.chunk) return -1;
   if (ld_dq == 0) ld_dq = (long)H * D;
   if (ld_dq & 3) return -1;
-  const long chunks = (Lk + chunk - 1) / chunk;
-  return chunks * B * Lq * H * D;
+  const long E = (long)H * D;
+  return (p.chunks > 1 ? (long)p.chunks * B * Lq * E : 0) + (p.q_splits > 1 ? 2L * p.q_splits * B * Lk * E : 0);
 }
 
 int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
@@ -2707,25 +2754,45 @@ int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const floa
                                  long ld_dkv, float dq_scale, float dropout_p, uint32_t dropout_site,
                                  const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream) {
   const long need = butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ld_dq);
-  if (need < 0 || !ws || ws_floats < need) return (int)hipErrorInvalidValue;
+  if (need < 0 || (need > 0 && !ws) || ws_floats < need) return (int)hipErrorInvalidValue;
   if (ld_dq == 0) ld_dq = (long)H * D;
   if (ld_dkv == 0) ld_dkv = (long)H * D;
-  if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
+  if (ld_dq < (long)H * D || ld_dkv < (long)H * D || (ld_dkv & 3)) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
-  const int chunk = longk_chunk(B, H, Lq, Lk, D);
-  const int chunks = (Lk + chunk - 1) / chunk;
-  const long E = (long)H * D, chunk_stride = (long)B * Lq * E;
+  const LongkPlan p = longk_plan(B, H, Lq, Lk, D);
+  const long E = (long)H * D, q_slab = (long)B * Lq * E, kv_slab = (long)B * Lk * E;
+  const bool dq_slabs = p.chunks > 1, kv_slabs = p.q_splits > 1;
+  float *ws_q = ws, *ws_k = ws + (dq_slabs ? p.chunks * q_slab : 0), *ws_v = ws_k + (kv_slabs ? p.q_splits * kv_slab : 0);
   int err;
-#define LONGK(W, S) launch_longk<W, S>(chunks, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, ws, E, chunk_stride, dk, dv, ld_dkv, dropout_p, dropout_site, rng_counter, s)
-  if (chunk == 256) err = LONGK(8, 2);
-  else if (chunk == 128) err = LONGK(8, 1);
-  else if (chunk == 64) err = LONGK(4, 1);
+#define LONGK(W, S)                                                                                                          \
+  launch_longk<W, S>(p.chunks, p.q_splits, p.q_tiles_per_wg, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse,      \
+                     dq_slabs ? ws_q : dq, dq_slabs ? E : ld_dq, dq_slabs ? q_slab : 0, dq_slabs ? 1.f : dq_scale,            \
+                     kv_slabs ? ws_k : dk, kv_slabs ? ws_v : dv, kv_slabs ? E : ld_dkv, kv_slabs ? kv_slab : 0, dropout_p,    \
+                     dropout_site, rng_counter, s)
+  if (p.chunk == 256) err = LONGK(8, 2);
+  else if (p.chunk == 128) err = LONGK(8, 1);
+  else if (p.chunk == 64) err = LONGK(4, 1);
   else return (int)hipErrorInvalidValue;
 #undef LONGK
   if (err) return err;
-  const long rows = (long)B * Lq, n4 = rows * (E / 4);
-  hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, chunks, rows, (int)(E / 4), ws,
-                     chunk_stride, dq, ld_dq, dq_scale);
+  if (dq_slabs || kv_slabs) {
+    FoldArgs fa;
+    fa.nseg = 0;
+    fa.E4 = (int)(E / 4);
+    fa.total = 0;
+    auto add = [&](const float *src, float *dst, int slabs, long stride, long rows, long ld, float scale) {
+      FoldSeg &g = fa.seg[fa.nseg++];
+      g.ws = src; g.dst = dst; g.slabs = slabs; g.slab_stride = stride; g.rows = rows; g.ld = ld; g.scale = scale;
+      g.first = fa.total;
+      fa.total += rows * (E / 4);
+    };
+    if (dq_slabs) add(ws_q, dq, p.chunks, q_slab, (long)B * Lq, ld_dq, dq_scale);
+    if (kv_slabs) {
+      add(ws_k, dk, p.q_splits, kv_slab, (long)B * Lk, ld_dkv, 1.f);
+      add(ws_v, dv, p.q_splits, kv_slab, (long)B * Lk, ld_dkv, 1.f);
+    }
+    hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((fa.total + 255) / 256)), dim3(256), 0, s, fa);
+  }
   return (int)hipGetLastError();
 }
 

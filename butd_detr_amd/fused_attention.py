@@ -151,22 +151,25 @@ def set_short_keys(flag):
     return prev
 
 
-def _short_key_bwd(Lq, Lk):
-    """The single-pass backward (``butd_attention_bwd_short_keys``: dk / dv accumulated, caller zero-fills) serves this
-    call.  Measured (profiles/r04_attention_short_keys.txt, 8 x 8 heads): it wins where a workgroup walks several
-    query tiles over one staged key set -- 1024 x 80: 88 us vs 115 us for the two kernels -- and loses where its dK / dV
-    atomics are not amortised: 256 x 80: 58 vs 40 us, 256 x 132: 91 vs 47, 1024 x 132: 135 vs 123 (float atomics cost
-    ~25 ns per thousand on this part)."""
+_long_keys = [switches.flag("attn_long_keys", True)]
+
+
+def _short_key_bwd(Lq, Lk, B=0, H=0, D=0):
+    """The round-4 single-pass backward for short key sets (``butd_attention_bwd_short_keys``: dk / dv accumulated with
+    atomics, caller zero-fills) serves this call: only where the round-5 one-pass kernel (no atomics; 1024 x 80: 64 us
+    against 89) does not -- other head dimensions, or BUTD_AB=attn_long_keys=0.  Measured for that case
+    (profiles/r04_attention_short_keys.txt, 8 x 8 heads): it wins where a workgroup walks several query tiles over one
+    staged key set -- 1024 x 80: 88 us vs 115 us for the two kernels -- and loses where its dK / dV atomics are not
+    amortised: 256 x 80: 58 vs 40 us, 256 x 132: 91 vs 47, 1024 x 132: 135 vs 123."""
     if not _short_keys[0] or _compute_bf16[0] or Lk > _SHORT_KEYS_MAX:
+        return False
+    if _long_keys[0] and B and int(_lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, 0)) >= 0:
         return False
     return Lq >= 512 and Lk <= 80
 
 
-_long_keys = [switches.flag("attn_long_keys", True)]
-
-
 def set_long_keys(flag):
-    """A/B switch (BUTD_AB=attn_long_keys=0): the one-pass backward for key sets of >= 512 rows."""
+    """A/B switch (BUTD_AB=attn_long_keys=0): the one-pass backward (butd_attention_bwd_long_keys)."""
     prev, _long_keys[0] = _long_keys[0], bool(flag)
     return prev
 
@@ -472,7 +475,7 @@ class _AttentionBlock(torch.autograd.Function):
         d_att = torch.empty((B, Lq, E), device=dev)
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
                _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)] + fold, xq)
-        short = _short_key_bwd(Lq, Lk)
+        short = _short_key_bwd(Lq, Lk, B, H, D)
         dq = torch.empty((B, Lq, E), device=dev)
         dk = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
         dv = zeros((B, Lk, E), device=dev) if short else torch.empty((B, Lk, E), device=dev)
@@ -817,7 +820,7 @@ class _XpmBlock(torch.autograd.Function):
         _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
                _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)] + fold, x)
         # gradients of the attention core, packed: self: G = [dq | dk | dv]; cross: dq, G = [dk | dv]
-        short = _short_key_bwd(Lq, Lk)      # (one kernel that ACCUMULATES dk / dv: zero-filled from the step's arena)
+        short = _short_key_bwd(Lq, Lk, B, H, D)      # (one kernel that ACCUMULATES dk / dv: zero-filled from the step's arena)
         new_g = (lambda shape: zeros(shape, device=dev)) if short else (lambda shape: torch.empty(shape, device=dev))
         if self_attn:
             G = new_g((B, Lq, 3 * E))

@@ -11,7 +11,7 @@ profiles/r04_panel_chain.txt, r04_side_branches.txt, r04_attention_short_keys.tx
 import os
 
 KNOWN = {
-    "attn_long_keys":   "one-pass attention backward for >= 512 keys (fused_attention)",
+    "attn_long_keys":   "one-pass attention backward, butd_attention_bwd_long_keys (fused_attention)",
     "attn_short_keys":  "one-kernel attention backward where Lq >= 512 and Lk <= 80 (fused_attention)",
     "ln_fold":          "LayerNorm backward: dgamma / dbeta partials folded by the next grouped launch (fused_attention)",
     "wgrad_slabs":      "(default OFF) deterministic split-K weight gradients: partial slabs + ride-along folds instead of float atomics; bit-reproducible, +0.8 ms per step (fused_attention)",

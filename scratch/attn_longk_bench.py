@@ -24,9 +24,9 @@ st = lambda: torch.cuda.current_stream().cuda_stream
 import os
 SHAPES = ((1024, 1024, False), (256, 1024, False), (80, 1024, False), (1024, 512, False), (1000, 1000, True), (2048, 2048, False))
 if os.environ.get("SHAPES") == "short":
-    SHAPES = ((256, 256, False), (256, 80, True), (256, 132, True), (1024, 132, True), (1024, 80, True), (80, 80, True),
-              (256, 1024, False), (80, 1024, False), (1024, 1024, False))
-CHUNKS = [int(c) for c in os.environ.get("CHUNKS", "0").split(",")]          # 0 = the library's rule
+    SHAPES = ((256, 256, False), (256, 80, True), (256, 132, True), (1024, 132, True), (1024, 80, True), (80, 80, True))
+# PLANS: "keys per workgroup:query splits" (0 = the library's rule), e.g. PLANS=0:0,64:1,64:4,64:8
+CHUNKS = [tuple(int(x) for x in c.split(":")) for c in os.environ.get("PLANS", "0:0").split(",")]
 for Lq, Lk, masked in SHAPES:
     torch.manual_seed(Lq + Lk)
     q, do = torch.randn(B, Lq, E, device=dev), torch.randn(B, Lq, E, device=dev)
@@ -39,7 +39,7 @@ for Lq, Lk, masked in SHAPES:
             mask[1, 100:400] = 1
     mp = mask.data_ptr() if mask is not None else None
     o, lse, delta = torch.empty_like(q), torch.empty(B, H, Lq, device=dev), torch.empty(B, H, Lq, device=dev)
-    for p in (0.0, 0.1):
+    for p in ((0.1,) if os.environ.get("SHAPES") == "short" else (0.0, 0.1)):
         lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), lse.data_ptr(), p, 5, ctr, st())
         G, Gq = torch.empty(B, Lk, 3 * E, device=dev), torch.empty(B, Lq, 3 * E, device=dev)
         args = lambda: (B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, o.data_ptr(), do.data_ptr(), lse.data_ptr())
@@ -53,10 +53,10 @@ for Lq, Lk, masked in SHAPES:
             short = lambda: lib.butd_attention_bwd_short_keys(*args(), delta.data_ptr(), *outs(), st())
             line += f" short-key kernel {tg(short):7.1f} us |"
         for chunk in CHUNKS:
-            lib.butd_attention_bwd_long_keys_set_chunk(chunk)
+            lib.butd_attention_bwd_long_keys_set_chunk(*chunk)
             need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, 3 * E))
             if need < 0:
-                line += f" chunk {chunk}: not served |"
+                line += f" {chunk[0]}:{chunk[1]} not served |"
                 continue
             ws = torch.empty(max(need, 1), device=dev)
             one = lambda: lib.butd_attention_bwd_long_keys(*args(), *outs(), ws.data_ptr(), need, st())
@@ -67,6 +67,6 @@ for Lq, Lk, masked in SHAPES:
             for name, t, rt, lo in (("dq", Gq, refq, 0), ("dk", G, ref, E), ("dv", G, ref, 2 * E)):
                 a, r = t[:, :, lo:lo + E].double(), rt[:, :, lo:lo + E].double()
                 worst = max(worst, float((a - r).abs().max() / r.abs().max()))
-            line += f" chunk {chunk}: {tg(one):7.1f} us (err {worst:.0e}) |"
-        lib.butd_attention_bwd_long_keys_set_chunk(0)
+            line += f" {chunk[0]}:{chunk[1]} {tg(one):6.1f} ({worst:.0e}) |"
+        lib.butd_attention_bwd_long_keys_set_chunk(0, 0)
         print(line, flush=True)

@@ -432,16 +432,20 @@ def test_short_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, 
         _close(a, bq, 1e-5 if name != "padding" else 1e-12)
 
 
-@pytest.mark.parametrize("B,Lq,Lk,masked,p", [(8, 1024, 1024, False, 0.1), (8, 256, 1024, False, 0.1), (8, 80, 1024, True, 0.1),
-                                              (2, 1000, 1000, True, 0.1), (3, 70, 513, True, 0.0), (1, 200, 2048, False, 0.1),
-                                              (2, 1, 700, True, 0.1), (8, 256, 256, False, 0.1), (8, 256, 132, True, 0.1),
-                                              (8, 80, 80, True, 0.1), (2, 256, 600, True, 0.0), (3, 33, 300, True, 0.1)])
-def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p):
-    """butd_attention_bwd_long_keys (one pass: a workgroup owns 256 keys and walks all queries, every score tile computed
-    once, dQ through per-chunk slabs folded in chunk order, delta formed while staging; 64-key chunks for <= 256 queries
-    over shorter key sets) against butd_attention_bwd on the same saved forward: same dropout masks (same hash), equal
-    to fp32 summation order (1e-5 of the scale), padding columns of the packed gradients untouched, and
-    bit-reproducible."""
+@pytest.mark.parametrize("B,Lq,Lk,masked,p,force", [
+    (8, 1024, 1024, False, 0.1, None), (8, 256, 1024, False, 0.1, None), (8, 80, 1024, True, 0.1, None),
+    (8, 256, 256, False, 0.1, None), (8, 256, 132, True, 0.1, None), (8, 80, 80, True, 0.1, None),
+    (8, 1024, 132, True, 0.1, None), (8, 1024, 80, True, 0.1, None), (8, 1024, 512, False, 0.0, None),
+    (2, 1000, 1000, True, 0.1, (256, 1)), (2, 1000, 1000, True, 0.1, (256, 3)), (3, 70, 513, True, 0.0, (256, 2)),
+    (1, 200, 2048, False, 0.1, (256, 1)), (2, 1, 700, True, 0.1, (256, 1)), (2, 256, 600, True, 0.0, (128, 2)),
+    (3, 33, 300, True, 0.1, (64, 1)), (2, 333, 77, True, 0.1, (64, 6)), (2, 130, 5, True, 0.1, (64, 3))])
+def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p, force):
+    """butd_attention_bwd_long_keys (one pass: a workgroup owns a chunk of 256 / 64 keys and walks its share of the
+    queries, every score tile computed once; dQ through per-chunk slabs and, when the queries are split over several
+    workgroups, dK / dV through per-split slabs, folded in order by one element-wise launch; delta formed while
+    staging) against butd_attention_bwd on the same saved forward: same dropout masks (same hash), equal to fp32
+    summation order (1e-5 of the scale), padding columns of the packed gradients untouched, and bit-reproducible.
+    ``force``: (keys per workgroup, query splits) through the tuning hook, for shapes / plans the rule does not pick."""
     _, fa, _, _ = mods
     from butd_detr_amd import _hiplib
     lib = _hiplib.load()
@@ -466,42 +470,41 @@ def test_long_key_backward_equals_two_kernel_backward(mods, B, Lq, Lk, masked, p
     assert lib.butd_attention_fwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
                                   lse.data_ptr(), p, 5, ctr.data_ptr(), st) == 0
     ldq, ldkv = E + 8, 2 * E + 4
-    assert lib.butd_attention_bwd_long_keys_scratch(8, H, 1024, 132, D, ldq) == -1     # many queries, few keys: not served
     assert lib.butd_attention_bwd_long_keys_scratch(1, 1, 64, 64, D, ldq) == -1        # would leave the part idle
     assert lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, 32, ldq) == -1       # other head dimensions: not served
-    # the library's rule (attention_ops.hip, longk_chunk); shapes it leaves to the two kernels run here with a forced chunk
-    chunk = 256 if ((Lk + 255) // 256) * B * H >= 192 else 64 if (Lq <= 256 and ((Lk + 63) // 64) * B * H >= 128) else 0
-    need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ldq))
-    forced = chunk == 0
-    if forced:
-        assert need == -1
-        chunk = 256 if Lk >= 512 else 128 if Lk >= 200 else 64
-        lib.butd_attention_bwd_long_keys_set_chunk(chunk)
+    assert lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, E + 2) == -1      # dq rows not 16-byte aligned
+    if force is not None:
+        lib.butd_attention_bwd_long_keys_set_chunk(*force)
+    try:
         need = int(lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ldq))
-    assert need == ((Lk + chunk - 1) // chunk) * B * Lq * E
-    res = {}
-    for name in ("two", "one", "one again"):
-        dqb = torch.full((B, Lq, ldq), 7.0, device=dev)       # dq rows wider than E
-        G = torch.full((B, Lk, ldkv), 7.0, device=dev)        # dk | dv side by side, rows wider than 2E
-        if name == "two":
-            delta = torch.empty(B, H, Lq, device=dev)
-            assert lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
-                                          do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqb.data_ptr(), G.data_ptr(),
-                                          G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5, ctr.data_ptr(), st) == 0
-        else:
-            ws = torch.full((need,), float("nan"), device=dev)
-            assert lib.butd_attention_bwd_long_keys(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp,
-                                                    out.data_ptr(), do.data_ptr(), lse.data_ptr(), dqb.data_ptr(),
-                                                    G.data_ptr(), G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5,
-                                                    ctr.data_ptr(), ws.data_ptr(), need, st) == 0
-            assert lib.butd_attention_bwd_long_keys(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp,
-                                                    out.data_ptr(), do.data_ptr(), lse.data_ptr(), dqb.data_ptr(),
-                                                    G.data_ptr(), G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5,
-                                                    ctr.data_ptr(), ws.data_ptr(), need - 1, st) != 0      # workspace too small
-        torch.cuda.synchronize()
-        res[name] = (dqb[:, :, :E].clone(), G[:, :, :E].clone(), G[:, :, E:2 * E].clone(), dqb[:, :, E:].clone(),
-                     G[:, :, 2 * E:].clone())
-    lib.butd_attention_bwd_long_keys_set_chunk(0)
+        assert need >= 0
+        if force is not None:
+            chunks, tiles = (Lk + force[0] - 1) // force[0], (Lq + 63) // 64
+            per = (tiles + min(force[1], tiles) - 1) // min(force[1], tiles)
+            splits = (tiles + per - 1) // per
+            assert need == (chunks * B * Lq * E if chunks > 1 else 0) + (2 * splits * B * Lk * E if splits > 1 else 0)
+        res = {}
+        for name in ("two", "one", "one again"):
+            dqb = torch.full((B, Lq, ldq), 7.0, device=dev)       # dq rows wider than E
+            G = torch.full((B, Lk, ldkv), 7.0, device=dev)        # dk | dv side by side, rows wider than 2E
+            if name == "two":
+                delta = torch.empty(B, H, Lq, device=dev)
+                assert lib.butd_attention_bwd(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
+                                              do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqb.data_ptr(), G.data_ptr(),
+                                              G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5, ctr.data_ptr(), st) == 0
+            else:
+                ws = torch.full((max(need, 1),), float("nan"), device=dev)
+                args = (B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(), do.data_ptr(),
+                        lse.data_ptr(), dqb.data_ptr(), G.data_ptr(), G.data_ptr() + 4 * E, ldq, ldkv, 0.5, p, 5,
+                        ctr.data_ptr(), ws.data_ptr())
+                assert lib.butd_attention_bwd_long_keys(*args, need, st) == 0
+                if need > 0:
+                    assert lib.butd_attention_bwd_long_keys(*args, need - 1, st) != 0      # workspace too small
+            torch.cuda.synchronize()
+            res[name] = (dqb[:, :, :E].clone(), G[:, :, :E].clone(), G[:, :, E:2 * E].clone(), dqb[:, :, E:].clone(),
+                         G[:, :, 2 * E:].clone())
+    finally:
+        lib.butd_attention_bwd_long_keys_set_chunk(0, 0)
     for a, bq, name in zip(res["one"], res["two"], ("dq", "dk", "dv", "dq padding", "dkv padding")):
         assert torch.isfinite(a).all(), name
         if "padding" in name:
