@@ -179,14 +179,17 @@ int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const flo
                                   uint32_t dropout_site, const uint64_t *rng_counter, butd_stream_t stream);
 
 /* Backward of butd_attention_fwd as ONE pass that computes every score tile once (54 matrix instructions per 16 x 16
- * tile instead of 72, one softmax / dropout pass instead of two), for LONG KEY SETS (the 1024 seed points every encoder
- * layer attends over and the decoder / text streams cross-attend to, models/encoder_decoder_layers.py:60-85,356-375):
- * a workgroup owns a chunk of 256 keys and walks all queries; its dQ shares go to one slab of `ws` per chunk and a small
- * launch adds the slabs in chunk order (no atomics: bit-reproducible).  Also serves <= 256 queries over shorter key sets
- * with 64-key chunks where that fills the part (the decoder's self-attention).  Same arguments and results as
- * butd_attention_bwd (delta is formed inside).  fp32, head dimension 36.
- *   butd_attention_bwd_long_keys_scratch: floats of `ws` this call needs, or -1 when the shape is not served
- *   (the caller then uses butd_attention_bwd). */
+ * tile instead of 72, one softmax / dropout pass instead of two).  A workgroup owns a chunk of keys -- 256 for LONG KEY
+ * SETS (the 1024 seed points every encoder layer attends over and the decoder / text streams cross-attend to,
+ * models/encoder_decoder_layers.py:60-85,356-375), 64 otherwise -- keeps their fragments and dK / dV accumulators in
+ * registers and walks its share of the queries; what is summed ACROSS workgroups (dQ over the key chunks; dK / dV over
+ * the query splits of short key sets) goes to slabs of `ws` and one small launch adds the slabs in order: no atomics,
+ * bit-reproducible.  Same arguments and results as butd_attention_bwd (delta is formed inside).  fp32, head dimension 36.
+ *   butd_attention_bwd_long_keys_scratch: floats of `ws` this call needs (>= 0), or -1 when the shape is not served
+ *   (the caller then uses butd_attention_bwd).
+ *   butd_attention_bwd_long_keys_set_chunk: tuning hook -- (keys per workgroup: 256 / 128 / 64, query splits) of every
+ *   following call; (0, 0) returns to the built-in rule.  Not thread-safe. */
+int butd_attention_bwd_long_keys_set_chunk(int keys, int q_splits);
 long butd_attention_bwd_long_keys_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq);
 int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
                                  const float *v, const uint8_t *key_padding_mask, const float *out,

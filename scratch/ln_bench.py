@@ -9,7 +9,7 @@ lib = _hiplib.load()
 dev = torch.device("cuda", 0)
 E_ = 288
 out = []
-for rows in (640, 2048, 8192):
+for rows in (640, 2048, 8192, 65536):
     x, res, dy = (torch.randn(rows, E_, device=dev) for _ in range(3))
     gamma, beta = torch.randn(E_, device=dev), torch.randn(E_, device=dev)
     y, dx, dres = (torch.empty(rows, E_, device=dev) for _ in range(3))
@@ -20,10 +20,12 @@ for rows in (640, 2048, 8192):
     def fwd():
         lib.butd_add_dropout_layernorm_fwd(rows, E_, x.data_ptr(), res.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5,
                                            y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), 0.1, 7, ctr.data_ptr(), s.cuda_stream)
-    def bwd():
-        lib.butd_add_dropout_layernorm_bwd(rows, E_, dy.data_ptr(), x.data_ptr(), res.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                           rstd.data_ptr(), dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), 0.1, 7,
-                                           ctr.data_ptr(), s.cuda_stream)
+    nb = lib.butd_layernorm_bwd_blocks(rows)
+    part = torch.empty(nb, 2 * E_, device=dev)
+    def bwd():      # the product's form: per-workgroup partial sums of dgamma / dbeta, folded by the next grouped launch
+        lib.butd_add_dropout_layernorm_bwd_partial(rows, E_, dy.data_ptr(), x.data_ptr(), res.data_ptr(), gamma.data_ptr(),
+                                                   mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(), dres.data_ptr(),
+                                                   part.data_ptr(), 0.1, 7, ctr.data_ptr(), s.cuda_stream)
     with torch.cuda.stream(s):
         fwd(); bwd()
     torch.cuda.synchronize()
