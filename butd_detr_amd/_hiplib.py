@@ -158,6 +158,9 @@ CRITERION_SYMBOLS = {
     "butd_contrastive_rows": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P, _P]),
     "butd_seed_objectness": (_c_int, [_c_int] * 5 + [_P] * 10 + [_P]),
     "butd_loss_combine": (_c_int, [_c_int] + [_P] * 6 + [_c_int] + [_c_float] * 3 + [_P, _P]),
+    "butd_criterion_reduce": (_c_int, [_c_int, _P, _c_long, _P, _P, _c_long, _P, _c_long, _P, _c_long, _c_float, _P, _P, _c_int]
+                              + [_c_float] * 3 + [_P, _P, _P]),
+    "butd_criterion_scale": (_c_int, [_c_int, _P, _P, _P, _c_int] + [_c_float] * 4 + [_P, _P, _c_long] * 3 + [_P, _P]),
     "butd_loss_combine_bwd": (_c_int, [_c_int, _P, _P, _c_int] + [_c_float] * 3 + [_P] * 5 + [_P]),
     "butd_contrastive_cols": (_c_int, [_c_int] * 5 + [_P] * 3 + [_c_int, _P, _c_float, _P, _P, _P]),
 }

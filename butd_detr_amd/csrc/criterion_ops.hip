@@ -495,6 +495,94 @@ __global__ void loss_combine_bwd_kernel(int P, const float *g, const int *status
   if (i == 0 && d_generation) d_generation[0] = gv * w_gen;
 }
 
+// ---- the whole tail of compute_hungarian_loss in one workgroup (round 5) -------------------------------------------------
+// per prefix p: ce = sum ce_rows[p] / nb, bbox = box_sums[p][0] / nb, giou = box_sums[p][1] / nb,
+//               align = (sum align_rows[p] + sum align_cols[p]) / nb        (nb = the device scalar num_boxes)
+// generation = sum gen_elem / gen_div;  then loss_combine_kernel's expression.  One workgroup of 1024 threads walks the
+// prefixes (41 K floats at the bench shape): fixed order, no atomics.  The stock graph was 3 row reductions, 4 divisions,
+// the objectness reduction + division and the combine launch, each 4.6 us as a graph node.
+__device__ float block_sum_1024(float v, float *red) {
+  v = wave_sum_f32(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) t += red[w];
+  return t;
+}
+__global__ __launch_bounds__(1024) void criterion_reduce_kernel(
+    int P, const float *__restrict__ ce_rows, long n_ce, const float *__restrict__ box_sums,
+    const float *__restrict__ align_rows, long n_ar, const float *__restrict__ align_cols, long n_ac,
+    const float *__restrict__ gen_elem, long n_gen, float gen_div, const float *__restrict__ num_boxes,
+    const int *__restrict__ status_words, int nstatus, float w_gen, float w_sum, float w_bbox,
+    float *__restrict__ per_prefix, float *__restrict__ out6) {
+  __shared__ float red[16];
+  const float inv_nb = 1.f / num_boxes[0];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int p = 0; p < P; ++p) {
+    float ce = 0.f, al = 0.f;
+    if (ce_rows) {
+      float a = 0.f;
+      for (long i = threadIdx.x; i < n_ce; i += 1024) a += ce_rows[p * n_ce + i];
+      ce = block_sum_1024(a, red) * inv_nb;
+    }
+    if (align_rows) {
+      float a = 0.f;
+      for (long i = threadIdx.x; i < n_ar; i += 1024) a += align_rows[p * n_ar + i];
+      float b = 0.f;
+      for (long i = threadIdx.x; i < n_ac; i += 1024) b += align_cols[p * n_ac + i];
+      al = (block_sum_1024(a, red) + block_sum_1024(b, red)) * inv_nb;
+    }
+    const float bb = box_sums[2 * p] * inv_nb, gi = box_sums[2 * p + 1] * inv_nb;
+    if (threadIdx.x == 0) {
+      per_prefix[4 * p] = ce; per_prefix[4 * p + 1] = bb; per_prefix[4 * p + 2] = gi; per_prefix[4 * p + 3] = al;
+    }
+    s[0] += ce; s[1] += bb; s[2] += gi; s[3] += al;
+  }
+  float gen = 0.f;
+  if (gen_elem) {
+    float a = 0.f;
+    for (long i = threadIdx.x; i < n_gen; i += 1024) a += gen_elem[i];
+    gen = block_sum_1024(a, red) / gen_div;
+  }
+  if (threadIdx.x == 0) {
+    const float loss = w_gen * gen + w_sum * (((s[0] + w_bbox * s[1]) + s[2]) + s[3]);
+    bool bad = false;
+    for (int i = 0; i < nstatus; ++i) bad = bad || status_words[i] != 0;
+    out6[0] = bad ? nanf("") : loss;
+    out6[1] = s[0]; out6[2] = s[1]; out6[3] = s[2]; out6[4] = s[3]; out6[5] = gen;
+  }
+}
+
+// its gradient for an upstream device scalar g: the saved derivatives of the row sums times c = g w_sum / nb (0 when an
+// assignment failed), the objectness derivative times g w_gen / gen_div, and the (P, 2) weights of butd_box_loss_bwd --
+// three element-wise tensors in one launch (float4 where the tensor allows)
+__global__ __launch_bounds__(256) void criterion_scale_kernel(
+    int P, const float *__restrict__ g, const float *__restrict__ num_boxes, const int *__restrict__ status_words,
+    int nstatus, float w_gen, float w_sum, float w_bbox, float gen_div, const float *__restrict__ dx_ce,
+    float *__restrict__ d_logits, long n_ce, const float *__restrict__ dx_al, float *__restrict__ d_align, long n_al,
+    const float *__restrict__ dx_gen, float *__restrict__ d_seed, long n_gen, float *__restrict__ box_w) {
+  bool bad = false;
+  for (int j = 0; j < nstatus; ++j) bad = bad || status_words[j] != 0;
+  const float gv = bad ? 0.f : g[0];
+  const float c = gv * w_sum / num_boxes[0], cg = gv * w_gen / gen_div;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < 2 * P && box_w) box_w[i] = (i & 1) ? c : c * w_bbox;
+  const long q_ce = (n_ce + 3) >> 2, q_al = (n_al + 3) >> 2, q_gen = (n_gen + 3) >> 2;
+  auto scale4 = [&](const float *src, float *dst, long n, long q, float k) {
+    if (4 * q + 4 <= n && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+      const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
+      *reinterpret_cast<float4 *>(dst + 4 * q) = make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
+    } else {
+      for (long e = 4 * q; e < n && e < 4 * q + 4; ++e) dst[e] = src[e] * k;
+    }
+  };
+  if (i < q_ce) scale4(dx_ce, d_logits, n_ce, i, c);
+  else if (i < q_ce + q_al) scale4(dx_al, d_align, n_al, i - q_ce, c);
+  else if (i < q_ce + q_al + q_gen) scale4(dx_gen, d_seed, n_gen, i - q_ce - q_al, cg);
+}
+
 inline int status() { return (int)hipGetLastError(); }
 
 }  // namespace
@@ -599,6 +687,36 @@ int butd_loss_combine_bwd(int P, const float *g, const int *status_words, int ns
   if (P <= 0 || P > 64 || !g) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(kWave), 0, (hipStream_t)stream, P, g, status_words,
                      status_words ? nstatus : 0, w_gen, w_sum, w_bbox, d_ce, d_bbox, d_giou, d_align, d_generation);
+  return status();
+}
+
+int butd_criterion_reduce(int P, const float *ce_rows, long n_ce, const float *box_sums, const float *align_rows,
+                          long n_align_rows, const float *align_cols, long n_align_cols, const float *gen_elem,
+                          long n_gen, float gen_div, const float *num_boxes, const int *status_words, int nstatus,
+                          float w_gen, float w_sum, float w_bbox, float *per_prefix, float *out6,
+                          butd_stream_t stream) {
+  if (P <= 0 || P > 64 || !box_sums || !num_boxes || !per_prefix || !out6) return (int)hipErrorInvalidValue;
+  if ((align_rows == nullptr) != (align_cols == nullptr) || (gen_elem && gen_div == 0.f)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(criterion_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, P, ce_rows, n_ce, box_sums,
+                     align_rows, n_align_rows, align_cols, n_align_cols, gen_elem, n_gen, gen_div, num_boxes, status_words,
+                     status_words ? nstatus : 0, w_gen, w_sum, w_bbox, per_prefix, out6);
+  return status();
+}
+
+int butd_criterion_scale(int P, const float *g, const float *num_boxes, const int *status_words, int nstatus,
+                         float w_gen, float w_sum, float w_bbox, float gen_div, const float *dx_ce, float *d_logits,
+                         long n_ce, const float *dx_align, float *d_align, long n_align, const float *dx_gen,
+                         float *d_seed, long n_gen, float *box_w, butd_stream_t stream) {
+  if (P <= 0 || P > 64 || !g || !num_boxes) return (int)hipErrorInvalidValue;
+  if (!dx_ce) n_ce = 0;
+  if (!dx_align) n_align = 0;
+  if (!dx_gen) n_gen = 0;
+  if ((n_ce && !d_logits) || (n_align && !d_align) || (n_gen && (!d_seed || gen_div == 0.f))) return (int)hipErrorInvalidValue;
+  long q = ((n_ce + 3) >> 2) + ((n_align + 3) >> 2) + ((n_gen + 3) >> 2);
+  if (q < 2 * P) q = 2 * P;
+  hipLaunchKernelGGL(criterion_scale_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, g,
+                     num_boxes, status_words, status_words ? nstatus : 0, w_gen, w_sum, w_bbox, gen_div ? gen_div : 1.f,
+                     dx_ce, d_logits, n_ce, dx_align, d_align, n_align, dx_gen, d_seed, n_gen, box_w);
   return status();
 }
 

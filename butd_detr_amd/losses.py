@@ -570,8 +570,152 @@ class _CombineLosses(torch.autograd.Function):
         return (*grads, None, None, None, None)
 
 
+class _HungarianTail(torch.autograd.Function):
+    """Everything of compute_hungarian_loss behind the assignment as ONE autograd node (round 5): the term kernels of
+    include/butd_criterion.h back to back, then ``butd_criterion_reduce`` (row sums, the divisions by num_boxes, the sums
+    over the prefixes, the weighting, the NaN of a failed assignment: one launch); backward: ``butd_criterion_scale``
+    (the saved derivatives times g w / num_boxes, three tensors in one launch) + ``butd_box_loss_bwd``.  As separate
+    autograd nodes glued by torch expressions the same arithmetic was ~65 graph nodes of 4.6 us each.
+    Returns (loss, [ce, bbox, giou, align, generation] summed over the prefixes, per_prefix (P,4) = the four terms)."""
+
+    @staticmethod
+    def forward(ctx, pred_logits, pred_boxes, align_logits, seed_logits, cfg):
+        lib = _hiplib.load()
+        dev = pred_boxes.device
+        P, B, Q, _ = pred_boxes.shape
+        match, tgt_boxes, pmap, num_boxes, status = cfg["match"], cfg["tgt_boxes"], cfg["positive_map"], cfg["num_boxes"], cfg["status"]
+        G = tgt_boxes.shape[1]
+        eos = float(cfg["eos_coef"])
+        match = match.contiguous()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        st = None if status is None else status.detach().contiguous().view(-1).to(torch.int32)
+        nb = _f32c(num_boxes).reshape(-1)
+        with torch.cuda.device(dev):
+            stream = _stream(pred_boxes)
+            pred, tgt = _f32c(pred_boxes), _f32c(tgt_boxes)
+            sums = torch.empty((P, 2), device=dev)
+            box_grad = torch.empty((P, B, G, 12), device=dev)
+            _hiplib.check(lib.butd_box_loss(P, B, Q, G, pred.data_ptr(), tgt.data_ptr(), match.data_ptr(), sums.data_ptr(),
+                                            box_grad.data_ptr(), stream), "butd_box_loss")
+            ce_rows = dx_ce = None
+            if pred_logits is not None:
+                C = pred_logits.shape[-1]
+                x, pm = _f32c(pred_logits), _f32c(_pad_last(pmap, C))
+                ce_rows, dx_ce = torch.empty((P, B, Q), device=dev), torch.empty_like(x)
+                _hiplib.check(lib.butd_soft_token_ce(P, B, Q, G, C, x.data_ptr(), match.data_ptr(), pm.data_ptr(),
+                                                     pm.shape[-1], eos, ce_rows.data_ptr(), dx_ce.data_ptr(), stream),
+                              "butd_soft_token_ce")
+            rows = cols = dx_al = None
+            if align_logits is not None:
+                L_ = align_logits.shape[-1]
+                x, pm = _f32c(align_logits), _f32c(_pad_last(pmap, L_))
+                last = cfg["last"].to(torch.int32).contiguous()
+                rows, cols = torch.empty((P, B, Q), device=dev), torch.empty((P, B, L_), device=dev)
+                owner = torch.empty((P, B, Q), dtype=torch.int32, device=dev)
+                dx_al = torch.empty_like(x)
+                _hiplib.check(lib.butd_contrastive_rows(P, B, Q, G, L_, x.data_ptr(), match.data_ptr(), pm.data_ptr(),
+                                                        pm.shape[-1], last.data_ptr(), eos, rows.data_ptr(),
+                                                        dx_al.data_ptr(), owner.data_ptr(), stream), "butd_contrastive_rows")
+                _hiplib.check(lib.butd_contrastive_cols(P, B, Q, G, L_, x.data_ptr(), owner.data_ptr(), pm.data_ptr(),
+                                                        pm.shape[-1], last.data_ptr(), eos, cols.data_ptr(),
+                                                        dx_al.data_ptr(), stream), "butd_contrastive_cols")
+            elem = dx_gen = None
+            gen_div = 1.0
+            if seed_logits is not None:
+                g = cfg["generation"]
+                K, N = g["seed_xyz"].shape[1], g["pil"].shape[1]
+                x = _f32c(seed_logits).reshape(B, K)
+                xyz, gc, gs, bm = _f32c(g["seed_xyz"]), _f32c(g["gt_center"]), _f32c(g["gt_size"]), _f32c(g["mask"])
+                inds, pil = g["seed_inds"].to(torch.int32).contiguous(), g["pil"].to(torch.int64).contiguous()
+                label = torch.empty((B, K), dtype=torch.uint8, device=dev)
+                elem, dx_gen = torch.empty_like(x), torch.empty_like(x)
+                _hiplib.check(lib.butd_seed_objectness(B, K, gc.shape[1], N, int(g["topk"]), xyz.data_ptr(), inds.data_ptr(),
+                                                       pil.data_ptr(), gc.data_ptr(), gs.data_ptr(), bm.data_ptr(),
+                                                       x.data_ptr(), label.data_ptr(), elem.data_ptr(), dx_gen.data_ptr(),
+                                                       stream), "butd_seed_objectness")
+                gen_div = float(B)
+            buf = torch.empty(6 + 4 * P, device=dev)          # (the outputs are views of it, as _CombineLosses' were)
+            out6, per_prefix = buf[:6], buf[6:].view(P, 4)
+            w_gen, w_sum, w_bbox = cfg["weights"]
+            _hiplib.check(lib.butd_criterion_reduce(
+                P, ptr(ce_rows), 0 if ce_rows is None else B * Q, sums.data_ptr(), ptr(rows), 0 if rows is None else B * Q,
+                ptr(cols), 0 if cols is None else cols.shape[1] * cols.shape[2], ptr(elem), 0 if elem is None else elem.numel(),
+                gen_div, nb.data_ptr(), ptr(st), 0 if st is None else st.numel(), w_gen, w_sum, w_bbox,
+                per_prefix.data_ptr(), out6.data_ptr(), stream), "butd_criterion_reduce")
+        ctx.save_for_backward(match, box_grad, dx_ce, dx_al, dx_gen, nb, st)
+        ctx.cfg = (P, B, Q, G, w_gen, w_sum, w_bbox, gen_div,
+                   None if pred_logits is None else pred_logits.shape, None if align_logits is None else align_logits.shape,
+                   None if seed_logits is None else seed_logits.shape)
+        sums5 = buf[1:6]
+        ctx.mark_non_differentiable(sums5, per_prefix)
+        return buf[0], sums5, per_prefix
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        match, box_grad, dx_ce, dx_al, dx_gen, nb, st = ctx.saved_tensors
+        P, B, Q, G, w_gen, w_sum, w_bbox, gen_div, sh_ce, sh_al, sh_gen = ctx.cfg
+        lib = _hiplib.load()
+        dev = box_grad.device
+        g = _f32c(g).reshape(1)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        d_ce = None if dx_ce is None else torch.empty_like(dx_ce)
+        d_al = None if dx_al is None else torch.empty_like(dx_al)
+        d_gen = None if dx_gen is None else torch.empty_like(dx_gen)
+        box_w = torch.empty((P, 2), device=dev)
+        d_boxes = torch.empty((P, B, Q, 6), device=dev)
+        with torch.cuda.device(dev):
+            stream = _stream(box_grad)
+            _hiplib.check(lib.butd_criterion_scale(
+                P, g.data_ptr(), nb.data_ptr(), ptr(st), 0 if st is None else st.numel(), w_gen, w_sum, w_bbox, gen_div,
+                ptr(dx_ce), ptr(d_ce), 0 if dx_ce is None else dx_ce.numel(), ptr(dx_al), ptr(d_al),
+                0 if dx_al is None else dx_al.numel(), ptr(dx_gen), ptr(d_gen), 0 if dx_gen is None else dx_gen.numel(),
+                box_w.data_ptr(), stream), "butd_criterion_scale")
+            _hiplib.check(lib.butd_box_loss_bwd(P, B, Q, G, match.data_ptr(), box_grad.data_ptr(), box_w.data_ptr(),
+                                                d_boxes.data_ptr(), stream), "butd_box_loss_bwd")
+        return (d_ce if d_ce is None else d_ce.view(sh_ce), d_boxes, d_al if d_al is None else d_al.view(sh_al),
+                d_gen if d_gen is None else d_gen.view(sh_gen), None)
+
+
 def hungarian_prefixes(num_decoder_layers):
     return ["proposal_", "last_"] + [f"{i}head_" for i in range(num_decoder_layers - 1)]
+
+
+_TAIL = [True]      # (tests: the single-node tail of compute_hungarian_loss vs the term-by-term autograd graph)
+
+
+def _hungarian_tail(end_points, prefixes, num_decoder_layers, crit, out, tgt, match, topk):
+    """compute_hungarian_loss behind the stacking of the prefixes, CUDA tensors, fused backend: the assignment, then
+    ``_HungarianTail`` (one autograd node).  Writes the same keys into ``end_points`` as the term-by-term path."""
+    if match is None:
+        match = crit.matcher.match_dense(out["pred_logits"], out["pred_boxes"], tgt["boxes"], tgt["positive_map"],
+                                         tgt["valid"], tgt.get("labels"))
+    status = getattr(crit.matcher, "last_status", None)
+    num_boxes = tgt["num_boxes"] if tgt.get("num_boxes") is not None else crit.num_boxes(tgt["valid"])
+    cfg = {"match": match, "tgt_boxes": tgt["boxes"], "positive_map": tgt["positive_map"], "num_boxes": num_boxes,
+           "status": status, "eos_coef": crit.eos_coef, "weights": (8.0, 1.0 / (num_decoder_layers + 1), 5.0)}
+    align_logits = None
+    if "contrastive_align" in crit.losses and "proj_tokens" in end_points:
+        align_logits = torch.matmul(out["proj_queries"], out["proj_tokens"].transpose(-1, -2)) / crit.temperature
+        # 'not mentioned': the last real token (python indexing: -1 wraps to the last column)
+        cfg["last"] = out["tokenized"]["attention_mask"].to(align_logits.device).sum(1) - 1
+    seed_logits = None
+    if "seeds_obj_cls_logits" in end_points:
+        seed_logits = end_points["seeds_obj_cls_logits"]
+        cfg["generation"] = {"seed_xyz": end_points["seed_xyz"], "seed_inds": end_points["seed_inds"],
+                             "pil": end_points["point_instance_label"], "gt_center": end_points["center_label"][:, :, :3],
+                             "gt_size": end_points["size_gts"][:, :, :3], "mask": end_points["box_label_mask"], "topk": topk}
+    logits = out["pred_logits"] if "labels" in crit.losses else None
+    loss, sums5, per_prefix = _HungarianTail.apply(logits, out["pred_boxes"], align_logits, seed_logits, cfg)
+    names = (("loss_ce", 0, logits is not None), ("loss_bbox", 1, True), ("loss_giou", 2, True),
+             ("loss_contrastive_align", 3, align_logits is not None))
+    for key, col, present in names:
+        if present:
+            for i, p in enumerate(prefixes):
+                end_points[f"{p}_{key}"] = per_prefix[i, col]
+    end_points.update({"loss_ce": sums5[0], "loss_bbox": sums5[1], "loss_giou": sums5[2],
+                       "query_points_generation_loss": sums5[4], "loss_constrastive_align": sums5[3], "loss": loss,
+                       "hungarian_match": match, "hungarian_status": status})
+    return loss, end_points
 
 
 def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_points_obj_topk=5, match=None):
@@ -589,6 +733,10 @@ def compute_hungarian_loss(end_points, num_decoder_layers, set_criterion, query_
         out["proj_tokens"] = end_points["proj_tokens"]
         out["proj_queries"] = stack("proj_queries")
         out["tokenized"] = end_points["tokenized"]
+    if (_TAIL[0] and _fused(out["pred_boxes"]) and len(prefixes) <= 64 and "boxes" in set_criterion.losses
+            and set(set_criterion.losses) <= {"boxes", "labels", "contrastive_align"}):
+        return _hungarian_tail(end_points, prefixes, num_decoder_layers, set_criterion, out, tgt, match,
+                               query_points_obj_topk)
     losses, match = set_criterion.dense_forward(out, tgt, match)
     for key, per_prefix in losses.items():
         for i, p in enumerate(prefixes):

@@ -99,6 +99,29 @@ int butd_loss_combine_bwd(int P, const float *g, const int *status_words, int ns
                           float w_bbox, float *d_ce, float *d_bbox, float *d_giou, float *d_align, float *d_generation,
                           butd_stream_t stream);
 
+/* The whole tail of compute_hungarian_loss (losses.py:546-617) in ONE launch (round 5): per prefix p
+ *   ce = sum ce_rows[p] / nb,  bbox = box_sums[p][0] / nb,  giou = box_sums[p][1] / nb,
+ *   align = (sum align_rows[p] + sum align_cols[p]) / nb                  -> per_prefix (P,4)
+ * (ce_rows (P, n_ce): butd_soft_token_ce's rows; box_sums (P,2): butd_box_loss; align_rows / _cols: butd_contrastive_rows /
+ * _cols; nb = *num_boxes, a device scalar), generation = sum gen_elem / gen_div (butd_seed_objectness's elem_loss), and
+ * butd_loss_combine's expression:  out6 = [loss, sum ce, sum bbox, sum giou, sum align, generation].  ce_rows, the align
+ * pair and gen_elem may be NULL.  One workgroup, fixed order: bit-reproducible.  P <= 64. */
+int butd_criterion_reduce(int P, const float *ce_rows, long n_ce, const float *box_sums, const float *align_rows,
+                          long n_align_rows, const float *align_cols, long n_align_cols, const float *gen_elem,
+                          long n_gen, float gen_div, const float *num_boxes, const int *status_words, int nstatus,
+                          float w_gen, float w_sum, float w_bbox, float *per_prefix, float *out6,
+                          butd_stream_t stream);
+
+/* Its gradient for an upstream device scalar g, in one launch: with c = g w_sum / nb (0 when any status word is nonzero)
+ *   d_logits = c dx_ce (n_ce floats),  d_align = c dx_align (n_align floats),  d_seed = (g w_gen / gen_div) dx_gen,
+ *   box_w (P,2) = [c w_bbox, c]  -- the weights butd_box_loss_bwd takes.
+ * dx_*: the derivatives of the row sums the forward kernels saved; NULL inputs are skipped. */
+int butd_criterion_scale(int P, const float *g, const float *num_boxes, const int *status_words, int nstatus,
+                         float w_gen, float w_sum, float w_bbox, float gen_div, const float *dx_ce, float *d_logits,
+                         long n_ce, const float *dx_align, float *d_align, long n_align, const float *dx_gen,
+                         float *d_seed, long n_gen, float *box_w, butd_stream_t stream);
+
+
 #ifdef __cplusplus
 }
 #endif

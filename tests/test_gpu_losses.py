@@ -233,3 +233,71 @@ def test_fused_seed_objectness_equals_the_dense_expression():
             L.set_backend("hip")
     assert torch.allclose(res["hip"][0], res["torch"][0], rtol=1e-5, atol=1e-7)
     assert (res["hip"][1] - res["torch"][1]).abs().max() <= 1e-5 * res["torch"][1].abs().max()
+
+
+def test_single_node_tail_equals_the_term_by_term_graph():
+    """compute_hungarian_loss at the bench shape: the one-node tail (butd_criterion_reduce / _scale) against the
+    term-by-term autograd graph of the same kernels -- every end_points entry and every gradient, for an upstream
+    gradient that is not 1, with and without the objectness term; and a failed assignment (NaN loss, zero gradients)."""
+    from butd_detr_amd import losses as L
+    out, tgt = _north_star_case()
+    P, B, Q, C = out["pred_logits"].shape
+    layers = P - 1
+    prefixes = L.hungarian_prefixes(layers)
+    torch.manual_seed(11)
+    K, N, G = 1024, 50000, tgt["boxes"].shape[1]
+    seed_inds = torch.stack([torch.randperm(N, device="cuda")[:K] for _ in range(B)]).int()
+    pil = torch.randint(-1, 3, (B, N), device="cuda")
+    base = {"box_label_mask": tgt["valid"].float(), "center_label": tgt["boxes"][..., :3].contiguous(),
+            "size_gts": tgt["boxes"][..., 3:].contiguous(), "positive_map": tgt["positive_map"],
+            "sem_cls_label": tgt["labels"], "proj_tokens": out["proj_tokens"], "tokenized": out["tokenized"],
+            "seed_inds": seed_inds, "seed_xyz": torch.rand(B, K, 3, device="cuda") * 6 - 3, "point_instance_label": pil}
+    crit = L.SetCriterion(L.HungarianMatcher(1, 5, 2, True), ["boxes", "labels", "contrastive_align"])
+    for with_gen, poison in ((True, False), (False, False), (True, True)):
+        res = {}
+        for tail in (False, True):
+            prev, L._TAIL[0] = L._TAIL[0], tail
+            try:
+                leaves = {"logits": out["pred_logits"].clone().requires_grad_(True),
+                          "boxes": out["pred_boxes"].clone().requires_grad_(True),
+                          "que": out["proj_queries"].clone().requires_grad_(True),
+                          "seed": torch.randn(B, 1, K, device="cuda").requires_grad_(True) if with_gen else None}
+                if tail is False:
+                    seed0 = leaves["seed"]
+                elif with_gen:
+                    leaves["seed"] = seed0.detach().clone().requires_grad_(True)
+                ep = dict(base)
+                boxes = leaves["boxes"]
+                if poison:
+                    boxes = boxes.clone()
+                    boxes.data[0, 0, 0, 0] = float("nan")
+                    boxes = boxes.detach().requires_grad_(True)
+                    leaves["boxes"] = boxes
+                for i, pfx in enumerate(prefixes):
+                    ep[f"{pfx}sem_cls_scores"] = leaves["logits"][i]
+                    ep[f"{pfx}center"], ep[f"{pfx}pred_size"] = boxes[i, ..., :3], boxes[i, ..., 3:]
+                    ep[f"{pfx}proj_queries"] = leaves["que"][i]
+                if with_gen:
+                    ep["seeds_obj_cls_logits"] = leaves["seed"]
+                loss, ep = L.compute_hungarian_loss(ep, layers, crit, 4)
+                (loss * 0.37).backward()
+                keys = ["loss", "loss_ce", "loss_bbox", "loss_giou", "loss_constrastive_align", "query_points_generation_loss"]
+                keys += [f"{pfx}_{k}" for pfx in prefixes for k in ("loss_ce", "loss_bbox", "loss_giou", "loss_contrastive_align")]
+                res[tail] = ({k: ep[k].detach().clone() for k in keys}, ep["hungarian_match"].clone(),
+                             {k: (None if v is None else v.grad) for k, v in leaves.items()})
+            finally:
+                L._TAIL[0] = prev
+        (v0, m0, g0), (v1, m1, g1) = res[False], res[True]
+        assert torch.equal(m0, m1)
+        for k in v0:
+            if poison and k == "loss":
+                assert torch.isnan(v0[k]) and torch.isnan(v1[k])
+            elif not poison:
+                assert torch.allclose(v1[k], v0[k], rtol=2e-5, atol=1e-6), (k, float(v0[k]), float(v1[k]))
+        for k in g0:
+            if g0[k] is None:
+                assert g1[k] is None
+            elif poison:
+                assert not g1[k].abs().sum() > 0, k            # nothing trains on an invalid match
+            else:
+                assert (g1[k] - g0[k]).abs().max() <= 2e-5 * g0[k].abs().max() + 1e-9, k
