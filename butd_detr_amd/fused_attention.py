@@ -141,12 +141,12 @@ def _attn_bwd():
     return _lib.butd_attention_bwd_bf16 if _compute_bf16[0] else _lib.butd_attention_bwd
 
 
-_short_keys = [switches.flag("attn_short_keys", True)]
+_short_keys = [True]
 _SHORT_KEYS_MAX = int(_lib.butd_attention_bwd_short_keys_max())
 
 
 def set_short_keys(flag):
-    """A/B switch (BUTD_AB=attn_short_keys=0): the one-kernel backward for key sets of <= 144 rows."""
+    """Test switch: the round-4 one-kernel backward for key sets of <= 144 rows (the fallback where the one-pass kernel does not serve)."""
     prev, _short_keys[0] = _short_keys[0], bool(flag)
     return prev
 

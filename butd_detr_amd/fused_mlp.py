@@ -23,7 +23,7 @@ from ._hiplib import BnSegment
 from .fused_attention import _gemm, _problem, _slabbed, _stream, fold_scope, rng_counter, _site, zeros
 
 _lib = _hiplib.load()
-_FOLD_BN = [switches.flag("mlp_fold_bn", True)]     # A/B switch of the in-product BatchNorm bookkeeping
+_FOLD_BN = [True]     # A/B switch of the in-product BatchNorm bookkeeping
 
 
 _FUSE_STATS = [switches.flag("mlp_fuse_stats", True)]

@@ -44,7 +44,7 @@ _MID_WIDE = [switches.flag("sa_mid_wide", True)]
 # (4 x 60 steps), and the SA1 gradients move 4-5x CLOSER to a float64 run (closer than stock torch's):
 # profiles/r04_sa_last_layer.txt.  (A first version that recomputed z1 with scalar code from the LDS X tile was neutral.)
 _NO_Z1 = [switches.flag("sa_no_z1", True)]
-_FUSED_EVAL = [switches.flag("sa_fused_eval", True)]     # inference: a whole level as one kernel (sa_fused_eval)
+_FUSED_EVAL = [True]     # inference: a whole level as one kernel (sa_fused_eval)
 _scratch_sizes = {}
 _sched = {}
 
@@ -85,7 +85,7 @@ def _last_scratch(P, C2, C3):
 
 
 _FUSE_STATS = [switches.flag("sa_fuse_stats", True)]   # layer 1's gate + BatchNorm-backward sums in the epilogue of the product that creates dH1
-_GATHER = [switches.flag("sa_gather", True)]      # feature gradient as a gather over the inverted neighbour lists
+_GATHER = [True]      # feature gradient as a gather over the inverted neighbour lists
 
 
 def inverse_index(idx, N):

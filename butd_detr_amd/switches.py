@@ -6,17 +6,17 @@ Every name below is a path that is ON in the product and whose predecessor is ke
 module-level flag directly) and for committed A/B measurements under profiles/.  Paths that measured slower in the step
 (round 4: row-panel chains, forked decoder key / value projections, forked prediction heads, the short-key attention
 backward at every site) are not switches any more -- they were deleted in round 5; their measurements are in
-profiles/r04_panel_chain.txt, r04_side_branches.txt, r04_attention_short_keys.txt.
+profiles/r04_panel_chain.txt, r04_side_branches.txt, r04_attention_short_keys.txt.  Paths settled for two rounds keep their
+module-level flag for the parity tests but left this hook (the short-key attention backward -- now only the fallback of
+other head dimensions --, the Conv+BN prologue fold, the inverted-list gather of SA2-4, the one-kernel inference level).
 """
 import os
 
 KNOWN = {
     "attn_long_keys":   "one-pass attention backward, butd_attention_bwd_long_keys (fused_attention)",
-    "attn_short_keys":  "one-kernel attention backward where Lq >= 512 and Lk <= 80 (fused_attention)",
     "ln_fold":          "LayerNorm backward: dgamma / dbeta partials folded by the next grouped launch (fused_attention)",
     "wgrad_slabs":      "(default OFF) deterministic split-K weight gradients: partial slabs + ride-along folds instead of float atomics; bit-reproducible, +0.8 ms per step (fused_attention)",
     "mlp_fuse_stats":   "Conv+BN chains backward: gate + BatchNorm sums in the producing product's epilogue (fused_mlp)",
-    "mlp_fold_bn":      "Conv+BN chains forward: BatchNorm bookkeeping in the consuming product's prologue (fused_mlp)",
     "sa_last_bwd":      "set abstraction: last layer + max-pool backward by linearity (fused_sa)",
     "sa_last_fwd":      "set abstraction: last layer forward without writing Z3 (fused_sa)",
     "sa_first_bwd":     "SA1: first layer backward without dZ1 (fused_sa)",
@@ -24,8 +24,6 @@ KNOWN = {
     "sa_mid_wide":      "SA2-4: layer 2 backward in one pass, only the gated gradient written (fused_sa)",
     "sa_no_z1":         "SA1: forward without Z1 (fused_sa)",
     "sa_fuse_stats":    "SA2-4: layer 1's gate + BatchNorm sums in the epilogue of the product that writes dH1 (fused_sa)",
-    "sa_gather":        "SA2-4: feature gradient as a gather over inverted neighbour lists (fused_sa)",
-    "sa_fused_eval":    "inference: a whole set-abstraction level as one kernel (fused_sa)",
     "fan_out":          "gradient fan-in of multiply-used tensors as one launch (fan_out)",
     "encoder_fork":     "language side of an encoder layer on a forked stream (encoder_decoder_layers)",
     "text_overlap":     "frozen language model on a forked stream when it is not prefetched (bdetr)",

@@ -11,6 +11,8 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o
 cp /tmp/prof/bench_kernel_stats.csv $O/r05_hip_bench_kernel_stats.csv
 python scratch/trace_summary.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} > $O/r05_hip_one_step_summary.txt
 python scratch/step_timeline.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} 10 > $O/r05_step_timeline.txt
+python scratch/torch_kernels_on_main.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} > $O/r05_stock_kernels.txt
+python scratch/small_kernels.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} > $O/r05_small_kernels.txt
 tail -1 $O/bench_under_rocprof.log | cut -c1-200
 head -5 $O/r05_hip_one_step_summary.txt | cut -c1-130; tail -7 $O/r05_hip_one_step_summary.txt
 mkdir -p gpurun_out/pmc
@@ -24,7 +26,7 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     if r.get("Counter_Name") != "$C": continue
     name = r["Kernel_Name"]
-    key = next((k for k in ("gemm_kernel", "ball_query_kernel", "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "fps_pruned", "bq_grid_query", "lsap_kernel", "ln_bwd_kernel", "sa_colstats", "sa_mask_stats", "sa_dz_mid", "sa_dz_last", "sa_last_fwd", "sa_last_fused", "sa_last_mfma", "sa_last_sparse", "sa_first_stats", "sa_gather_rows") if k in name), None)
+    key = next((k for k in ("gemm_kernel", "ball_query_kernel", "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "attn_bwd_longk_kernel", "attn_dq_fold_kernel", "sa_mid_wide_kernel", "fps_pruned", "bq_grid_query", "lsap_kernel", "ln_bwd_kernel", "sa_colstats", "sa_mask_stats", "sa_dz_mid", "sa_dz_last", "sa_last_fwd", "sa_last_fused", "sa_last_mfma", "sa_last_sparse", "sa_first_stats", "sa_gather_rows") if k in name), None)
     if key:
         agg[key][0] += 1; agg[key][1] += float(r["Counter_Value"])
 out = {k: {"launches": c, "avg_$C": v / c} for k, (c, v) in agg.items()}
@@ -37,6 +39,9 @@ unset BUTD_BENCH_NO_CHILD
   python scratch/attn_occ.py 2>/dev/null | grep "B="
   echo "# dropout off / on (what the mask hash costs) and the decoder's shapes:"
   python scratch/attn_bench.py 2>/dev/null | grep "Lq="
+  echo "# the one-pass backward (butd_attention_bwd_long_keys, the library's plan) next to the two-kernel walk, dropout 0.0 / 0.1:"
+  python scratch/attn_longk_bench.py 2>/dev/null | grep " x "
+  SHAPES=short python scratch/attn_longk_bench.py 2>/dev/null | grep " x "
   echo "# the bf16 entry points (bf16 LDS images, v_mfma_f32_16x16x32_bf16; round 4: fwd 96 / bwd 288 us at 1024 x 1024):"
   BF16=1 python scratch/attn_bench.py 2>/dev/null | grep "Lq="; } > $O/r05_attention_core.txt
 python scratch/step_marks.py 20 > $O/r05_step_marks.txt 2>/dev/null

@@ -22,7 +22,7 @@ if len(sys.argv) > 1:
             flips.append((n, round(float(eh.max()), 5), round(float(et.max()), 5), round(float(eh.mean()), 6), round(float(et.mean()), 6)))
     print("FLIPS", json.dumps(flips))
 else:
-    for tag, env in (("new", {}), ("old", {"BUTD_AB": "sa_last_bwd=0,sa_first_bwd=0,sa_gather=0"}),
+    for tag, env in (("new", {}), ("old", {"BUTD_AB": "sa_last_bwd=0,sa_first_bwd=0"}),
                      ("new bwd, old fwd", {"BUTD_AB": "sa_last_fwd=0"})):
         out = subprocess.run([sys.executable, __file__, "child"], env={**os.environ, **env}, capture_output=True, text=True).stdout
         line = [l for l in out.splitlines() if l.startswith("FLIPS")]

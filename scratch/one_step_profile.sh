@@ -9,6 +9,7 @@ timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -o
 python scratch/trace_summary.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} > $O/one_step_summary$1.txt
 python scratch/step_timeline.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} 10 > $O/step_timeline$1.txt
 python scratch/torch_kernels_on_main.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} > $O/stock_kernels$1.txt
+python scratch/small_kernels.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} > $O/small_kernels$1.txt
 if [ -n "$WIN" ]; then python scratch/window_kernels.py /tmp/prof/bench_kernel_trace.csv fps_pruned_kernel ${SKIP:-2} $WIN > $O/window$1.txt; fi
 tail -1 $O/bench_under_rocprof$1.log | cut -c1-200
 head -${HEAD:-48} $O/one_step_summary$1.txt | cut -c1-150; tail -7 $O/one_step_summary$1.txt; cat $O/stock_kernels$1.txt | cut -c1-330
