@@ -201,7 +201,7 @@ def sa_linear_roofline(args, gemm):
     if not _LAST_CHILD_ROWS or not gemm.get("launches_per_step"):
         return None
     names = ("sa_last_fwd_kernel", "sa_last_fused_kernel", "sa_last_mfma_kernel", "sa_last_sparse_kernel", "sa_mid_first_kernel",
-             "sa_l12_fwd_kernel")
+             "sa_l12_fwd_kernel", "sa_mid_wide_kernel")
     gemm_calls = sum(c for n, c, _ in _LAST_CHILD_ROWS if "gemm_kernel" in n)
     steps = (sum(c for n, c, _ in _LAST_CHILD_ROWS if "lsap_kernel" in n)
              or gemm_calls / gemm["launches_per_step"])       # steps in the child's trace
@@ -220,10 +220,13 @@ def sa_linear_roofline(args, gemm):
         bytes_ += 4.0 * P1 * (8 + 64) + 4.0 * P1 * (2 * 64 + 8)
     else:
         bytes_ += 4.0 * P1 * (3 * 64 + 8)                                 # SA1 lower pass reading Z1
+    if per["sa_mid_wide_kernel"] > 0:     # round 5: SA2-4's layer 2 backward in one pass (dW2 and dH1: 4 P C^2; g2, Z2, Z1 read, g1 written)
+        flops += sum(4.0 * P * c2 * c2 for P, c2, _ in levels[1:])
+        bytes_ += sum(4.0 * P * c2 * 4 for P, c2, _ in levels[1:])
     both_ms = ms + gemm["ms_per_step_in_kernel"]
     both = (flops + gemm["algorithmic_flops_per_step"]) / (both_ms * 1e-3) / 1e12
-    return {"kernel": "sa_last_fwd / sa_last_fused / sa_last_mfma + sa_last_sparse / sa_mid_first / sa_l12_fwd (set-abstraction last layer "
-                      "+ max-pool by linearity, SA1 lower layers: the products that left gemm_kernel)",
+    return {"kernel": "sa_last_fwd / sa_last_fused / sa_last_mfma + sa_last_sparse / sa_mid_first / sa_l12_fwd / sa_mid_wide (set-abstraction "
+                      "last layer + max-pool by linearity, SA1 lower layers, SA2-4 middle layer backward: the products that left gemm_kernel)",
             "bound": "mfma", "achieved": round(flops / (ms * 1e-3) / 1e12, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
             "frac": round(flops / (ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TF, 4), "traffic": None,
             "ms_per_step_in_kernels": round(ms, 3), "ms_per_kernel": {k: round(v, 3) for k, v in per.items()},
@@ -313,7 +316,17 @@ def attention_roofline(batch, reps=10, bf16=False):
         return fwd_fn(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
                                       lse.data_ptr(), 0.1, 7, ctr, stream.cuda_stream)
 
+    # the backward the product runs for this shape (fused_attention._attention_backward): the one-pass kernel + its
+    # slab fold when the library serves the shape (fp32), else the dQ walk + the dK/dV walk
+    need = -1 if bf16 else int(lib.butd_attention_bwd_long_keys_scratch(B, H, L, L, D, 0))
+    ws = torch.empty(max(need, 1), device=dev)
+
     def bwd():
+        if need >= 0:
+            return lib.butd_attention_bwd_long_keys(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None,
+                                                    out.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(),
+                                                    dk.data_ptr(), dv.data_ptr(), 0, 0, 1.0, 0.1, 7, ctr, ws.data_ptr(),
+                                                    need, stream.cuda_stream)
         return bwd_fn(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None, out.data_ptr(),
                                       do.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(),
                                       dv.data_ptr(), 0, 0, 1.0, 0.1, 7, ctr, stream.cuda_stream)
@@ -332,10 +345,12 @@ def attention_roofline(batch, reps=10, bf16=False):
     flops_f = 4.0 * L * L * D * H * B
     achieved = (flops_f * 3.5) / ((ms_f + ms_b) * 1e-3) / 1e12
     peak = BF16_MATRIX_PEAK_TF if bf16 else FP32_MATRIX_PEAK_TF
-    return {"kernel": "attn_fwd / attn_bwd_dq / attn_bwd_dkv%s (B=%d, 8 heads, 1024x1024, head dim 36)"
-                      % (" <bf16 matrix steps>" if bf16 else "", B),
+    return {"kernel": "attn_fwd / %s%s (B=%d, 8 heads, 1024x1024, head dim 36)"
+                      % ("attn_bwd_longk + attn_dq_fold (one pass)" if need >= 0 else "attn_bwd_dq / attn_bwd_dkv",
+                         " <bf16 matrix steps>" if bf16 else "", B),
             "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(achieved / peak, 4), "traffic": _pmc_traffic("attn_fwd_kernel"),
+            "traffic_bwd": _pmc_traffic("attn_bwd_longk_kernel") if need >= 0 else _pmc_traffic("attn_bwd_dkv_kernel"),
             "fwd_ms": round(ms_f, 4), "bwd_ms": round(ms_b, 4)}
 
 
