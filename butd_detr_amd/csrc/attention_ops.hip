@@ -2707,7 +2707,7 @@ int butd_attention_bwd_short_keys(int B, int H, int Lq, int Lk, int D, const flo
  *   1024 x 132: 118 (133) | 126 | 104 | 93 | 103 | 123;  1024 x 80: 108 (89) | 123 | 73 | 64 | 72 | 90;
  *   256 x 80: 37 (60) | 41 | 29 | 30 | 30;  256 x 132: 45 (94) | 42 | 40 | 46;  256 x 256: 49 | 45 | 46 | 55;  80 x 80: 29 | 25 | 20 | 20.
  * So: 256 keys (8 waves x 2 sub-tiles), one split, where that gives >= 192 workgroups; else 64 keys (4 waves x 1) with
- * the queries split so that about 512 workgroups exist (dK / dV then go through per-split slabs like dQ).
+ * the queries split so that about 512-640 workgroups exist (dK / dV then go through per-split slabs like dQ).
  * g_longk_force_*: tuning hook (0 = the rule). */
 struct LongkPlan { int chunk, chunks, q_splits, q_tiles_per_wg; };
 static int g_longk_force_chunk = 0, g_longk_force_splits = 0;
@@ -2726,8 +2726,8 @@ static LongkPlan longk_plan(int B, int H, int Lq, int Lk, int D) {
   else if ((long)((Lk + 255) / 256) * bh >= 192) p.chunk = 256;
   else {
     p.chunk = 64;
-    const long x = (long)((Lk + 63) / 64) * bh;
-    want = (int)((512 + x - 1) / x);
+    const long x = (long)((Lk + 63) / 64) * bh, target = tiles > 4 ? 640 : 512;   // (1024 x 132: 4 splits, 256 x 132: 2)
+    want = (int)((target + x - 1) / x);
   }
   if (g_longk_force_splits) want = g_longk_force_splits;
   p.chunks = (Lk + p.chunk - 1) / p.chunk;
