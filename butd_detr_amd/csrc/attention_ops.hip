@@ -1698,25 +1698,19 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
 
   // ---- staging of a 64-query tile: this thread's float4s (row, column quartet) and where they land in the images
   const int vpr = D >> 2;
-  int s_row[kVec], s_goff[kVec], s_koff[kVec][4];      // (s_row = 64: this lane holds no quartet)
-#pragma unroll
-  for (int j = 0; j < kVec; ++j) {
-    const int f = tid + j * kLongThreads;
-    const int r = f >> 4, c4 = f & 15;
-    const bool ok = c4 < vpr;
-    s_row[j] = ok ? r : 64;
-    s_goff[j] = ok ? (int)(r * E) + c4 * 4 : 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s_koff[j][i] = ok ? r * I::LD + I::col(c4 * 4 + i) : 0;
-  }
+  // (row f >> 4, quartet f & 15 of float4 slot f = tid + j * threads; offsets are recomputed where they are used -- a
+  //  dozen registers that would otherwise live through the matrix loop)
+  const bool s_ok = (tid & 15) < vpr;
+  const int s_c4 = tid & 15;
   float4 qr[kVec], gr[kVec], orr[kVec];
   float sr = 0.f;
   auto fetch = [&](int qs) {
     const int nrows = Lq - qs;
 #pragma unroll
     for (int j = 0; j < kVec; ++j) {
-      const bool ok = s_row[j] < 64 && s_row[j] < nrows;
-      const long o = (long)qs * E + s_goff[j];
+      const int r = (tid + j * kLongThreads) >> 4;
+      const bool ok = s_ok && r < nrows;
+      const long o = (long)qs * E + (long)r * E + s_c4 * 4;
       qr[j] = ok ? *reinterpret_cast<const float4 *>(qb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
       gr[j] = ok ? *reinterpret_cast<const float4 *>(gb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
       orr[j] = ok ? *reinterpret_cast<const float4 *>(ob + o) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1733,9 +1727,12 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
       part += __shfl_xor(part, 4, 16);
       part += __shfl_xor(part, 2, 16);
       part += __shfl_xor(part, 1, 16);
-      if (s_row[j] < 64) {
-        qi_[s_koff[j][0]] = qr[j].x; qi_[s_koff[j][1]] = qr[j].y; qi_[s_koff[j][2]] = qr[j].z; qi_[s_koff[j][3]] = qr[j].w;
-        gi_[s_koff[j][0]] = gr[j].x; gi_[s_koff[j][1]] = gr[j].y; gi_[s_koff[j][2]] = gr[j].z; gi_[s_koff[j][3]] = gr[j].w;
+      if (s_ok) {
+        const int base = ((tid + j * kLongThreads) >> 4) * I::LD;
+        const int k0_ = base + I::col(s_c4 * 4), k1_ = base + I::col(s_c4 * 4 + 1), k2_ = base + I::col(s_c4 * 4 + 2),
+                  k3_ = base + I::col(s_c4 * 4 + 3);
+        qi_[k0_] = qr[j].x; qi_[k1_] = qr[j].y; qi_[k2_] = qr[j].z; qi_[k3_] = qr[j].w;
+        gi_[k0_] = gr[j].x; gi_[k1_] = gr[j].y; gi_[k2_] = gr[j].z; gi_[k3_] = gr[j].w;
       }
       if (((tid + j * kLongThreads) & 15) == 0) Del[(tid + j * kLongThreads) >> 4] = part;
     }
@@ -1790,11 +1787,18 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
 #pragma unroll
         for (int i = 0; i < 4; ++i) pd[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lq[i]));
         if (drop) {
-          const uint32_t pair_tile = pair_col[j] + (uint32_t)(qs + t * 16 + fg * 4) * LkP;
+          // one hash decides a key PAIR of a row: the lanes of keys 2m and 2m + 1 need the same four words.  Each hashes
+          // two of the rows and takes the other two from its neighbour (quad_perm [1,0,3,2]): two 32-bit multiplies
+          // (quarter rate) less per row pair than hashing all four
+          const uint32_t pair_tile = pair_col[j] + (uint32_t)(qs + t * 16 + fg * 4 + (fr & 1) * 2) * LkP;
+          const uint32_t ha = pair_hash(hkey, pair_tile), hb = pair_hash(hkey, pair_tile + LkP);
+          const uint32_t oa = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0xB1, 0xf, 0xf, false);
+          const uint32_t ob = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)hb, 0xB1, 0xf, 0xf, false);
+          const bool odd = (fr & 1) != 0;
+          const uint32_t hh4[4] = {odd ? oa : ha, odd ? ob : hb, odd ? ha : oa, odd ? hb : ob};
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const uint32_t hh = pair_hash(hkey, pair_tile + (uint32_t)i * LkP);
-            const bool keep = ((hh >> field_shift) & 0xffffu) >= thr;
+            const bool keep = ((hh4[i] >> field_shift) & 0xffffu) >= thr;
             ds[i] = pd[i] * ((keep ? dp[i] : 0.f) - dl[i]);
             pd[i] = keep ? pd[i] : 0.f;                      // the 1/(1-p) of dV is applied once, at the end
           }
