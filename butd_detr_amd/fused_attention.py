@@ -317,6 +317,7 @@ def _wgrad(dy, x, dw, db, M, N, K, **kw):
     # there are 512 rows to share out -- a 640-row product takes 9.6 us with 8 slices, 15.9 us with 2
     # (a thin 10^6-row product such as SA1's first layer, 64 x 8: 155 us with 256 slices, 105 with 512)
     cap = 512 if N * K <= 1024 else 256
+    # (re-measured in the step, round 5: 128 / 512 rows per slice, caps of 16 / 64 slices: within noise or slower)
     split = max(1, min(cap, M // 512)) if M >= 16384 else min(32, max(M // 256, min(8, M // 64), 1))
     return _slabbed(_problem(dy, x, dw, N, K, M, (1, N), (1, K), K, bias_grad=db, ones_col=db is not None,
                              accumulate=True, split_k=split, **kw), dw, db)

@@ -41,7 +41,14 @@ def _call(name, ref, *args):
     _hiplib.check(err, name)
 
 
-def _split(M):
+_THIN_SPLIT = [32]     # (scratch A/B: slices of a thin weight gradient; 8 = the rule of the square products)
+
+
+def _split(M, N=0, K=0):
+    # thin products (a 3- / 6-wide side: the box heads' output layers, the 6 -> 288 position embedding) run on the
+    # element-wise staged kernel, ~1.5 us per 32-row slab in a handful of workgroups: more, shorter slices
+    if 0 < min(N, K) <= 8:
+        return max(1, min(_THIN_SPLIT[0], M // 32))
     return min(32, max(M // 256, min(8, M // 64), 1))      # see fused_attention._wgrad
 
 
@@ -188,7 +195,7 @@ class _MlpChains(torch.autograd.Function):
             a, lda, b_aff, b_drop = operand(l, i)
             K = Cin if l == 0 else Hs[l - 1]
             return _slabbed(_problem(dy, a, dw, N, K, P, (1, ldy), (1, lda), K, bias_grad=db,
-                                     ones_col=db is not None, accumulate=True, split_k=_split(P),
+                                     ones_col=db is not None, accumulate=True, split_k=_split(P, N, K),
                                      b_affine=b_aff, b_drop=b_drop), dw, db)
 
         # The product that CREATES the gradient arriving at layer l's BatchNorm + ReLU applies the ReLU gate and leaves the
