@@ -15,10 +15,14 @@ mainq = max(byq, key=lambda q: len(byq[q]))
 m = byq[mainq]
 t0 = int(m[0]["Start_Timestamp"])
 prev_end = None
+import os
+if os.environ.get("ALLQ") == "1":          # every queue, tagged (the main queue = *)
+    m = sorted(win, key=lambda r: int(r["Start_Timestamp"]))
 for r in m:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
     if lo <= s <= hi:
         n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").replace("at::native::", "")
         gap = (s - prev_end) * 1e3 if prev_end is not None else 0.0
-        print(f"{s:8.3f} ms  {1e3 * (e - s):7.1f} us  gap {gap:5.1f}  grid {r['Grid_Size_X']:>8s}  {n[:150]}")
+        tag = ("*" if r["Queue_Id"] == mainq else " ") + r["Queue_Id"]
+        print(f"{s:8.3f} ms  {1e3 * (e - s):7.1f} us  gap {gap:5.1f}  q{tag}  grid {r['Grid_Size_X']:>8s}  {n[:150]}")
     prev_end = e
