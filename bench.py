@@ -318,12 +318,13 @@ def attention_roofline(batch, reps=10, bf16=False):
 
     # the backward the product runs for this shape (fused_attention._attention_backward): the one-pass kernel + its
     # slab fold when the library serves the shape (fp32), else the dQ walk + the dK/dV walk
-    need = -1 if bf16 else int(lib.butd_attention_bwd_long_keys_scratch(B, H, L, L, D, 0))
+    need = int((lib.butd_attention_bwd_long_keys_bf16_scratch if bf16 else lib.butd_attention_bwd_long_keys_scratch)(B, H, L, L, D, 0))
     ws = torch.empty(max(need, 1), device=dev)
+    one_pass = lib.butd_attention_bwd_long_keys_bf16 if bf16 else lib.butd_attention_bwd_long_keys
 
     def bwd():
         if need >= 0:
-            return lib.butd_attention_bwd_long_keys(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None,
+            return one_pass(B, H, L, L, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), None,
                                                     out.data_ptr(), do.data_ptr(), lse.data_ptr(), dq.data_ptr(),
                                                     dk.data_ptr(), dv.data_ptr(), 0, 0, 1.0, 0.1, 7, ctr, ws.data_ptr(),
                                                     need, stream.cuda_stream)

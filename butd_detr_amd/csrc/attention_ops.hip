@@ -2595,6 +2595,243 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_h_kernel(
   }
 }
 
+// ---- the one-pass backward on the bf16 matrix cores (bf16 images of section "bf16 operating point") -------------------
+// attn_bwd_longk_kernel's walk -- 8 waves own 256 keys (32 per wave: two 16-key sub-tiles), the queries pass 64 at a time
+// through LDS images, dQ shares are summed through LDS and stored to the chunk's slab -- with the products of the bf16
+// kernels above: S / dP as two K = 32 instructions per 16 x 16 tile over the padded head dimension, dV^T / dK^T with TWO
+// query sub-tiles per instruction (transposed images of dO and Q), and dQ^T with the wave's TWO key sub-tiles per
+// instruction (K^T operands in registers, dS transposed through two wave-private LDS patches): 8.5 matrix instructions per
+// score tile where the dQ walk + the dK/dV walk issue 12.5, and ONE pass of the exponentials, dropout hashes and
+// roundings those kernels are bound by.  fp32: statistics, exponentials, accumulators, everything in memory.
+template <int NS, int NT>
+__global__ __launch_bounds__(512) void attn_bwd_longk_h_kernel(
+    int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
+    const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
+    const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ dq_out, long ld_dq,
+    long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, float p_drop,
+    uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  using I = ImgH<NS>;
+  using T = TImgH<NT>;
+  constexpr int kWaves = 8, kSub = 2, kThreads = kWaves * 64, kChunk = kWaves * kSub * 16;
+  constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD, LDX = 20;
+  constexpr int kVec = 64 * 16 / kThreads;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *Lse = smem;                                   // [64]  lse * log2(e)
+  float *Del = Lse + 64;                               // [64]
+  float *X = Del + 64;                                 // [waves][2 sub-tiles][16][LDX]
+  float *Red = X + kWaves * 2 * 16 * LDX;              // [waves][64][D]
+  __bf16 *Qimg = reinterpret_cast<__bf16 *>(Red + kWaves * 64 * D);
+  __bf16 *Gimg = Qimg + kImg;
+  __bf16 *Qt = Gimg + kImg;
+  __bf16 *Gt = Qt + kTimg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const TileId wg = tile_id();
+  const int b = wg.b, h = wg.h, chunk = wg.t;
+  const long E = (long)H * D;
+  const int k0 = chunk * kChunk + wave * (kSub * 16);
+  const bool wave_live = k0 < Lk;
+  const int live_waves = min(kWaves, (Lk - chunk * kChunk + kSub * 16 - 1) / (kSub * 16));
+  const float *qb = q + (long)b * Lq * E + h * D;
+  const float *gb = dout + (long)b * Lq * E + h * D;
+  const float *ob = out + (long)b * Lq * E + h * D;
+  const float *kb = k + (long)b * Lk * E + h * D;
+  const float *vb = v + (long)b * Lk * E + h * D;
+  const float *lb = lse + ((long)b * H + h) * Lq;
+  float *dqb = dq_out + (long)chunk * chunk_stride + (long)b * Lq * ld_dq + h * D;
+  const bool drop = p_drop > 0.f;
+  const float inv_keep = drop ? 1.f / (1.f - p_drop) : 1.f;
+  const uint32_t thr = drop_threshold(p_drop);
+  const uint32_t hkey = (drop && rng_counter) ? rng::site_key(*rng_counter, site) : rng::site_key(0ull, site);
+  const uint32_t LkP = (uint32_t)(Lk + 1) >> 1;
+  const uint32_t field_shift = (uint32_t)(fr & 1) * 16u;
+
+  HFrag<NS> kF[kSub], vF[kSub];
+  float my_bias[kSub];
+  uint32_t pair_col[kSub];
+  bool any_bias = false;
+#pragma unroll
+  for (int j = 0; j < kSub; ++j) {
+    const int ki = k0 + j * 16 + fr;
+    float kf[NS], vf[NS];
+    load_row_frag<NS>(kf, kb, E, ki, Lk, fg, D);
+    load_row_frag<NS>(vf, vb, E, ki, Lk, fg, D);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vf[s] *= inv_keep;
+    kF[j] = make_hfrag<NS>(kf);
+    vF[j] = make_hfrag<NS>(vf);
+    my_bias[j] = key_bias(mask ? mask + (long)b * Lk : nullptr, ki, Lk);
+    any_bias = any_bias || my_bias[j] != 0.f;
+    pair_col[j] = (uint32_t)(((long)b * H + h) * Lq) * LkP + (uint32_t)(ki >> 1);
+  }
+  const bool wave_masked = __any(any_bias);
+  // dQ^T += K^T dS^T over the wave's 32 keys in ONE instruction: elements 0..3 = keys 4g .. 4g+3 of sub-tile 0, 4..7 of sub-tile 1
+  bf16x8 kaH[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int key = k0 + (e >> 2) * 16 + fg * 4 + (e & 3), d = nt * 16 + fr;
+      kaH[nt][e] = (__bf16)((key < Lk && d < D) ? kb[(long)key * E + d] : 0.f);
+    }
+  f32x4 ak[kSub][NT], av[kSub][NT];
+#pragma unroll
+  for (int j = 0; j < kSub; ++j)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      ak[j][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      av[j][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  {   // pads of the fragment rows and rows D.. of the transposed images: zero, once (the commits never write them)
+    uint32_t *w = reinterpret_cast<uint32_t *>(Qimg);
+    for (int e = tid; e < (2 * kImg + 2 * kTimg) / 2; e += kThreads) w[e] = 0u;
+  }
+  const int vpr = D >> 2;
+  const bool s_ok = (tid & 15) < vpr;
+  const int s_c4 = tid & 15;
+  float4 qr[kVec], gr[kVec], orr[kVec];
+  float sr = 0.f;
+  auto fetch = [&](int qs) {
+    const int nrows = Lq - qs;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      const int r = (tid + j * kThreads) >> 4;
+      const bool ok = s_ok && r < nrows;
+      const long o = (long)qs * E + (long)r * E + s_c4 * 4;
+      qr[j] = ok ? *reinterpret_cast<const float4 *>(qb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gr[j] = ok ? *reinterpret_cast<const float4 *>(gb + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+      orr[j] = ok ? *reinterpret_cast<const float4 *>(ob + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < 64) sr = (qs + tid < Lq) ? lb[qs + tid] * kLog2e : INFINITY;
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int j = 0; j < kVec; ++j) {
+      float part = gr[j].x * orr[j].x + gr[j].y * orr[j].y + gr[j].z * orr[j].z + gr[j].w * orr[j].w;
+      part += __shfl_xor(part, 8, 16);
+      part += __shfl_xor(part, 4, 16);
+      part += __shfl_xor(part, 2, 16);
+      part += __shfl_xor(part, 1, 16);
+      const int r = (tid + j * kThreads) >> 4;
+      if (s_ok) {
+        const float qe[4] = {qr[j].x, qr[j].y, qr[j].z, qr[j].w}, ge[4] = {gr[j].x, gr[j].y, gr[j].z, gr[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int d = s_c4 * 4 + i;
+          Qimg[r * I::LD + I::col(d)] = (__bf16)qe[i];
+          Gimg[r * I::LD + I::col(d)] = (__bf16)ge[i];
+          Qt[d * T::LD + r] = (__bf16)qe[i];
+          Gt[d * T::LD + r] = (__bf16)ge[i];
+        }
+      }
+      if (((tid + j * kThreads) & 15) == 0) Del[r] = part;
+    }
+    if (tid < 64) Lse[tid] = sr;
+  };
+  const int iters = (Lq + 63) / 64;
+  fetch(0);
+  __syncthreads();
+  commit();
+  __syncthreads();
+  float *Xw = X + wave * 2 * 16 * LDX, *Rw = Red + wave * 64 * D;
+  for (int it = 0; it < iters; ++it) {
+    const int qs = it * 64;
+    const bool more = it + 1 < iters;
+    if (wave_live) {
+#pragma unroll 1
+      for (int u = 0; u < 2; ++u) {       // two 16-query sub-tiles per K = 32 instruction of the dV^T / dK^T products
+        f32x4 pd2[2][kSub], ds2[2][kSub];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+          const int t = 2 * u + w;
+          const HFrag<NS> qF = frag_h<NS>(Qimg + (t * 16 + fr) * I::LD, fg), gF = frag_h<NS>(Gimg + (t * 16 + fr) * I::LD, fg);
+          const float4 l4 = *reinterpret_cast<const float4 *>(Lse + t * 16 + fg * 4);
+          const float4 d4 = *reinterpret_cast<const float4 *>(Del + t * 16 + fg * 4);
+          const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dl[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+          for (int j = 0; j < kSub; ++j) {
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            f32x4 st = mma_h<NS>(qF, kF[j], zero);   // S[q][key]
+            f32x4 dp = mma_h<NS>(gF, vF[j], zero);   // dP[q][key] / (1 - p)
+            if (wave_masked) {
+              st[0] += my_bias[j]; st[1] += my_bias[j]; st[2] += my_bias[j]; st[3] += my_bias[j];
+            }
+            f32x4 pd, ds;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pd[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(st[i], kLog2e, -lq[i]));
+            if (drop) {
+              const uint32_t pair_tile = pair_col[j] + (uint32_t)(qs + t * 16 + fg * 4) * LkP;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t hh = pair_hash(hkey, pair_tile + (uint32_t)i * LkP);
+                const bool keep = ((hh >> field_shift) & 0xffffu) >= thr;
+                ds[i] = pd[i] * ((keep ? dp[i] : 0.f) - dl[i]);
+                pd[i] = keep ? pd[i] : 0.f;
+              }
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) ds[i] = pd[i] * (dp[i] - dl[i]);
+            }
+            pd2[w][j] = pd;
+            ds2[w][j] = ds;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Xw[j * 16 * LDX + (fg * 4 + i) * LDX + fr] = ds[i];
+          }
+          __builtin_amdgcn_wave_barrier();
+          const f32x4 dst0 = *reinterpret_cast<const f32x4 *>(Xw + fr * LDX + fg * 4);
+          const f32x4 dst1 = *reinterpret_cast<const f32x4 *>(Xw + 16 * LDX + fr * LDX + fg * 4);
+          __builtin_amdgcn_wave_barrier();
+          const bf16x8 sT = pack8(dst0, dst1);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 dqa = mma32(kaH[nt], sT, (f32x4){0.f, 0.f, 0.f, 0.f});   // dQ^T[d][q] over this wave's 32 keys
+            if (nt * 16 + fg * 4 < D) *reinterpret_cast<f32x4 *>(Rw + (t * 16 + fr) * D + nt * 16 + fg * 4) = dqa;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kSub; ++j) {
+          const bf16x8 pb = pack8(pd2[0][j], pd2[1][j]), sb = pack8(ds2[0][j], ds2[1][j]);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            av[j][nt] = mma32(pair8(Gt + (nt * 16 + fr) * T::LD + u * 32 + fg * 4), pb, av[j][nt]);
+            ak[j][nt] = mma32(pair8(Qt + (nt * 16 + fr) * T::LD + u * 32 + fg * 4), sb, ak[j][nt]);
+          }
+        }
+      }
+    }
+    if (more) fetch(qs + 64);
+    __syncthreads();
+    for (int e = tid; e < 64 * vpr; e += kThreads) {
+      f32x4 a = *reinterpret_cast<const f32x4 *>(Red + 4 * e);
+#pragma unroll
+      for (int w = 1; w < kWaves; ++w)
+        if (w < live_waves) a += *reinterpret_cast<const f32x4 *>(Red + w * 64 * D + 4 * e);
+      const int r = e / vpr, c4 = e - r * vpr;
+      if (qs + r < Lq) *reinterpret_cast<f32x4 *>(dqb + (long)(qs + r) * ld_dq + 4 * c4) = a * dq_scale;
+    }
+    if (more) commit();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < kSub; ++j) {
+    const int ki = k0 + j * 16 + fr;
+    if (ki < Lk) {
+      float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
+      float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = nt * 16 + fg * 4 + i;
+          if (n < D) {
+            okp[n] = ak[j][nt][i];
+            ovp[n] = av[j][nt][i] * inv_keep;
+          }
+        }
+    }
+  }
+}
+
 template <int WAVES, int SUB>
 int launch_longk(int chunks, int q_splits, int q_tiles_per_wg, int B, int H, int Lq, int Lk, int D, const float *q,
                  const float *k, const float *v, const uint8_t *mask, const float *out, const float *dout,
@@ -2797,6 +3034,50 @@ int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const floa
     }
     hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((fa.total + 255) / 256)), dim3(256), 0, s, fa);
   }
+  return (int)hipGetLastError();
+}
+
+/* the same walk on the bf16 matrix cores (BASELINE configs[3]): served where the fp32 plan is 256 keys per workgroup and
+ * one query split (the long key sets); everything else stays on the two bf16 kernels */
+long butd_attention_bwd_long_keys_bf16_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq) {
+  if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
+  const LongkPlan p = longk_plan(B, H, Lq, Lk, D);
+  if (p.chunk != 256 || p.q_splits != 1 || p.chunks < 2) return -1;
+  if (ld_dq == 0) ld_dq = (long)H * D;
+  if (ld_dq & 3) return -1;
+  return (long)p.chunks * B * Lq * H * D;
+}
+
+int butd_attention_bwd_long_keys_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                      const float *v, const uint8_t *key_padding_mask, const float *out,
+                                      const float *dout, const float *lse, float *dq, float *dk, float *dv, long ld_dq,
+                                      long ld_dkv, float dq_scale, float dropout_p, uint32_t dropout_site,
+                                      const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream) {
+  const long need = butd_attention_bwd_long_keys_bf16_scratch(B, H, Lq, Lk, D, ld_dq);
+  if (need < 0 || !ws || ws_floats < need) return (int)hipErrorInvalidValue;
+  if (ld_dq == 0) ld_dq = (long)H * D;
+  if (ld_dkv == 0) ld_dkv = (long)H * D;
+  if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  const LongkPlan p = longk_plan(B, H, Lq, Lk, D);
+  const long E = (long)H * D, q_slab = (long)B * Lq * E;
+  using I = ImgH<9>;
+  using T = TImgH<3>;
+  const size_t bytes = sizeof(float) * (size_t)(64 + 64 + 8 * 2 * 16 * 20 + 8 * 64 * 36) +
+                       sizeof(__bf16) * (size_t)(2 * 64 * I::LD + 2 * T::ROWS * T::LD);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_longk_h_kernel<9, 3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((attn_bwd_longk_h_kernel<9, 3>), dim3(p.chunks, H, B), dim3(512), bytes, s, H, Lq, Lk, D, q, k, v,
+                     key_padding_mask, out, dout, lse, ws, E, q_slab, 1.f, dk, dv, ld_dkv, dropout_p, dropout_site,
+                     rng_counter);
+  FoldArgs fa;
+  fa.nseg = 1;
+  fa.E4 = (int)(E / 4);
+  fa.seg[0].ws = ws; fa.seg[0].dst = dq; fa.seg[0].slabs = p.chunks; fa.seg[0].slab_stride = q_slab;
+  fa.seg[0].rows = (long)B * Lq; fa.seg[0].ld = ld_dq; fa.seg[0].scale = dq_scale; fa.seg[0].first = 0;
+  fa.total = (long)B * Lq * (E / 4);
+  hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((fa.total + 255) / 256)), dim3(256), 0, s, fa);
   return (int)hipGetLastError();
 }
 

@@ -186,7 +186,16 @@ def _attention_backward(B, H, Lq, Lk, D, q, k, v, mask, att, d_att, lse, dq_ptr,
         # (which shapes it serves, and with how many keys per workgroup: the library's measured rule, attention_ops.hip)
         if _long_keys[0] and not short and not _compute_bf16[0]:
             need = int(_lib.butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ld_dq))
-        if need >= 0:
+        bf16_need = -1
+        if _long_keys[0] and not short and _compute_bf16[0]:
+            bf16_need = int(_lib.butd_attention_bwd_long_keys_bf16_scratch(B, H, Lq, Lk, D, ld_dq))
+        if bf16_need >= 0:      # the bf16 operating point: the long key sets in one pass as well
+            ws = torch.empty(max(bf16_need, 1), device=dev)
+            err = _lib.butd_attention_bwd_long_keys_bf16(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                                         _ptr(mask), att.data_ptr(), d_att.data_ptr(), lse.data_ptr(),
+                                                         dq_ptr, dk_ptr, dv_ptr, ld_dq, ld_dkv, scale, p_attn, site_attn,
+                                                         ctr, ws.data_ptr(), bf16_need, _stream(ref))
+        elif need >= 0:
             ws = torch.empty(max(need, 1), device=dev)
             err = _lib.butd_attention_bwd_long_keys(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(mask),
                                                     att.data_ptr(), d_att.data_ptr(), lse.data_ptr(), dq_ptr, dk_ptr,

@@ -197,6 +197,16 @@ int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const floa
                                  long ld_dkv, float dq_scale, float dropout_p, uint32_t dropout_site,
                                  const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream);
 
+/* butd_attention_bwd_long_keys with the matrix steps on the bf16 matrix cores (bf16 LDS images, v_mfma_f32_16x16x32_bf16,
+ * fp32 accumulation; BASELINE configs[3]): the long key sets only (where the fp32 plan is 256 keys per workgroup and one
+ * query split); `_scratch` returns -1 elsewhere and the caller uses butd_attention_bwd_bf16. */
+long butd_attention_bwd_long_keys_bf16_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq);
+int butd_attention_bwd_long_keys_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                      const float *v, const uint8_t *key_padding_mask, const float *out,
+                                      const float *dout, const float *lse, float *dq, float *dk, float *dv, long ld_dq,
+                                      long ld_dkv, float dq_scale, float dropout_p, uint32_t dropout_site,
+                                      const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream);
+
 /* The same two entry points with the matrix steps on the bf16 matrix cores (BASELINE configs[3]: "bf16 attention"):
  * operands rounded to bf16 (nearest even) in registers, v_mfma_f32_16x16x16_bf16, fp32 accumulation; scores'
  * statistics, exponentials, the (o, m, l) state, dropout masks and every tensor in memory are fp32 as above. */

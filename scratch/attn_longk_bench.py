@@ -69,4 +69,11 @@ for Lq, Lk, masked in SHAPES:
                 worst = max(worst, float((a - r).abs().max() / r.abs().max()))
             line += f" {chunk[0]}:{chunk[1]} {tg(one):6.1f} ({worst:.0e}) |"
         lib.butd_attention_bwd_long_keys_set_chunk(0, 0)
+        nb = int(lib.butd_attention_bwd_long_keys_bf16_scratch(B, H, Lq, Lk, D, 3 * E))
+        if nb >= 0 and os.environ.get("BF16") == "1":       # the bf16 entry points: two kernels | one pass
+            wsb = torch.empty(max(nb, 1), device=dev)
+            two_h = lambda: lib.butd_attention_bwd_bf16(*args(), delta.data_ptr(), *outs(), st())
+            one_h = lambda: lib.butd_attention_bwd_long_keys_bf16(*args(), *outs(), wsb.data_ptr(), nb, st())
+            assert two_h() == 0 and one_h() == 0
+            line += f" bf16: two kernels {tg(two_h):6.1f} | one pass {tg(one_h):6.1f} |"
         print(line, flush=True)

@@ -304,6 +304,61 @@ def test_bf16_attention_core_alone(mods):
         _close(res["bf16"][i], res["f32"][i], 3e-2)
 
 
+@pytest.mark.parametrize("B,Lq,Lk,masked", [(8, 1024, 1024, False), (8, 256, 1024, False), (8, 80, 1024, True), (4, 200, 1500, True)])
+def test_bf16_long_key_backward_in_one_pass(mods, B, Lq, Lk, masked):
+    """butd_attention_bwd_long_keys_bf16 (one pass, bf16 images, K = 32 matrix instruction) against the two bf16 kernels on
+    the same saved forward (the dropout scale rides on V here and on dO in the dQ kernel, so other operand roundings: within
+    1.5e-2 of the scale of each other) and against the fp32 backward (3e-2, the bound of the bf16 entry points, and no
+    further from fp32 than the two kernels are); packed gradient rows; bit-identical between two runs."""
+    from butd_detr_amd import _hiplib
+    ab, fa, _, _ = mods
+    lib = _hiplib.load()
+    H, D = 8, 36
+    E = H * D
+    g = torch.Generator(device="cuda").manual_seed(Lq + Lk)
+    q, k, v, do = (torch.randn(B, L, E, device="cuda", generator=g) * 0.5 for L in (Lq, Lk, Lk, Lq))
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.uint8, device="cuda")
+        for b in range(B):
+            mask[b, Lk - 1 - 37 * b:] = 1
+    mp = mask.data_ptr() if mask is not None else None
+    ctr = fa.rng_counter(q.device).data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    out, lse = torch.empty_like(q), torch.empty(B, H, Lq, device="cuda")
+    assert lib.butd_attention_fwd_bf16(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(),
+                                       lse.data_ptr(), 0.1, 5, ctr, st) == 0
+    ldq, ldkv = E + 4, 2 * E
+    need = int(lib.butd_attention_bwd_long_keys_bf16_scratch(B, H, Lq, Lk, D, ldq))
+    assert need == ((Lk + 255) // 256) * B * Lq * E
+    assert lib.butd_attention_bwd_long_keys_bf16_scratch(B, H, 256, 132, D, ldq) == -1      # short key sets: the two kernels
+    res = {}
+    for name in ("f32", "two", "one", "one again"):
+        dqb = torch.full((B, Lq, ldq), 7.0, device="cuda")
+        G = torch.full((B, Lk, ldkv), 7.0, device="cuda")
+        delta = torch.empty(B, H, Lq, device="cuda")
+        args = (B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mp, out.data_ptr(), do.data_ptr(), lse.data_ptr())
+        outs = (dqb.data_ptr(), G.data_ptr(), G.data_ptr() + 4 * E, ldq, ldkv, 0.5, 0.1, 5, ctr)
+        if name == "f32":
+            assert lib.butd_attention_bwd(*args, delta.data_ptr(), *outs, st) == 0
+        elif name == "two":
+            assert lib.butd_attention_bwd_bf16(*args, delta.data_ptr(), *outs, st) == 0
+        else:
+            ws = torch.full((need,), float("nan"), device="cuda")
+            assert lib.butd_attention_bwd_long_keys_bf16(*args, *outs, ws.data_ptr(), need, st) == 0
+        torch.cuda.synchronize()
+        res[name] = (dqb[:, :, :E].clone(), G[:, :, :E].clone(), G[:, :, E:].clone(), dqb[:, :, E:].clone())
+    assert float(res["one"][3].min()) == 7.0 and float(res["one"][3].max()) == 7.0
+    err = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    for i, name in enumerate(("dq", "dk", "dv")):
+        assert torch.isfinite(res["one"][i]).all()
+        e_one, e_two = err(res["one"][i], res["f32"][i]), err(res["two"][i], res["f32"][i])
+        print(f"{name}: one pass vs fp32 {e_one:.2e}, two kernels vs fp32 {e_two:.2e}, one vs two {err(res['one'][i], res['two'][i]):.2e}")
+        assert e_one <= 3e-2 and e_one <= 1.5 * e_two + 1e-3, (name, e_one, e_two)      # no further from fp32 than the two kernels
+        _close(res["one"][i], res["two"][i], 1.5e-2)
+        assert torch.equal(res["one"][i], res["one again"][i])
+
+
 def test_chain_of_blocks_with_the_position_sum_from_the_layernorm_kernel(mods):
     """``next_pos`` / ``xq_pre`` (butd_add_dropout_layernorm_fwd_pos): a block writes `output + pos` for the next
     block, which uses it in place of its own `x + pos` -- values and every gradient (x, pos, memory, parameters) equal
