@@ -39,8 +39,8 @@ unset BUTD_BENCH_NO_CHILD
   python scratch/attn_occ.py 2>/dev/null | grep "B="
   echo "# dropout off / on (what the mask hash costs) and the decoder's shapes:"
   python scratch/attn_bench.py 2>/dev/null | grep "Lq="
-  echo "# the one-pass backward (butd_attention_bwd_long_keys, the library's plan) next to the two-kernel walk, dropout 0.0 / 0.1:"
-  python scratch/attn_longk_bench.py 2>/dev/null | grep " x "
+  echo "# the one-pass backward (butd_attention_bwd_long_keys, the library's plan) next to the two-kernel walk, dropout 0.0 / 0.1; bf16: the bf16 entry points, two kernels | one pass:"
+  BF16=1 python scratch/attn_longk_bench.py 2>/dev/null | grep " x "
   SHAPES=short python scratch/attn_longk_bench.py 2>/dev/null | grep " x "
   echo "# the bf16 entry points (bf16 LDS images, v_mfma_f32_16x16x32_bf16; round 4: fwd 96 / bwd 288 us at 1024 x 1024):"
   BF16=1 python scratch/attn_bench.py 2>/dev/null | grep "Lq="; } > $O/r05_attention_core.txt
