@@ -2603,23 +2603,24 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_h_kernel(
 // instruction (K^T operands in registers, dS transposed through two wave-private LDS patches): 8.5 matrix instructions per
 // score tile where the dQ walk + the dK/dV walk issue 12.5, and ONE pass of the exponentials, dropout hashes and
 // roundings those kernels are bound by.  fp32: statistics, exponentials, accumulators, everything in memory.
-template <int NS, int NT>
-__global__ __launch_bounds__(512) void attn_bwd_longk_h_kernel(
+template <int NS, int NT, int kWaves, int kSub>
+__global__ __launch_bounds__(kWaves * 64) void attn_bwd_longk_h_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, const float *__restrict__ out,
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ dq_out, long ld_dq,
-    long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, float p_drop,
-    uint32_t site, const uint64_t *__restrict__ rng_counter) {
+    long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, long kv_stride,
+    int chunks, int q_tiles_per_wg, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = ImgH<NS>;
   using T = TImgH<NT>;
-  constexpr int kWaves = 8, kSub = 2, kThreads = kWaves * 64, kChunk = kWaves * kSub * 16;
+  static_assert(kSub == 1 || kSub == 2, "one K = 32 contraction per wave (a single sub-tile leaves its upper half zero)");
+  constexpr int kThreads = kWaves * 64, kChunk = kWaves * kSub * 16;
   constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD, LDX = 20;
   constexpr int kVec = 64 * 16 / kThreads;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *Lse = smem;                                   // [64]  lse * log2(e)
   float *Del = Lse + 64;                               // [64]
-  float *X = Del + 64;                                 // [waves][2 sub-tiles][16][LDX]
-  float *Red = X + kWaves * 2 * 16 * LDX;              // [waves][64][D]
+  float *X = Del + 64;                                 // [waves][sub-tiles][16][LDX]
+  float *Red = X + kWaves * kSub * 16 * LDX;           // [waves][64][D]
   __bf16 *Qimg = reinterpret_cast<__bf16 *>(Red + kWaves * 64 * D);
   __bf16 *Gimg = Qimg + kImg;
   __bf16 *Qt = Gimg + kImg;
@@ -2627,7 +2628,7 @@ __global__ __launch_bounds__(512) void attn_bwd_longk_h_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const TileId wg = tile_id();
-  const int b = wg.b, h = wg.h, chunk = wg.t;
+  const int b = wg.b, h = wg.h, chunk = wg.t % chunks, qsplit = wg.t / chunks;     // (see attn_bwd_longk_kernel)
   const long E = (long)H * D;
   const int k0 = chunk * kChunk + wave * (kSub * 16);
   const bool wave_live = k0 < Lk;
@@ -2672,7 +2673,7 @@ __global__ __launch_bounds__(512) void attn_bwd_longk_h_kernel(
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int key = k0 + (e >> 2) * 16 + fg * 4 + (e & 3), d = nt * 16 + fr;
-      kaH[nt][e] = (__bf16)((key < Lk && d < D) ? kb[(long)key * E + d] : 0.f);
+      kaH[nt][e] = (__bf16)(((e >> 2) < kSub && key < Lk && d < D) ? kb[(long)key * E + d] : 0.f);
     }
   f32x4 ak[kSub][NT], av[kSub][NT];
 #pragma unroll
@@ -2728,14 +2729,15 @@ __global__ __launch_bounds__(512) void attn_bwd_longk_h_kernel(
     }
     if (tid < 64) Lse[tid] = sr;
   };
-  const int iters = (Lq + 63) / 64;
-  fetch(0);
+  const int tile0 = qsplit * q_tiles_per_wg;
+  const int iters = min(q_tiles_per_wg, (Lq + 63) / 64 - tile0);
+  fetch(tile0 * 64);
   __syncthreads();
   commit();
   __syncthreads();
-  float *Xw = X + wave * 2 * 16 * LDX, *Rw = Red + wave * 64 * D;
+  float *Xw = X + wave * kSub * 16 * LDX, *Rw = Red + wave * 64 * D;
   for (int it = 0; it < iters; ++it) {
-    const int qs = it * 64;
+    const int qs = (tile0 + it) * 64;
     const bool more = it + 1 < iters;
     if (wave_live) {
 #pragma unroll 1
@@ -2779,7 +2781,8 @@ __global__ __launch_bounds__(512) void attn_bwd_longk_h_kernel(
           }
           __builtin_amdgcn_wave_barrier();
           const f32x4 dst0 = *reinterpret_cast<const f32x4 *>(Xw + fr * LDX + fg * 4);
-          const f32x4 dst1 = *reinterpret_cast<const f32x4 *>(Xw + 16 * LDX + fr * LDX + fg * 4);
+          f32x4 dst1 = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (kSub == 2) dst1 = *reinterpret_cast<const f32x4 *>(Xw + 16 * LDX + fr * LDX + fg * 4);
           __builtin_amdgcn_wave_barrier();
           const bf16x8 sT = pack8(dst0, dst1);
 #pragma unroll
@@ -2816,8 +2819,8 @@ __global__ __launch_bounds__(512) void attn_bwd_longk_h_kernel(
   for (int j = 0; j < kSub; ++j) {
     const int ki = k0 + j * 16 + fr;
     if (ki < Lk) {
-      float *okp = dk + ((long)b * Lk + ki) * ldo + h * D;
-      float *ovp = dv + ((long)b * Lk + ki) * ldo + h * D;
+      float *okp = dk + qsplit * kv_stride + ((long)b * Lk + ki) * ldo + h * D;
+      float *ovp = dv + qsplit * kv_stride + ((long)b * Lk + ki) * ldo + h * D;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -3037,16 +3040,37 @@ int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const floa
   return (int)hipGetLastError();
 }
 
-/* the same walk on the bf16 matrix cores (BASELINE configs[3]): served where the fp32 plan is 256 keys per workgroup and
- * one query split (the long key sets); everything else stays on the two bf16 kernels */
+/* the same walk on the bf16 matrix cores (BASELINE configs[3]): the fp32 plan's 256- and 64-key chunks (8 waves x 2 / 4 waves
+ * x 1 sub-tiles: a single sub-tile fills half of the dQ product's K = 32 contraction) with the same slabs and fold */
 long butd_attention_bwd_long_keys_bf16_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq) {
   if (B <= 0 || H <= 0 || Lq <= 0 || Lk <= 0) return -1;
   const LongkPlan p = longk_plan(B, H, Lq, Lk, D);
-  if (p.chunk != 256 || p.q_splits != 1 || p.chunks < 2) return -1;
-  if (ld_dq == 0) ld_dq = (long)H * D;
-  if (ld_dq & 3) return -1;
-  return (long)p.chunks * B * Lq * H * D;
+  if (p.chunk != 256 && p.chunk != 64) return -1;
+  // measured (8 x 8 heads, us, two bf16 kernels | one pass): 1024 x 1024: 256 | 135; 256 x 1024: 89 | 58; 80 x 1024: 71 | 44;
+  // 1024 x 80: 77 | 47; 1024 x 132: 83 | 78; 256 x 132: 37 | 34; 256 x 80: 32 | 29; 80 x 80: 27 | 20; 256 x 256: 38 | 40
+  if (!g_longk_force_chunk && p.chunk == 64 && p.chunks >= 4 && (Lq + 63) / 64 <= 4) return -1;
+  return butd_attention_bwd_long_keys_scratch(B, H, Lq, Lk, D, ld_dq);
 }
+
+extern "C++" {
+template <int WAVES, int SUB>
+static int launch_longk_h(const LongkPlan &p, int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                          const float *v, const uint8_t *mask, const float *out, const float *dout, const float *lse,
+                          float *dq_out, long ld_dq, long chunk_stride, float dq_scale, float *dk, float *dv, long ld_dkv,
+                          long kv_stride, float pd, uint32_t site, const uint64_t *rng_counter, hipStream_t s) {
+  using I = ImgH<9>;
+  using T = TImgH<3>;
+  const size_t bytes = sizeof(float) * (size_t)(64 + 64 + WAVES * SUB * 16 * 20 + WAVES * 64 * 36) +
+                       sizeof(__bf16) * (size_t)(2 * 64 * I::LD + 2 * T::ROWS * T::LD);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_longk_h_kernel<9, 3, WAVES, SUB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL((attn_bwd_longk_h_kernel<9, 3, WAVES, SUB>), dim3(p.chunks * p.q_splits, H, B), dim3(WAVES * 64), bytes, s, H,
+                     Lq, Lk, D, q, k, v, mask, out, dout, lse, dq_out, ld_dq, chunk_stride, dq_scale, dk, dv, ld_dkv, kv_stride,
+                     p.chunks, p.q_tiles_per_wg, pd, site, rng_counter);
+  return 0;
+}
+}  // extern "C++"
 
 int butd_attention_bwd_long_keys_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
                                       const float *v, const uint8_t *key_padding_mask, const float *out,
@@ -3054,30 +3078,43 @@ int butd_attention_bwd_long_keys_bf16(int B, int H, int Lq, int Lk, int D, const
                                       long ld_dkv, float dq_scale, float dropout_p, uint32_t dropout_site,
                                       const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream) {
   const long need = butd_attention_bwd_long_keys_bf16_scratch(B, H, Lq, Lk, D, ld_dq);
-  if (need < 0 || !ws || ws_floats < need) return (int)hipErrorInvalidValue;
+  if (need < 0 || (need > 0 && !ws) || ws_floats < need) return (int)hipErrorInvalidValue;
   if (ld_dq == 0) ld_dq = (long)H * D;
   if (ld_dkv == 0) ld_dkv = (long)H * D;
-  if (ld_dq < (long)H * D || ld_dkv < (long)H * D) return (int)hipErrorInvalidValue;
+  if (ld_dq < (long)H * D || ld_dkv < (long)H * D || (ld_dkv & 3)) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const LongkPlan p = longk_plan(B, H, Lq, Lk, D);
-  const long E = (long)H * D, q_slab = (long)B * Lq * E;
-  using I = ImgH<9>;
-  using T = TImgH<3>;
-  const size_t bytes = sizeof(float) * (size_t)(64 + 64 + 8 * 2 * 16 * 20 + 8 * 64 * 36) +
-                       sizeof(__bf16) * (size_t)(2 * 64 * I::LD + 2 * T::ROWS * T::LD);
-  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&attn_bwd_longk_h_kernel<9, 3>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  if (attr != hipSuccess) return (int)attr;
-  hipLaunchKernelGGL((attn_bwd_longk_h_kernel<9, 3>), dim3(p.chunks, H, B), dim3(512), bytes, s, H, Lq, Lk, D, q, k, v,
-                     key_padding_mask, out, dout, lse, ws, E, q_slab, 1.f, dk, dv, ld_dkv, dropout_p, dropout_site,
-                     rng_counter);
-  FoldArgs fa;
-  fa.nseg = 1;
-  fa.E4 = (int)(E / 4);
-  fa.seg[0].ws = ws; fa.seg[0].dst = dq; fa.seg[0].slabs = p.chunks; fa.seg[0].slab_stride = q_slab;
-  fa.seg[0].rows = (long)B * Lq; fa.seg[0].ld = ld_dq; fa.seg[0].scale = dq_scale; fa.seg[0].first = 0;
-  fa.total = (long)B * Lq * (E / 4);
-  hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((fa.total + 255) / 256)), dim3(256), 0, s, fa);
+  const long E = (long)H * D, q_slab = (long)B * Lq * E, kv_slab = (long)B * Lk * E;
+  const bool dq_slabs = p.chunks > 1, kv_slabs = p.q_splits > 1;
+  float *ws_q = ws, *ws_k = ws + (dq_slabs ? p.chunks * q_slab : 0), *ws_v = ws_k + (kv_slabs ? p.q_splits * kv_slab : 0);
+  int err;
+#define LONGKH(W, S)                                                                                                          \
+  launch_longk_h<W, S>(p, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, dout, lse, dq_slabs ? ws_q : dq,                    \
+                       dq_slabs ? E : ld_dq, dq_slabs ? q_slab : 0, dq_slabs ? 1.f : dq_scale, kv_slabs ? ws_k : dk,          \
+                       kv_slabs ? ws_v : dv, kv_slabs ? E : ld_dkv, kv_slabs ? kv_slab : 0, dropout_p, dropout_site,         \
+                       rng_counter, s)
+  if (p.chunk == 256) err = LONGKH(8, 2);
+  else err = LONGKH(4, 1);
+#undef LONGKH
+  if (err) return err;
+  if (dq_slabs || kv_slabs) {
+    FoldArgs fa;
+    fa.nseg = 0;
+    fa.E4 = (int)(E / 4);
+    fa.total = 0;
+    auto add = [&](const float *src, float *dst, int slabs, long stride, long rows, long ld, float scale) {
+      FoldSeg &g = fa.seg[fa.nseg++];
+      g.ws = src; g.dst = dst; g.slabs = slabs; g.slab_stride = stride; g.rows = rows; g.ld = ld; g.scale = scale;
+      g.first = fa.total;
+      fa.total += rows * (E / 4);
+    };
+    if (dq_slabs) add(ws_q, dq, p.chunks, q_slab, (long)B * Lq, ld_dq, dq_scale);
+    if (kv_slabs) {
+      add(ws_k, dk, p.q_splits, kv_slab, (long)B * Lk, ld_dkv, 1.f);
+      add(ws_v, dv, p.q_splits, kv_slab, (long)B * Lk, ld_dkv, 1.f);
+    }
+    hipLaunchKernelGGL(attn_dq_fold_kernel, dim3((unsigned)((fa.total + 255) / 256)), dim3(256), 0, s, fa);
+  }
   return (int)hipGetLastError();
 }
 

@@ -198,8 +198,8 @@ int butd_attention_bwd_long_keys(int B, int H, int Lq, int Lk, int D, const floa
                                  const uint64_t *rng_counter, float *ws, long ws_floats, butd_stream_t stream);
 
 /* butd_attention_bwd_long_keys with the matrix steps on the bf16 matrix cores (bf16 LDS images, v_mfma_f32_16x16x32_bf16,
- * fp32 accumulation; BASELINE configs[3]): the long key sets only (where the fp32 plan is 256 keys per workgroup and one
- * query split); `_scratch` returns -1 elsewhere and the caller uses butd_attention_bwd_bf16. */
+ * fp32 accumulation; BASELINE configs[3]): the same plan (256- and 64-key chunks, query splits), slabs and fold; `_scratch`
+ * returns -1 where the fp32 entry point does (the caller then uses butd_attention_bwd_bf16). */
 long butd_attention_bwd_long_keys_bf16_scratch(int B, int H, int Lq, int Lk, int D, long ld_dq);
 int butd_attention_bwd_long_keys_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
                                       const float *v, const uint8_t *key_padding_mask, const float *out,

@@ -71,6 +71,7 @@ for Lq, Lk, masked in SHAPES:
         lib.butd_attention_bwd_long_keys_set_chunk(0, 0)
         nb = int(lib.butd_attention_bwd_long_keys_bf16_scratch(B, H, Lq, Lk, D, 3 * E))
         if nb >= 0 and os.environ.get("BF16") == "1":       # the bf16 entry points: two kernels | one pass
+            G.zero_(); Gq.zero_()
             wsb = torch.empty(max(nb, 1), device=dev)
             two_h = lambda: lib.butd_attention_bwd_bf16(*args(), delta.data_ptr(), *outs(), st())
             one_h = lambda: lib.butd_attention_bwd_long_keys_bf16(*args(), *outs(), wsb.data_ptr(), nb, st())
