@@ -129,7 +129,10 @@ def test_riders_and_the_final_flush_inside_a_backward_pass():
     for n in a:
         # (a convolution bias in front of a BatchNorm has a zero gradient: both runs hold rounding noise there)
         scale = max(float(atom[n].abs().max()), 1e-3 * top)
-        assert float((a[n] - atom[n]).abs().max()) <= 2e-5 * scale, n
+        # (the 6 -> 288 position embedding's thin products run in 32 atomic slices of 64 rows since round 5: the atomic
+        #  leg's own arrival-order noise on sums of 2048 O(1) terms is 2-4e-6 absolute, seen failing 2e-5 in 5 of 12 runs)
+        tol = 1e-4 if n.startswith("self_posembed") else 2e-5
+        assert float((a[n] - atom[n]).abs().max()) <= tol * scale, n
         if not n.startswith("self_posembed"):      # (the Conv + BatchNorm chain's products are fused_mlp's)
             assert torch.equal(a[n], b[n]), n      # bit-reproducible (the atomic path is not)
     assert torch.equal(q_a, q_b)
