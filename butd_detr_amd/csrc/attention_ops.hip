@@ -644,12 +644,18 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
     unsigned long long t2 = t1, t3 = t1, t4 = t1;
 #endif
     if (live) {
+      // 16-key sub-tiles of this tile that hold a key at all (uniform; 4 except in the last tile: 80 text tokens = 4 + 1,
+      // 132 boxes = 4 + 4 + 1): the others keep a zero score, get the -inf bias below and are skipped by both products
+      const int live_t = min(4, (Lk - key0 + 15) >> 4);
       f32x4 st[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        float kf[NS];
-        I::frag(kf, Kimg[cur], t * 16 + fr, fg);
-        st[t] = mma_d<NS, BF>(make_frag<NS, BF>(kf), qF, (f32x4){0.f, 0.f, 0.f, 0.f});
+        st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (t < live_t) {
+          float kf[NS];
+          I::frag(kf, Kimg[cur], t * 16 + fr, fg);
+          st[t] = mma_d<NS, BF>(make_frag<NS, BF>(kf), qF, st[t]);
+        }
       }
       // the first V operands travel while the softmax runs
       f32x4 va[NT];
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
             const float a4[4] = {va[nt][0], va[nt][1], va[nt][2], va[nt][3]};
             o[nt] = mma_k16(a4, st[t], o[nt]);
           }
-        } else {
+        } else if (t < live_t) {
 #pragma unroll
           for (int s = 0; s < 4; ++s)
 #pragma unroll
