@@ -102,7 +102,7 @@ def gemm_work(step_fn):
     from butd_detr_amd import fused_attention as fa
     import butd_detr_amd.fused_mlp as fmlp
     import butd_detr_amd.fused_sa as fsa
-    work = {"launches": 0, "flops": 0.0, "bytes": 0.0}
+    work = {"launches": 0, "flops": 0.0, "bytes": 0.0, "attention_flops": 0.0, "attention_launches": 0}
     orig = fa._gemm
 
     def counted(problems, ref):
@@ -111,12 +111,18 @@ def gemm_work(step_fn):
         work["bytes"] += sum(4.0 * (p.M * p.K + p.N * p.K + p.M * p.N) for p in problems)
         orig(problems, ref)
 
+    def attention(kind, flops):         # every attention-core call of the step (fused_attention._count_attention)
+        work["attention_flops"] += flops
+        work["attention_launches"] += 1
+
     fa._gemm = fsa._gemm = fmlp._gemm = counted
+    prev_hook, fa._work_hook[0] = fa._work_hook[0], attention
     try:
         step_fn()
         torch.cuda.synchronize()
     finally:
         fa._gemm = fsa._gemm = fmlp._gemm = orig
+        fa._work_hook[0] = prev_hook
     return work
 
 
@@ -289,6 +295,8 @@ def gemm_roofline(args, fallback_step=None):
             "duration_source": source or ("rocprofv3 --kernel-trace --stats of the captured step in a child process "
                                           "(%d launches over %d steps profiled)" % (calls, steps)),
             "algorithmic_flops_per_step": work["flops"], "algorithmic_bytes_per_step": work["bytes"],
+            "attention_flops_per_step": work.get("attention_flops"), "attention_calls_per_step": work.get("attention_launches"),
+            "steps_in_trace": steps,
             "algorithmic_bytes_per_launch": round(work["bytes"] / max(launches, 1)),
             "traffic_over_algorithmic": (round(traffic / (work["bytes"] / max(launches, 1)), 3)
                                          if traffic else None)}
@@ -574,6 +582,70 @@ def encoder6_row(args, device, criterion, batches):
             "final_loss": round(float(loss), 4)}
 
 
+def in_situ_row(args, model, opt, criterion, batches, gemm, sa_lin):
+    """What the kernels achieve INSIDE the step (the stand-alone microbenchmarks of one site are the best case):
+    * attention core over ALL sites of the step, from the roofline child's trace: the flops of every attention call
+      (4 B H Lq Lk D forward, 2.5 x backward; counted in the child) / the summed durations of the attention kernels;
+    * per-region time and matrix-core rate from marks captured into the step's graph (butd_detr_amd/step_regions.py:
+      s_memrealtime stamps at region boundaries, no profiler; the marks themselves cost ~0.2 ms per step).  Region flops
+      = grouped-GEMM problems + attention calls launched inside the region; the backbone's products that left the
+      grouped GEMM (roofline_sa_linear.matrix_flops_per_step) are added to the backbone."""
+    from butd_detr_amd import step_regions
+    from butd_detr_amd.train_step import GraphedTrainStep
+    out = {}
+    steps = gemm.get("steps_in_trace") or 0
+    if _LAST_CHILD_ROWS and steps and gemm.get("attention_flops_per_step"):
+        names = ("attn_fwd_kernel", "attn_bwd", "attn_dq_fold")      # ("attn_fwd" alone is the language model's SDPA kernel)
+        per = {}
+        for n, _, t in _LAST_CHILD_ROWS:
+            for key in names:
+                if key in n:
+                    per[key] = per.get(key, 0.0) + t / steps * 1e-6
+        ms = sum(per.values())
+        tf = gemm["attention_flops_per_step"] / (ms * 1e-3) / 1e12
+        out["attention_core"] = {
+            "what": "every attention call of one training step (%d forward + backward launches' worth of sites: 1024x1024, "
+                    "80x80, 80x1024, 1024x80, 1024x132 in the encoder; 256x256, 256x80, 256x132, 256x1024 in the decoder)"
+                    % gemm["attention_calls_per_step"],
+            "gflop_per_step": round(gemm["attention_flops_per_step"] * 1e-9, 2), "ms_per_step": round(ms, 3),
+            "ms_per_kernel_family": {k: round(v, 3) for k, v in per.items()},
+            "achieved": round(tf, 2), "peak": FP32_MATRIX_PEAK_TF, "unit": "TFLOP/s",
+            "frac": round(tf / FP32_MATRIX_PEAK_TF, 4),
+            "source": "rocprofv3 --kernel-trace of the captured step (the roofline child)"}
+        fam = gemm["algorithmic_flops_per_step"] + gemm["attention_flops_per_step"]
+        fam_ms = gemm["ms_per_step_in_kernel"] + ms
+        out["attention_plus_products"] = {
+            "what": "gemm_kernel + the attention kernels together (projections, FFN, heads, set-abstraction products on "
+                    "the grouped GEMM, and the attention core)",
+            "ms_per_step": round(fam_ms, 3), "achieved": round(fam / (fam_ms * 1e-3) / 1e12, 2),
+            "frac": round(fam / (fam_ms * 1e-3) / 1e12 / FP32_MATRIX_PEAK_TF, 4)}
+    graphed = GraphedTrainStep(model, opt, criterion=criterion)
+    marks = step_regions.StepMarks(model, graphed, next(model.parameters()).device).install()
+    try:
+        n = len(batches)
+        for k in range(max(args.warmup, 4)):
+            graphed(*batches[k % n], next_inputs=batches[(k + 1) % n][0])
+        res = marks.measure(batches, replays=12)
+    finally:
+        marks.remove()
+    regions = res["regions"]
+    if sa_lin and "backbone" in regions:           # the products of csrc/sa_last_bwd.hip are not grouped-GEMM calls
+        r = regions["backbone"]
+        r["gflop"] = round(r["gflop"] + sa_lin["matrix_flops_per_step"] * 1e-9, 2)
+        r["tflops"] = round(r["gflop"] / r["ms"], 2)
+        r["frac_of_fp32_matrix_peak"] = round(r["tflops"] / FP32_MATRIX_PEAK_TF, 4)
+    out["regions"] = regions
+    out["regions_ms_per_step_with_marks"] = round(res["ms_per_step"], 3)
+    out["regions_marks"] = res["marks"]
+    out["regions_source"] = ("s_memrealtime marks captured into the step's hipGraph (butd_detr_amd/step_regions.py), mean of "
+                             "10 free-running replays; forward intervals belong to the module whose mark ends them, backward "
+                             "intervals to the module whose mark starts them")
+    if os.environ.get("BUTD_STEP_MARKS_OUT"):
+        with open(os.environ["BUTD_STEP_MARKS_OUT"], "w") as f:
+            f.write(step_regions.format_intervals(res) + "\n")
+    return out
+
+
 def _flush_c_stdio():
     import ctypes
     try:
@@ -726,9 +798,13 @@ def main():
             sa_lin = sa_linear_roofline(args, out["roofline"]) if args.dtype == "f32" else None
             if sa_lin:
                 out["roofline_sa_linear"] = sa_lin
+            if world == 1 and not args.eager and args.dtype == "f32":
+                out["in_situ"] = in_situ_row(args, model, opt, criterion, batches, out["roofline"], sa_lin)
             if not args.no_extras:
                 out["roofline_ball_query"] = ball_query_roofline(inputs)
                 out["roofline_attention"] = attention_roofline(args.batch)
+                out["roofline_attention"]["scope"] = ("stand-alone, best site (the encoder's 1024 x 1024 visual self-attention); "
+                                                      "in_situ.attention_core is the figure over all sites of the step")
                 out["matcher_detection_split"] = matcher_at_detection_size(args.batch)
         else:
             out["roofline"] = ball_query_roofline(inputs)

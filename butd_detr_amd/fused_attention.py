@@ -119,6 +119,14 @@ def _ptr(t):
 
 
 _compute_bf16 = [False]
+# measurement hook (bench.py / step_regions.py): called as hook(kind, flops) for every attention-core launch
+# ("attn_fwd": 4 B H Lq Lk D; "attn_bwd": 2.5 x that); None on the product path
+_work_hook = [None]
+
+
+def _count_attention(kind, B, H, Lq, Lk, D):
+    if _work_hook[0] is not None:
+        _work_hook[0](kind, (4.0 if kind == "attn_fwd" else 10.0) * B * H * Lq * Lk * D)
 
 
 def set_compute_dtype(name):
@@ -208,6 +216,7 @@ def _attention_backward(B, H, Lq, Lk, D, q, k, v, mask, att, d_att, lse, dq_ptr,
                 lse.data_ptr(), delta.data_ptr(), dq_ptr, dk_ptr, dv_ptr, ld_dq, ld_dkv, scale, p_attn, site_attn, ctr,
                 _stream(ref))
     _hiplib.check(err, "butd_attention_bwd")
+    _count_attention("attn_bwd", B, H, Lq, Lk, D)
 
 
 def get_compute_dtype():
@@ -442,6 +451,7 @@ class _AttentionBlock(torch.autograd.Function):
                                           _ptr(mask), att.data_ptr(), lse.data_ptr(), p_attn, site_attn,
                                           rng_counter(dev).data_ptr(), _stream(xq))
         _hiplib.check(err, "butd_attention_fwd")
+        _count_attention("attn_fwd", B, H, Lq, Lk, D)
         proj = torch.empty((B, Lq, E), device=dev)
         _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], xq)
         y = torch.empty((B, Lq, E), device=dev)
@@ -778,6 +788,7 @@ class _XpmBlock(torch.autograd.Function):
                                           _ptr(mask), att.data_ptr(), lse.data_ptr(), p_attn, site_attn,
                                           rng_counter(dev).data_ptr(), _stream(x))
         _hiplib.check(err, "butd_attention_fwd")
+        _count_attention("attn_fwd", B, H, Lq, Lk, D)
         proj = torch.empty((B, Lq, E), device=dev)
         y = torch.empty((B, Lq, E), device=dev)
         mean = torch.empty((Mq,), device=dev)
