@@ -107,7 +107,8 @@ def attention_block(attn, dropout, norm, *, residual, query, key, value, key_pad
     return norm(residual + dropout(out))
 
 
-def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None, ffn=None):
+def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None, ffn=None,
+          hoisted=None):
     """The block in the two shapes the model uses it (every call site of
     encoder_decoder_layers.py:87-122,149-155,179-185,356-404):
         memory is None:  self-attention,  query = key = x (+ pos), value = x
@@ -116,11 +117,12 @@ def block(attn, dropout, norm, *, x, pos=None, memory=None, key_padding_mask=Non
 
     Hand-over hints (fused backend; the stock path ignores them and every block computes its own operands):
     ``next_pos`` -- also produce ``y + next_pos`` (from the LayerNorm kernel that writes y), the next block's ``xq_pre``;
-    ``ffn``      -- (ffn Sequential, norm): the FFN block that follows (``next_pos`` then belongs to ITS output).
+    ``ffn``      -- (ffn Sequential, norm): the FFN block that follows (``next_pos`` then belongs to ITS output);
+    ``hoisted``  -- (fused_attention.DecoderMemory, layer, name): key / value projections of ``memory`` computed already.
     Returns y when neither next_pos nor ffn is given, else (y, y + next_pos | None)."""
     if _BACKEND == "hip" and x.is_cuda:
         from . import fused_attention
-        return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask, xq_pre, next_pos, ffn)
+        return fused_attention.block(attn, dropout, norm, x, pos, memory, key_padding_mask, xq_pre, next_pos, ffn, hoisted)
     q = x if pos is None else x + pos
     k, v = (q, x) if memory is None else (memory, memory)
     y = norm(x + dropout(_mha_torch(attn, q, k, v, key_padding_mask)))

@@ -324,8 +324,20 @@ class BeaUTyDETR(nn.Module):
         # the encoder outputs feed all decoder layers: one gradient sum per stream (fan_out.py)
         self._stage_hook(inputs, "decoder")
         n_dec = len(self.decoder)
-        vis_l, text_l = fan_out(vis, n_dec), fan_out(text_feats, n_dec)
-        det_l = fan_out(detected_feats if self.butd else None, n_dec)
+        # the three memories' key / value projections of ALL layers in a few grouped launches before the decoder, their
+        # input / weight gradients in one node after its backward (fused_attention.DecoderMemory; fused backend only)
+        memory_kv = None
+        if self._fused(vis):
+            from .fused_attention import decoder_memory
+            memory_kv = decoder_memory(list(self.decoder), [("text", "cross_l", text_feats),
+                                                              ("boxes", "cross_d", detected_feats if self.butd else None),
+                                                              ("seeds", "cross_v", vis)])
+        if memory_kv is None:
+            vis_l, text_l = fan_out(vis, n_dec), fan_out(text_feats, n_dec)
+            det_l = fan_out(detected_feats if self.butd else None, n_dec)
+        else:       # (no per-layer gradient of the memories arrives: the hoisted node returns their sums)
+            vis_l, text_l = (vis.detach(),) * n_dec, (text_feats.detach(),) * n_dec
+            det_l = ((detected_feats.detach() if self.butd else None),) * n_dec
         for i, (layer, head) in enumerate(zip(self.decoder, self.prediction_heads)):
             prefix = "last_" if i == self.num_decoder_layers - 1 else f"{i}head_"
             if self.self_position_embedding == "none":
@@ -338,7 +350,8 @@ class BeaUTyDETR(nn.Module):
                 raise NotImplementedError
             query = layer(query, vis_l[i], text_l[i], query_pos, None, text_padding_mask,
                           detected_feats=det_l[i],
-                          detected_mask=detected_mask if self.butd else None)
+                          detected_mask=detected_mask if self.butd else None,
+                          **({} if memory_kv is None else {"memory_kv": (memory_kv, i)}))
             # the layer output feeds the next layer, its head and the contrastive projection
             query, q_head, q_proj = fan_out(query, 3)
             if self.contrastive_align_loss:
@@ -346,6 +359,8 @@ class BeaUTyDETR(nn.Module):
             center, size = self._run_head(head, q_head.transpose(1, 2), cluster_xyz, end_points, prefix, features_pm=q_head)
             base_xyz, base_size = center.detach(), size.detach()   # (the reference clones: bdetr.py:275-276; the cat /
             # position embedding below copy them anyway and nothing writes the head outputs in place)
+        if memory_kv is not None:
+            memory_kv.token = None      # (the blocks hold the autograd edge; this breaks the token -> node -> object cycle)
         if proj_inputs:
             proj = unstack(self._normalized_proj(torch.stack([q for _, q in proj_inputs])))
             for i, (prefix, _) in enumerate(proj_inputs):

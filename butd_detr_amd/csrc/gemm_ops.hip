@@ -47,7 +47,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kThreads = 256;
 constexpr int kLdH = 40;   // bf16 image: 32 k + 8 pad per row (80 B)
 constexpr int kBK = 32, kLd = kBK + 4;  // slab depth; LDS row stride 36 floats = 9 x 16 B
-constexpr int kMaxProblems = 8;
+constexpr int kMaxProblems = 32;   // (the GemmBatch is a by-value kernel argument of ~14 KB: this runtime takes 64 KB, scratch/ubench/kernarg_size.hip)
 constexpr int kAffK = 320;  // contraction range whose A-operand affine is staged in LDS (fast path)
 
 // Loads that must be emitted as global_load_*: a FLAT load also counts against lgkmcnt, so the

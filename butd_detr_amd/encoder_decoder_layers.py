@@ -307,8 +307,10 @@ class BiDecoderLayer(nn.Module):
             self.self_posembed = None
 
     def forward(self, query, vis_feats, lang_feats, query_pos, padding_mask,
-                text_key_padding_mask, detected_feats=None, detected_mask=None):
-        """query (B,Q,d), vis (B,V,d), lang (B,L,d), query_pos (B,Q,3|6) -> (B,Q,d)."""
+                text_key_padding_mask, detected_feats=None, detected_mask=None, memory_kv=None):
+        """query (B,Q,d), vis (B,V,d), lang (B,L,d), query_pos (B,Q,3|6) -> (B,Q,d).
+        ``memory_kv`` (not in the reference): (fused_attention.DecoderMemory, layer index) -- the key / value projections of
+        the three memories were computed for all layers before the decoder (bdetr.py); None: each block projects its own."""
         if self.self_posembed is not None:
             query_pos = self.self_posembed(query_pos).transpose(1, 2).contiguous()
         else:
@@ -324,12 +326,13 @@ class BiDecoderLayer(nn.Module):
             return out if isinstance(out, tuple) else (out, None)
 
         boxes = detected_feats is not None
+        hoisted = (lambda name: None) if memory_kv is None else (lambda name: (memory_kv[0], memory_kv[1], name))
         query, qp = blk(self.self_attn, self.dropout1, self.norm1, x=query, pos=pos_s, key_padding_mask=padding_mask)
         query, qp = blk(self.cross_l, self.dropout_l, self.norm_l, x=query, pos=pos_l, xq_pre=qp, memory=lang_feats,
-                        key_padding_mask=text_key_padding_mask)
+                        key_padding_mask=text_key_padding_mask, hoisted=hoisted("text"))
         if boxes:
             query, qp = blk(self.cross_d, self.dropout_d, self.norm_d, x=query, pos=pos_d, xq_pre=qp,
-                            memory=detected_feats, key_padding_mask=detected_mask)
+                            memory=detected_feats, key_padding_mask=detected_mask, hoisted=hoisted("boxes"))
         query = ab.block(self.cross_v, self.dropout_v, self.norm_v, x=query, pos=pos_v, xq_pre=qp,
-                         memory=vis_feats, key_padding_mask=None, ffn=(self.ffn, self.norm2))[0]
+                         memory=vis_feats, key_padding_mask=None, ffn=(self.ffn, self.norm2), hoisted=hoisted("seeds"))[0]
         return query.contiguous()

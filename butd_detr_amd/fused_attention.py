@@ -248,7 +248,7 @@ def _problem(a, b, c, M, N, K, lda, ldb, ldc, *, a2=None, a2_mode=0, a2_scale=1.
                        *(() if c_bn is None else (_ptr(c_bn[0]), _ptr(c_bn[1]), int(c_bn[2]), float(c_bn[3]), int(c_bn[4]))))
 
 
-_MAX_GROUP = 8
+_MAX_GROUP = 32        # butd_gemm_grouped's limit (kMaxProblems)
 # Deterministic split-K (include/butd_attention.h: c_partial / fold_src).  A weight-gradient problem writes per-slice slabs;
 # its fold is an element-wise rider that joins the NEXT grouped launch of the same backward function (no launch of its
 # own), and what is still pending when that function returns goes out as one small launch (``fold_scope``).  The gradient
@@ -296,10 +296,16 @@ def fold_scope(backward):
         _scope_depth[0] += 1
         try:
             out = backward(ctx, *grads)
+        except BaseException:
+            if _scope_depth[0] == 1:
+                del _pending_folds[:]       # their slabs die with this frame: a later launch must not carry them
+            raise
         finally:
             _scope_depth[0] -= 1
         if _pending_folds and _scope_depth[0] == 0:
-            ref = next(g for g in grads if g is not None)
+            ref = next((g for g in grads if g is not None), None)
+            if ref is None:                 # (a node whose incoming gradients are all None: the current device's stream)
+                ref = torch.empty(0, device=torch.device("cuda", torch.cuda.current_device()))
             _flush_folds(ref)
         return out
     return wrapped
@@ -343,7 +349,9 @@ def _wgrad(dy, x, dw, db, M, N, K, **kw):
 
 def _slabbed(prob, dw, db):
     """The accumulate (split-K, atomics) problem ``prob`` with target dw (dense rows) / db in its deterministic form:
-    per-slice slabs + a fold problem (``prob._fold``) that ``_gemm`` schedules.  The fold STORES: dw / db need no zero fill."""
+    per-slice slabs + a fold problem (``prob._fold``) that ``_gemm`` schedules.  The fold STORES: dw / db need no zero fill --
+    and must have this ONE producer (every call site hands a fresh, disjoint slice of its gradient slab; a target that
+    already holds another product's share has to stay on the atomic form)."""
     if not _wgrad_slabs[0] or (prob.M * prob.N) % 4 or prob.ldc != prob.N or (dw.data_ptr() & 15):
         return prob
     kslab = (prob.K + 31) // 32
@@ -884,7 +892,298 @@ class _XpmBlock(torch.autograd.Function):
                 None, None, None, None, None, None, None, None)
 
 
-def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None, ffn=None):
+# -------------------------------------------------------------------------------------------------
+# The decoder's memories (round 6).  Every BiDecoderLayer cross-attends to the SAME three tensors -- the encoder's text,
+# box and seed features (bdetr.py:277-299, encoder_decoder_layers.py:376-395) -- so the key / value projections of all
+# layers depend on the encoder output alone.  ``DecoderMemory.project`` computes the 2 x 3 x n_layers projections in a few
+# grouped launches BEFORE the decoder (on a forked stream, next to the launch-bound query generation), and a layer's
+# cross-attention block is then  Q projection (2048 rows) -> attention -> output projection -> LayerNorm.
+# Backward mirrors it: every block writes its dK | dV side by side into ONE matrix per memory (row stride 2 E n_layers),
+# and when autograd has passed the last block the hoisted node computes the memory-side input gradient of ALL layers as one
+# product over the concatenated contraction ([dK_0 dV_0 ... dK_5 dV_5] . [W_0; ...; W_5]: no per-layer d_mem, no fan-in
+# sum) and the K / V weight gradients of all layers in grouped launches.  The blocks and the hoisted node are tied
+# together by a one-element token tensor (the autograd edge that orders them); the gradient matrices travel in the
+# shared ``DecoderMemory`` object, not through autograd.  BUTD_AB=decoder_kv_hoist=0 restores the per-block projections.
+# -------------------------------------------------------------------------------------------------
+_hoist = [switches.flag("decoder_kv_hoist", True)]
+_hoist_side = [switches.flag("decoder_kv_side", False)]   # measured, round 6: 21.35 ms forked, 21.17 on the main stream, 21.27 without the hoist (profiles/r06_decoder_hoist.txt)
+_hoist_streams = {}
+# problems per launch of the hoisted node (the library takes 32): measured in the step, 8 per launch 21.17 ms, everything
+# of a kind in one launch (12 x 8192-row, 24 small, 21 backward problems) 21.26 -- a launch that large picks the wide
+# tiles and its tail runs alone
+_HOIST_GROUP = [int(os.environ.get("BUTD_HOIST_GROUP", "12"))]
+
+
+def set_decoder_kv_hoist(flag, side=None):
+    prev = (_hoist[0], _hoist_side[0])
+    _hoist[0] = bool(flag)
+    if side is not None:
+        _hoist_side[0] = bool(side)
+    return prev
+
+
+class DecoderMemory:
+    """What the hoisted node and the cross-attention blocks of one forward pass share."""
+
+    def __init__(self, n_layers, E):
+        self.n_layers, self.E = n_layers, E
+        self.mem, self.kv, self.wcat = {}, {}, {}
+        self.G, self.dw, self.dead = {}, {}, set()
+        self.token = None
+        self.side, self.joined = None, True
+
+    def join(self, ref):
+        """The first consumer on the main stream waits for the forked projections."""
+        if not self.joined:
+            torch.cuda.current_stream(ref.device).wait_stream(self.side)
+            self.joined = True
+
+    def grad_matrix(self, name):
+        G = self.G.get(name)
+        if G is None:
+            B, Lk, _ = self.mem[name].shape
+            G = self.G[name] = torch.empty((B, Lk, 2 * self.E * self.n_layers), device=self.mem[name].device)
+        return G
+
+    def weight_grads(self, layer, name, device):
+        t = self.dw.get((layer, name))
+        if t is None:
+            E = self.E
+            slab = zeros(3 * E * E + 3 * E, device=device)
+            t = self.dw[(layer, name)] = (slab[:3 * E * E].view(3 * E, E), slab[3 * E * E:])
+        return t
+
+    def release(self):
+        self.kv.clear(); self.G.clear(); self.dw.clear(); self.wcat.clear(); self.mem.clear()
+
+
+class _HoistedKV(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, shared, names, *tensors):
+        """tensors = the memories (one per name), then per memory and layer (in_proj_weight, in_proj_bias)."""
+        ctx.set_materialize_grads(False)
+        nl, E = shared.n_layers, shared.E
+        mems = tensors[:len(names)]
+        params = tensors[len(names):]
+        dev = mems[0].device
+        main = torch.cuda.current_stream(dev)
+        side = None
+        if _hoist_side[0]:
+            from . import graph_audit
+            side = _hoist_streams.get(dev)
+            if side is None:
+                side = _hoist_streams[dev] = graph_audit.own_stream(dev, role="decoder.memory")
+            side.wait_stream(main)
+        groups = []
+        outs = []
+        for j, (name, mem) in enumerate(zip(names, mems)):
+            B, Lk, _ = mem.shape
+            Mk = B * Lk
+            buf = torch.empty((nl, 2, B, Lk, E), device=dev)
+            outs.append(buf)
+            probs = []
+            for i in range(nl):
+                w, b = params[2 * (j * nl + i)], params[2 * (j * nl + i) + 1]
+                probs.append(_fwd(mem, w[E:2 * E], buf[i, 0], Mk, E, E, bias=b[E:2 * E]))
+                probs.append(_fwd(mem, w[2 * E:], buf[i, 1], Mk, E, E, bias=b[2 * E:]))
+                shared.kv[(i, name)] = (buf[i, 0], buf[i, 1])
+            shared.mem[name] = mem
+            groups.append((Mk, probs))
+        # the launches: equal-sized problems together (one tile rule per launch), the small memories first (the first
+        # cross-attention of layer 0 reads the text projections)
+        groups.sort(key=lambda g: g[0])
+        queue, launches = [], []
+        for Mk, probs in groups:
+            if Mk >= 4096:                      # a launch of its own kind
+                if queue:
+                    launches += [queue[k:k + _HOIST_GROUP[0]] for k in range(0, len(queue), _HOIST_GROUP[0])]
+                    queue = []
+                launches += [probs[k:k + _HOIST_GROUP[0]] for k in range(0, len(probs), _HOIST_GROUP[0])]
+            else:
+                queue += probs
+        if queue:
+            launches += [queue[k:k + _HOIST_GROUP[0]] for k in range(0, len(queue), _HOIST_GROUP[0])]
+        handle = (side if side is not None else main).cuda_stream
+        for probs in launches:
+            _launch(probs, dev, handle)
+        if mems[0].requires_grad or any(p.requires_grad for p in params):
+            # the stacked K | V weights of a memory, for the one-product input gradient of the backward pass
+            with torch.cuda.stream(side) if side is not None else _null():
+                for j, name in enumerate(names):
+                    shared.wcat[name] = torch.cat([params[2 * (j * nl + i)][E:] for i in range(nl)])
+        shared.side, shared.joined = side, side is None
+        ctx.shared, ctx.names = shared, names
+        ctx.save_for_backward(*tensors)
+        return torch.empty(1, device=dev)       # the autograd edge between this node and the blocks (no data)
+
+    @staticmethod
+    @fold_scope
+    def backward(ctx, _d_token):
+        shared, names = ctx.shared, ctx.names
+        tensors = ctx.saved_tensors
+        nl, E = shared.n_layers, shared.E
+        mems, params = tensors[:len(names)], tensors[len(names):]
+        dev = mems[0].device
+        ld = 2 * E * nl
+        d_mems, first, rest = [], [], []
+        grads = []
+        for j, (name, mem) in enumerate(zip(names, mems)):
+            B, Lk, _ = mem.shape
+            Mk = B * Lk
+            G = shared.G.get(name)
+            if G is None:                                   # no block of this memory had a gradient
+                d_mems.append(None)
+                grads += [None] * (2 * nl)
+                continue
+            for i in range(nl):
+                if (i, name) in shared.dead:
+                    G[:, :, 2 * E * i:2 * E * (i + 1)].zero_()
+            G2 = G.view(Mk, ld)
+            d_mem = torch.empty((B, Lk, E), device=dev)
+            d_mems.append(d_mem)
+            first.append(_problem(G2, shared.wcat[name], d_mem, Mk, E, ld, (ld, 1), (1, E), E))
+            for i in range(nl):
+                dw, db = shared.weight_grads(i, name, dev)
+                rest.append(_xwgrad(G2[:, 2 * E * i:2 * E * (i + 1)], ld, mem, dw[E:], db[E:], Mk, 2 * E, E))
+                grads += [dw, db]
+        # the memory-side input gradients first (the encoder's backward waits for them), the weight gradients after them
+        probs = first + rest
+        for k in range(0, len(probs), _HOIST_GROUP[0]):
+            _gemm(probs[k:k + _HOIST_GROUP[0]], mems[0])
+        shared.release()
+        return (None, None) + tuple(d_mems) + tuple(grads)
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def decoder_memory(layers, memories):
+    """``layers``: the BiDecoderLayers; ``memories``: [(name, attention-module attribute, tensor (B, Lk, E) | None)].
+    -> DecoderMemory (its token is the autograd edge) or None when the hoist does not apply."""
+    mems = [(n, a, t) for n, a, t in memories if t is not None]
+    if not _hoist[0] or not mems or not mems[0][2].is_cuda:
+        return None
+    E = mems[0][2].shape[-1]
+    shared = DecoderMemory(len(layers), E)
+    tensors = [t.contiguous() for _, _, t in mems]
+    _check(*tensors)
+    params = []
+    for _, attr, _ in mems:
+        for layer in layers:
+            attn = getattr(layer, attr)
+            params += [attn.in_proj_weight, attn.in_proj_bias]
+    shared.token = _HoistedKV.apply(shared, tuple(n for n, _, _ in mems), *tensors, *params)
+    return shared
+
+
+class _XhoistBlock(torch.autograd.Function):
+    """LayerNorm(x + Dropout(MHA(x + pos, K, V))) with K, V = a layer's hoisted projections of a decoder memory."""
+
+    @staticmethod
+    def forward(ctx, x, pos, token, mask, w_in, b_in, w_o, b_o, gamma, beta, num_heads, eps, p_attn, p_out, site_attn,
+                site_out, xq_pre, next_pos, shared, layer, name):
+        B, Lq, E = x.shape
+        H, D = num_heads, E // num_heads
+        dev = x.device
+        scale = math.sqrt(1.0 / float(D))
+        Mq = B * Lq
+        xq = x if pos is None else xq_pre
+        if xq is None:
+            xq = x + pos
+        shared.join(x)
+        k, v = shared.kv[(layer, name)]
+        Lk = k.shape[1]
+        q = torch.empty((B, Lq, E), device=dev)
+        _gemm([_fwd(xq, w_in[:E], q, Mq, E, E, bias=b_in[:E], scale=scale)], x)
+        att = torch.empty((B, Lq, E), device=dev)
+        lse = torch.empty((B, H, Lq), device=dev)
+        with torch.cuda.device(dev):
+            err = _attn_fwd()(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                              _ptr(mask), att.data_ptr(), lse.data_ptr(), p_attn, site_attn,
+                              rng_counter(dev).data_ptr(), _stream(x))
+        _hiplib.check(err, "butd_attention_fwd")
+        _count_attention("attn_fwd", B, H, Lq, Lk, D)
+        proj = torch.empty((B, Lq, E), device=dev)
+        y = torch.empty((B, Lq, E), device=dev)
+        mean = torch.empty((Mq,), device=dev)
+        rstd = torch.empty((Mq,), device=dev)
+        y_pos = torch.empty((B, Lq, E), device=dev) if next_pos is not None else None
+        _gemm([_fwd(att, w_o, proj, Mq, E, E, bias=b_o)], x)
+        with torch.cuda.device(dev):
+            err = _lib.butd_add_dropout_layernorm_fwd_pos(
+                Mq, E, proj.data_ptr(), x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), eps,
+                y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), p_out, site_out,
+                rng_counter(dev).data_ptr(), _ptr(next_pos), _ptr(y_pos), _stream(x))
+        _hiplib.check(err, "butd_add_dropout_layernorm_fwd_pos")
+        ctx.save_for_backward(x, xq if pos is not None else None, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean, rstd)
+        ctx.cfg = (H, p_attn, p_out, site_attn, site_out, shared, layer, name)
+        if y_pos is None:
+            return y
+        ctx.mark_non_differentiable(y_pos)
+        ctx.set_materialize_grads(False)
+        return y, y_pos
+
+    @staticmethod
+    @fold_scope
+    def backward(ctx, dy, *_d_extras):
+        H, p_attn, p_out, site_attn, site_out, shared, layer, name = ctx.cfg
+        if dy is None:
+            shared.dead.add((layer, name))
+            return (None,) * 21
+        x, xq_saved, mask, w_in, w_o, gamma, q, k, v, att, lse, proj, mean, rstd = ctx.saved_tensors
+        has_pos = xq_saved is not None
+        xq = xq_saved if has_pos else x
+        B, Lq, E = x.shape
+        Lk = k.shape[1]
+        D = E // H
+        Mq = B * Lq
+        dev = x.device
+        dy = dy.contiguous()
+        slab = zeros(E * E + E + 2 * E, device=dev)
+        d_w_o = slab[:E * E].view(E, E)
+        d_b_o = slab[E * E:E * E + E]
+        d_gamma = slab[E * E + E:E * E + 2 * E]
+        d_beta = slab[E * E + 2 * E:]
+        R = torch.empty((B, Lq, E), device=dev)
+        d_proj = torch.empty((B, Lq, E), device=dev) if p_out > 0 else R
+        fold = _ln_bwd(Mq, E, dy, proj, x, gamma, mean, rstd, d_proj, R, d_gamma, d_beta, p_out, site_out, x)
+        d_att = torch.empty((B, Lq, E), device=dev)
+        _gemm([_dgrad(d_proj, w_o, d_att, Mq, E, E),
+               _wgrad(d_proj, att, d_w_o, d_b_o, Mq, E, E)] + fold, x)
+        # dK | dV of this layer go into the memory's gradient matrix, at this layer's columns
+        G = shared.grad_matrix(name)
+        ld = 2 * E * shared.n_layers
+        short = _short_key_bwd(Lq, Lk, B, H, D)
+        dq = torch.empty((B, Lq, E), device=dev)
+        base = G.data_ptr() + 4 * (2 * E * layer)
+        if short:           # (the accumulating kernel of other head dimensions: through a zero-filled staging matrix)
+            tmp = zeros((B, Lk, 2 * E), device=dev)
+            dk_ptr, dv_ptr, ld_dkv = tmp.data_ptr(), tmp.data_ptr() + 4 * E, 2 * E
+        else:
+            dk_ptr, dv_ptr, ld_dkv = base, base + 4 * E, ld
+        scale = math.sqrt(1.0 / float(D))
+        _attention_backward(B, H, Lq, Lk, D, q, k, v, mask, att, d_att, lse, dq.data_ptr(), dk_ptr, dv_ptr, E, ld_dkv,
+                            scale, p_attn, site_attn, short, x)
+        if short:
+            G[:, :, 2 * E * layer:2 * E * (layer + 1)].copy_(tmp)
+        d_w_in, d_b_in = shared.weight_grads(layer, name, dev)
+        d_pos = None
+        if has_pos:
+            d_pos = torch.empty((B, Lq, E), device=dev)
+            qprob = _problem(dq, w_in, d_pos, Mq, E, E, (E, 1), (1, E), E, c2=R)
+        else:
+            qprob = _problem(dq, w_in, R, Mq, E, E, (E, 1), (1, E), E, c_add=True)
+        _gemm([qprob, _xwgrad(dq, E, xq, d_w_in[:E], d_b_in[:E], Mq, E, E)], x)
+        return (R, d_pos, None, None, None, None, d_w_o, d_b_o, d_gamma, d_beta) + (None,) * 11
+
+
+def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, xq_pre=None, next_pos=None, ffn=None,
+          hoisted=None):
     """LayerNorm(x + Dropout(MHA(x + pos, k, v))), (k, v) = (x + pos, x) or (memory, memory).
     ``next_pos``: also return ``y + next_pos`` (written by the kernel that produced y; no gradient flows through it) for
     the next block, which takes it as ``xq_pre`` in place of computing ``x + pos`` itself.
@@ -905,10 +1204,17 @@ def block(attn, dropout, norm, x, pos=None, memory=None, key_padding_mask=None, 
     extras_asked = next_pos is not None or ffn is not None
     blk_pos = None if ffn is not None else next_pos
     ffn_sites = (_next_site(), _next_site()) if ffn is not None else None     # (numbered before the block's own, as ever)
-    out = _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
-                          attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
-                          norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
-                          _next_site(), _next_site(), xq_pre, blk_pos)
+    if hoisted is not None:         # (DecoderMemory, layer index, memory name): K / V of ``memory`` are already projected
+        shared, layer, name = hoisted
+        out = _XhoistBlock.apply(x, pos, shared.token, _as_mask(key_padding_mask),
+                                 attn.in_proj_weight.detach(), attn.in_proj_bias.detach(), attn.out_proj.weight,
+                                 attn.out_proj.bias, norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn,
+                                 p_out, _next_site(), _next_site(), xq_pre, blk_pos, shared, layer, name)
+    else:
+        out = _XpmBlock.apply(x, pos, memory, _as_mask(key_padding_mask),
+                              attn.in_proj_weight, attn.in_proj_bias, attn.out_proj.weight, attn.out_proj.bias,
+                              norm.weight, norm.bias, attn.num_heads, float(norm.eps), p_attn, p_out,
+                              _next_site(), _next_site(), xq_pre, blk_pos)
     y, y_pos = out if isinstance(out, tuple) else (out, None)
     if ffn is not None:
         seq, norm2 = ffn

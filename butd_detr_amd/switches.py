@@ -24,6 +24,8 @@ KNOWN = {
     "sa_mid_wide":      "SA2-4: layer 2 backward in one pass, only the gated gradient written (fused_sa)",
     "sa_no_z1":         "SA1: forward without Z1 (fused_sa)",
     "sa_fuse_stats":    "SA2-4: layer 1's gate + BatchNorm sums in the epilogue of the product that writes dH1 (fused_sa)",
+    "decoder_kv_hoist": "decoder: the memories' key / value projections of all layers before the decoder, their input / weight gradients after it (fused_attention.DecoderMemory)",
+    "decoder_kv_side":  "... with the forward projections on a forked stream next to the query generation (fused_attention)",
     "fan_out":          "gradient fan-in of multiply-used tensors as one launch (fan_out)",
     "encoder_fork":     "language side of an encoder layer on a forked stream (encoder_decoder_layers)",
     "text_overlap":     "frozen language model on a forked stream when it is not prefetched (bdetr)",

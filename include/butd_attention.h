@@ -135,7 +135,7 @@ typedef struct {
   long fold_stride, fold_len, fold_len2;
 } butd_gemm_problem;
 
-/* Launches up to 8 independent problems in ONE 1-D grid (every problem owns a range of workgroups).
+/* Launches up to 32 independent problems in ONE 1-D grid (every problem owns a range of workgroups).
  * rng_counter: device pointer to a uint64 step counter (may be NULL when no problem uses dropout). */
 int butd_gemm_grouped(const butd_gemm_problem *problems, int count, const uint64_t *rng_counter,
                       butd_stream_t stream);

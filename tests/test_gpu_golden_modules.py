@@ -127,6 +127,48 @@ def test_decoder_layer_golden(backend, mode):
 
 
 @pytest.mark.parametrize("mode", ["eval", "train"])
+@pytest.mark.parametrize("side", [False, True])
+def test_decoder_layer_golden_hoisted_memory(mode, side):
+    """The same reference vectors through the round-6 path of the full model: the layer's three memories projected by the
+    hoisted node (fused_attention.decoder_memory, on the forked stream or not), its cross-attention blocks reading them,
+    the memory-side input gradients and the K / V weight gradients from the hoisted node's backward."""
+    from butd_detr_amd import attention_blocks, fused_attention as fa
+    from butd_detr_amd.encoder_decoder_layers import BiDecoderLayer
+    prev_backend = attention_blocks.get_backend()
+    attention_blocks.set_backend("hip")
+    prev = fa.set_decoder_kv_hoist(True, side=side)
+    try:
+        g = load(f"decoder_small_{mode}.npz")
+        layer = BiDecoderLayer(288, n_heads=8, dim_feedforward=256, dropout=0.1 if mode == "eval" else 0.0,
+                               activation="relu", self_position_embedding="loc_learned", butd=True)
+        weights.fill_(layer, seed=12).cuda()
+        layer.train(mode == "train")
+        inp = cuda(decoder_inputs())
+        for k in ("query", "vis", "text", "boxes"):
+            inp[k].requires_grad_(True)
+        shared = fa.decoder_memory([layer], [("text", "cross_l", inp["text"]), ("boxes", "cross_d", inp["boxes"]),
+                                             ("seeds", "cross_v", inp["vis"])])
+        assert shared is not None
+        out = layer(inp["query"], inp["vis"].detach(), inp["text"].detach(), inp["query_pos"], None, inp["text_mask"],
+                    detected_feats=inp["boxes"].detach(), detected_mask=inp["box_mask"], memory_kv=(shared, 0))
+        shared.token = None
+        close(out, g["out"], OUT_TOL)
+        (out * probe(out.shape, 3).cuda()).sum().backward()
+        close(inp["query"].grad, g["g_query"], GRAD_TOL)
+        close(inp["vis"].grad, g["g_vis"], GRAD_TOL)
+        close(inp["text"].grad, g["g_text"], GRAD_TOL)
+        close(inp["boxes"].grad, g["g_boxes"], GRAD_TOL)
+        p = dict(layer.named_parameters())
+        close(p["cross_v.in_proj_weight"].grad, g["g_cross_v_in_proj_weight"], GRAD_TOL)
+        close(p["self_posembed.position_embedding_head.0.weight"].grad, g["g_self_posembed_0_weight"], GRAD_TOL)
+        close(p["ffn.3.weight"].grad, g["g_ffn_3_weight"], GRAD_TOL)
+        assert all(q.grad is not None for q in layer.parameters())
+    finally:
+        fa.set_decoder_kv_hoist(*prev)
+        attention_blocks.set_backend(prev_backend)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
 def test_backbone_golden(mode):
     from butd_detr_amd.backbone_module import Pointnet2Backbone
     g = load(f"backbone_4096_{mode}.npz")
