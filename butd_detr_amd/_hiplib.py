@@ -117,6 +117,12 @@ SA_SYMBOLS = {
     "butd_sa_mid_first_bwd": (_c_int, [_c_long, _c_int, _c_int] + [_P] * 23 + [_P]),
     "butd_sa_last_bwd_scratch": (_c_int, [_c_long, _c_int, _c_int, _P, _P]),
     "butd_sa_last_bwd": (_c_int, [_c_int] * 5 + [_P] * 21 + [_P]),
+    "butd_sa_first_linear_supported": (_c_int, [_c_int]),
+    "butd_sa_first_linear_fwd": (_c_int, [_c_int] * 5 + [_P, _P, _P, _c_float, _c_int, _P, _P, _c_long, _P, _P, _P, _c_int,
+                                                        _c_long, _P]),
+    "butd_sa_first_linear_bwd_scratch": (_c_int, [_c_int, _c_int, _c_int, _P]),
+    "butd_sa_first_linear_bwd": (_c_int, [_c_int] * 5 + [_P, _P, _P, _P, _c_float, _c_int] + [_P] * 9 + [_c_int, _P, _P,
+                                                                                                   _c_long, _P, _P]),
     "butd_sa_dz_mid": (_c_int, [_c_long, _c_int] + [_P] * 9 + [_c_int, _P]),
     "butd_sa_scatter_rows": (_c_int, [_c_int] * 5 + [_P, _c_int, _P, _P] + [_P]),
     "butd_sa_inverse_index": (_c_int, [_c_int] * 4 + [_P] * 4 + [_P]),

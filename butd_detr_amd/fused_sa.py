@@ -11,7 +11,7 @@ import os
 import torch
 
 from . import _hiplib, switches
-from .fused_attention import _dgrad, _flush_folds, _fwd, _gemm, _pending_folds, _wgrad, fold_scope, zeros
+from .fused_attention import _dgrad, _flush_folds, _fwd, _gemm, _pending_folds, _problem, _wgrad, fold_scope, zeros
 
 _lib = _hiplib.load()
 
@@ -44,6 +44,10 @@ _MID_WIDE = [switches.flag("sa_mid_wide", True)]
 # (4 x 60 steps), and the SA1 gradients move 4-5x CLOSER to a float64 run (closer than stock torch's):
 # profiles/r04_sa_last_layer.txt.  (A first version that recomputed z1 with scalar code from the LDS X tile was neutral.)
 _NO_Z1 = [switches.flag("sa_no_z1", True)]
+# SA2-4 (levels with input features): the first layer by linearity of the grouping (csrc/sa_first_linear.hip, round 6): the
+# C-wide product over the level's N points instead of its P grouped rows, Z1 as a gather + three multiply-adds; backward: one
+# pass over (g1, Z1) along the inverted neighbour lists, products over N rows.  The grouped input X is never formed.
+_FIRST_LINEAR = [switches.flag("sa_first_linear", True)]
 _FUSED_EVAL = [True]     # inference: a whole level as one kernel (sa_fused_eval)
 _scratch_sizes = {}
 _sched = {}
@@ -152,13 +156,20 @@ class _SAMlpPool(torch.autograd.Function):
         # rows of 3+C floats (6, 131, 259) are not 16-byte aligned: pad the grouped input and the first
         # weight matrix to a multiple of 4 columns (zeros) so the first product takes the float4 path
         Kp = (Cin + 3) // 4 * 4
-        if Kp != Cin:
+        # the first layer by linearity (levels with features whose rows are float4-aligned: SA2-4): no grouped input
+        lin1 = bool(_FIRST_LINEAR[0] and feats_pm is not None and C >= 16 and C % 4 == 0 and feat_ptr_offset == 0
+                    and feat_stride == C and _lib.butd_sa_first_linear_supported(int(C1)))
+        if Kp != Cin and not lin1:
             ws[0] = torch.nn.functional.pad(ws[0], (0, Kp - Cin))
-
-        X = torch.empty((P, Kp), device=dev)
         fptr = None if feats_pm is None else feats_pm.data_ptr() + 4 * feat_ptr_offset
-        _call("butd_sa_group", xyz, B, N, np_, ns, C, xyz.data_ptr(), new_xyz.data_ptr(), fptr,
-              feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr(), Kp)
+        if lin1:
+            X = xyz.new_empty((0, Kp))
+            w1_full = w1.reshape(C1, Cin)
+            Wf = w1_full[:, 3:].contiguous()                    # (C1, C)
+        else:
+            X = torch.empty((P, Kp), device=dev)
+            _call("butd_sa_group", xyz, B, N, np_, ns, C, xyz.data_ptr(), new_xyz.data_ptr(), fptr,
+                  feat_stride, idx.data_ptr(), float(radius), int(bool(normalize)), X.data_ptr(), Kp)
 
         Cm = max(C1, C2, C3)
         # 16 private copies of the epilogue's column sums (folded by butd_sa_bn_finalize): a 65 536-row product
@@ -197,6 +208,23 @@ class _SAMlpPool(torch.autograd.Function):
                       g.data_ptr(), b.data_ptr(), float(eps), float(momentum), int(training), rm.data_ptr(), rv.data_ptr(),
                       _p(nbt), aff[li, 0].data_ptr(), aff[li, 1].data_ptr(), aff[li, 2].data_ptr(), aff[li, 3].data_ptr())
                 prev_aff = (aff[li, 2], aff[li, 3])
+                Zs.append(Z)
+                inp = Z
+                continue
+            if li == 0 and lin1:
+                Y = torch.empty((B * N, C1), device=dev)
+                _gemm([_problem(feats_pm, Wf, Y, B * N, C1, C, (feat_stride, 1), (C, 1), C1)], xyz)
+                Z = torch.empty((P, C1), device=dev)
+                _call("butd_sa_first_linear_fwd", xyz, B, N, np_, ns, C1, xyz.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(),
+                      float(radius), int(bool(normalize)), Y.data_ptr(), w1_full.data_ptr(), Cin, Z.data_ptr(),
+                      stats[0, 0, 0].data_ptr() if training else None, stats[0, 0, 1].data_ptr() if training else None,
+                      SLOTS, 2 * Cm)
+                g, b, rm, rv, nbt, eps = layers[0]
+                _call("butd_sa_bn_finalize", xyz, Cl, P, stats[0, 0, 0].data_ptr(), stats[0, 0, 1].data_ptr(),
+                      SLOTS if training else 1, 2 * Cm, g.data_ptr(), b.data_ptr(), float(eps), float(momentum), int(training),
+                      rm.data_ptr(), rv.data_ptr(), _p(nbt), aff[0, 0].data_ptr(), aff[0, 1].data_ptr(),
+                      aff[0, 2].data_ptr(), aff[0, 3].data_ptr())
+                prev_aff = (aff[0, 2], aff[0, 3])
                 Zs.append(Z)
                 inp = Z
                 continue
@@ -251,6 +279,8 @@ class _SAMlpPool(torch.autograd.Function):
                    w1.shape, w2.shape, w3.shape, Cin, lin)
         ctx.no_z1 = no_z1
         ctx.inv = (inv_start, inv_list) if inv_start is not None else None
+        # (the linear first layer's backward re-reads the coordinates and the features instead of X)
+        ctx.lin1 = (xyz, new_xyz, feats_pm, Wf, float(radius), bool(normalize), P) if lin1 else None
         return out_cm, out_pm
 
     @staticmethod
@@ -260,6 +290,8 @@ class _SAMlpPool(torch.autograd.Function):
         B, N, np_, ns, C, training, need_dfeat, s1, s2, s3, Cin, lin = ctx.cfg
         dev = X.device
         P, Kp = X.shape                                 # Kp = Cin rounded up to a multiple of 4
+        if ctx.lin1 is not None:
+            P = ctx.lin1[6]
         C1, C2, C3 = w1.shape[0], w2.shape[0], w3.shape[0]
         # gradient of the pooled output, position-major (B, np, C) like everything else here
         if d_cm is None:
@@ -361,6 +393,31 @@ class _SAMlpPool(torch.autograd.Function):
                 _call("butd_sa_mask_stats", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), scale(0).data_ptr(),
                       shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
                       S[0, 1].data_ptr())
+            if ctx.lin1 is not None:
+                # by linearity: one pass over (g1, Z1) along the inverted lists -> T (B N x C1) and dWx; the products over
+                # the level's N points finish the layer (no dZ1, no grouped input gradient)
+                xyz, new_xyz, feats_pm, Wf, radius, normalize, _ = ctx.lin1
+                start, lst = ctx.inv if ctx.inv is not None else inverse_index(idx, N)
+                import ctypes
+                nws = ctypes.c_long(0)
+                _hiplib.check(_lib.butd_sa_first_linear_bwd_scratch(B, N, C1, ctypes.byref(nws)), "butd_sa_first_linear_bwd_scratch")
+                ws_l = torch.empty(nws.value, device=dev)
+                T = torch.empty((B * N, C1), device=dev)
+                dWx = torch.empty((C1, 3), device=dev)
+                _call("butd_sa_first_linear_bwd", X, B, N, np_, ns, C1, xyz.data_ptr(), new_xyz.data_ptr(), start.data_ptr(),
+                      lst.data_ptr(), radius, int(normalize), dH1.data_ptr(), Z1.data_ptr(), g1.data_ptr(),
+                      scale(0).data_ptr(), shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(),
+                      S[0, 1].data_ptr(), tr, T.data_ptr(), dWx.data_ptr(), 3, ws_l.data_ptr())
+                dWf = zeros((C1, C), device=dev)
+                probs = [_wgrad(T, feats_pm, dWf, None, B * N, C1, C)]
+                if need_dfeat:
+                    d_feats = torch.empty((B, N, C), device=dev)
+                    probs.append(_dgrad(T, Wf, d_feats, B * N, C1, C))
+                _gemm(probs, X)
+                if _pending_folds:
+                    _flush_folds(S)
+                dW1 = torch.cat((dWx, dWf), 1)
+                return _SAMlpPool._finish(ctx, S, dW1, dW2, dW3, d_feats, (C1, C2, C3), (s1, s2, s3), Cin)
             _call("butd_sa_dz_mid", X, P, C1, dH1.data_ptr(), Z1.data_ptr(), g1.data_ptr(), scale(0).data_ptr(),
                   shift(0).data_ptr(), mean(0).data_ptr(), rstd(0).data_ptr(), S[0, 0].data_ptr(), S[0, 1].data_ptr(), tr)
             dZ1 = dH1

@@ -22,6 +22,7 @@ KNOWN = {
     "sa_first_bwd":     "SA1: first layer backward without dZ1 (fused_sa)",
     "sa_mid_bwd":       "SA1: layer 2 + layer 1 backward in one pass (fused_sa)",
     "sa_mid_wide":      "SA2-4: layer 2 backward in one pass, only the gated gradient written (fused_sa)",
+    "sa_first_linear":  "SA2-4: the first layer by linearity of the grouping -- product over the level's N points, Z1 gathered, backward along the inverted lists; no grouped input (fused_sa)",
     "sa_no_z1":         "SA1: forward without Z1 (fused_sa)",
     "sa_fuse_stats":    "SA2-4: layer 1's gate + BatchNorm sums in the epilogue of the product that writes dH1 (fused_sa)",
     "decoder_kv_hoist": "decoder: the memories' key / value projections of all layers before the decoder, their input / weight gradients after it (fused_attention.DecoderMemory)",

@@ -162,6 +162,31 @@ int butd_sa_first_two_fwd(long P, int C, int Kp, const float *X, const float *W1
                           double *sum1, double *sumsq1, const float *scale1, const float *shift1, float *Z2, double *sum2,
                           double *sumsq2, int phase, butd_stream_t stream);
 
+/* The FIRST layer of a level WITH input features (SA2-SA4) without the grouped input X (round 6; csrc/sa_first_linear.hip).
+ * A grouped row copies a point's features (pointnet2_utils.py:317-376), so with W1 = [Wx | Wf] (3 | C columns)
+ *   Z1[p, :] = Y[b, idx[p], :] + dxyz[p] Wx^T,   Y = feats Wf^T  (B*N x C1: the caller's product over the level's N points),
+ *   dxyz[p]  = (xyz[b, idx[p]] - new_xyz[b, j]) (/ radius if normalize)
+ * butd_sa_first_linear_fwd writes Z1 (P x C1) and, when sum / sumsq != NULL, adds its BatchNorm column sums (double atomics
+ * into `slots` private copies `slot_stride` doubles apart, caller zero-fills, as butd_gemm_problem.col_slots).  W1 (C1 rows of
+ * ldw floats): only its first three columns are read.  C1 in {64, 128, 256}.
+ * butd_sa_first_linear_bwd: with dZ1 = gamma rstd (g - S1/P - zhat S2/P) of the GATED gradient G1 (training; scale * g
+ * otherwise: the arithmetic of butd_sa_dz_mid), over the inverted neighbour lists (butd_sa_inverse_index):
+ *   T[b, n, :] = sum of dZ1 over the grouped rows that copy point n   (B*N x C1, written)
+ *   dWx[c, i]  = sum_p dZ1[p, c] dxyz[p, i]                             (C1 x 3, row stride ld_dwx, written; partials in ws,
+ *                                                                        summed in double in a fixed order)
+ * The caller's products over B*N rows finish the layer: d_feats = T Wf, dWf = T^T feats.  Neither dZ1 nor the grouped
+ * input gradient (P x (3 + C)) exists in memory.  ws: butd_sa_first_linear_bwd_scratch floats. */
+int butd_sa_first_linear_supported(int C1);
+int butd_sa_first_linear_fwd(int B, int N, int np, int ns, int C1, const float *xyz, const float *new_xyz, const int *idx,
+                             float radius, int normalize, const float *Y, const float *W1, long ldw, float *Z1, double *sum,
+                             double *sumsq, int slots, long slot_stride, butd_stream_t stream);
+int butd_sa_first_linear_bwd_scratch(int B, int N, int C1, long *ws_floats);
+int butd_sa_first_linear_bwd(int B, int N, int np, int ns, int C1, const float *xyz, const float *new_xyz,
+                             const int *start, const int *list, float radius, int normalize, const float *G1,
+                             const float *Z1, const float *gamma1, const float *scale1, const float *shift1,
+                             const float *mean1, const float *rstd1, const double *S1, const double *S2, int training,
+                             float *T, float *dWx, long ld_dwx, float *ws, butd_stream_t stream);
+
 /* Hidden layers, part 1 (read-only pass over dH, Z (P x C)): with g = dH * [scale*z+shift > 0],
  * S1[c] += sum_p g, S2[c] += sum_p g*zhat (double, caller zero-fills). */
 int butd_sa_mask_stats(long P, int C, const float *dH, const float *Z, const float *scale,

@@ -251,7 +251,14 @@ def test_bdetr_train_six_layers_golden(backend):
     # BatchNorm sums of SA1's first layer, deterministic partial sums in the set-abstraction backward): the FUSED path is at
     # 7.8e-3 max / 1.6e-3 mean over the 14 gradient tensors, identical on every run and box seen; stock torch ops on this
     # GPU at 1.9e-2 / 1.6e-3.  Bounds: fused 1e-2 max, 2.5e-3 mean; stock ops 2.5e-2 max, 5e-3 mean.
-    gmax, gmean = (1e-2, 2.5e-3) if backend == "hip" else (2.5e-2, 5e-3)
+    # Round 6 (the first layer of SA2-4 by linearity: another summation order of the same fp32 terms; per-tensor table with the
+    # switch on / off and stock torch in profiles/r06_train6_gradient_errors.txt): the fused path lands at 1.36e-2 max on
+    # decoder.5.ffn.3.weight and 3.4e-3 mean on decoder.5.cross_l.out_proj.bias (4.9e-3 / 1.3e-3 with the grouped-input
+    # path); against a float64 run of the same modules both are inside the same flip budget
+    # (tests/test_gpu_gradient_truth.py) -- which fp32 rounding the heads' 164-sample BatchNorm amplifies is not a property
+    # of a kernel (stock torch: 1.9e-2 on points_obj_cls.conv2.weight).  Bounds: fused 2e-2 max / 5e-3 mean, stock ops
+    # 2.5e-2 / 5e-3.
+    gmax, gmean = (2e-2, 5e-3) if backend == "hip" else (2.5e-2, 5e-3)
 
     def grad_close(t, ref):
         a = t.detach().float().cpu().numpy()

@@ -23,24 +23,27 @@ pytestmark = pytest.mark.gpu
 
 
 def _fusions(on):
-    """The epilogue / ride-along fusions of rounds 4 and 5 on (the product) or off (round 3's launches: atomic LayerNorm
-    backward, separate mask / statistics passes, dense set-abstraction backward, pairwise gradient sums)."""
-    from butd_detr_amd import fan_out, fused_attention as fa, fused_mlp, fused_sa
-    prev = (fa.set_ln_fold(on), fused_mlp.set_fuse_stats(on), fan_out.set_enabled(on),
-            [f[0] for f in (fused_sa._LAST_LIN, fused_sa._LAST_FWD, fused_sa._FIRST_LIN, fused_sa._MID_FIRST, fused_sa._NO_Z1,
-                            fused_sa._FUSE_STATS, fused_sa._GATHER)])
-    for f in (fused_sa._LAST_LIN, fused_sa._LAST_FWD, fused_sa._FIRST_LIN, fused_sa._MID_FIRST, fused_sa._NO_Z1,
-              fused_sa._FUSE_STATS, fused_sa._GATHER):
+    """The epilogue / ride-along fusions of rounds 4-6 on (the product) or off (round 3's launches: atomic LayerNorm
+    backward, separate mask / statistics passes, dense set-abstraction backward with the grouped input, pairwise gradient
+    sums, two-kernel attention backward, term-by-term criterion tail, per-block decoder key / value projections)."""
+    from butd_detr_amd import fan_out, fused_attention as fa, fused_mlp, fused_sa, losses
+    sa_flags = (fused_sa._LAST_LIN, fused_sa._LAST_FWD, fused_sa._FIRST_LIN, fused_sa._MID_FIRST, fused_sa._NO_Z1,
+                fused_sa._FUSE_STATS, fused_sa._GATHER, fused_sa._MID_WIDE, fused_sa._FIRST_LINEAR, losses._TAIL)
+    prev = (fa.set_ln_fold(on), fused_mlp.set_fuse_stats(on), fan_out.set_enabled(on), [f[0] for f in sa_flags],
+            fa.set_long_keys(on), fa.set_decoder_kv_hoist(on))
+    for f in sa_flags:
         f[0] = on
     return prev
 
 
 def _restore_fusions(prev):
-    from butd_detr_amd import fan_out, fused_attention as fa, fused_mlp, fused_sa
+    from butd_detr_amd import fan_out, fused_attention as fa, fused_mlp, fused_sa, losses
     fa.set_ln_fold(prev[0]); fused_mlp.set_fuse_stats(prev[1]); fan_out.set_enabled(prev[2])
     for f, v in zip((fused_sa._LAST_LIN, fused_sa._LAST_FWD, fused_sa._FIRST_LIN, fused_sa._MID_FIRST, fused_sa._NO_Z1,
-                     fused_sa._FUSE_STATS, fused_sa._GATHER), prev[3]):
+                     fused_sa._FUSE_STATS, fused_sa._GATHER, fused_sa._MID_WIDE, fused_sa._FIRST_LINEAR, losses._TAIL), prev[3]):
         f[0] = v
+    fa.set_long_keys(prev[4])
+    fa.set_decoder_kv_hoist(*prev[5])
 
 
 @pytest.mark.parametrize("fusions", [True, False], ids=["product path", "round-3 launches (every later fusion off)"])

@@ -269,3 +269,84 @@ def test_wide_middle_layer_in_one_pass(cfg):
     for n in outs["pair"][2]:
         assert _err(outs["wide"][2][n], outs["pair"][2][n]) < 2e-5, (n, _err(outs["wide"][2][n], outs["pair"][2][n]))
     assert torch.equal(outs["wide"][2]["mlp_module.layer1.conv.weight"], outs["wide again"][2]["mlp_module.layer1.conv.weight"])
+
+
+def _with_first_linear(flag, fn):
+    from butd_detr_amd import fused_sa
+    prev = fused_sa._FIRST_LINEAR[0]
+    fused_sa._FIRST_LINEAR[0] = flag
+    try:
+        return fn()
+    finally:
+        fused_sa._FIRST_LINEAR[0] = prev
+
+
+@pytest.mark.parametrize("cfg", CFGS[1:4] + [dict(B=8, N=2048, C=128, npoint=1024, radius=0.4, nsample=32, mlp=[128, 128, 128, 256]),
+                                             dict(B=2, N=900, C=64, npoint=300, radius=0.7, nsample=16, mlp=[64, 64, 128, 128])])
+@pytest.mark.parametrize("input_grad", [True, False])
+def test_first_layer_by_linearity_equals_grouped_input_path(cfg, input_grad):
+    """Round 6 (csrc/sa_first_linear.hip): levels with input features run their first layer over the N points of the level
+    (Y = feats Wf^T, Z1 = gather + the three coordinate terms) and its backward along the inverted neighbour lists (T, dWx;
+    d_feats = T Wf, dWf = T^T feats) -- vs the path that forms the grouped input X (butd_sa_group + the P-row products +
+    butd_sa_dz_mid + butd_sa_gather_rows).  Same arithmetic up to the order in which a Z1 element's 3 + C terms are summed."""
+    m = _module(cfg, 51)
+    torch.manual_seed(53)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    outs = {}
+    for key, flag in (("grouped", False), ("linear", True), ("linear again", True)):
+        state = {k: v.clone() for k, v in m.state_dict().items()}
+        outs[key] = _with_first_linear(flag, lambda: _run(m, xyz, feats, probe, linear=True, input_grad=input_grad))
+        if key == "grouped":
+            buffers = {k: v.clone() for k, v in m.state_dict().items() if "running" in k}
+        else:
+            for k, v in buffers.items():          # the running statistics of the three layers after one training step
+                assert _err(m.state_dict()[k], v) < 1e-5, k
+        m.load_state_dict(state)
+    # a ReLU gate or an arg-max that falls the other way after the reassociation reroutes single entries
+    bad, mean, size, worst = _stats(outs["linear"][0], outs["grouped"][0])
+    assert mean < 1e-6 and bad <= max(1, 1e-4 * size), (bad, mean, size, worst)
+    if input_grad:
+        bad, mean, size, worst = _stats(outs["linear"][1], outs["grouped"][1])
+        assert mean < 2e-6 and bad <= max(2, 1e-3 * size), (bad, mean, size, worst)
+    for n in outs["grouped"][2]:
+        bad, mean, size, worst = _stats(outs["linear"][2][n], outs["grouped"][2][n])
+        assert mean < 1e-4 and bad <= max(2, 2e-3 * size) and worst < 1e-2, (n, bad, mean, size, worst)   # (vs float64: the test below)
+    # T and dWx are gathered / summed in a fixed order; the products behind them use the step's float atomics
+    assert torch.equal(outs["linear"][0], outs["linear again"][0])
+
+
+@pytest.mark.parametrize("cfg", CFGS[1:3])
+def test_first_layer_by_linearity_vs_float64_module(cfg):
+    """The same level against the stock module in float64 (same neighbour lists): the linear first layer is no further
+    from the truth than the grouped-input path, both inside north_star's 1e-3."""
+    from butd_detr_amd import pointnet2_utils
+    m = _module(cfg, 57)
+    torch.manual_seed(59)
+    xyz = torch.rand(cfg["B"], cfg["N"], 3, device="cuda") * 2 - 1
+    feats = torch.randn(cfg["B"], cfg["C"], cfg["N"], device="cuda")
+    probe = torch.randn(cfg["B"], cfg["mlp"][-1], cfg["npoint"], device="cuda")
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    y_g, gf_g, gp_g = _with_first_linear(False, lambda: _run(m, xyz, feats, probe, linear=True))
+    m.load_state_dict(state)
+    y_l, gf_l, gp_l = _with_first_linear(True, lambda: _run(m, xyz, feats, probe, linear=True))
+    m.load_state_dict(state)
+    inds = pointnet2_utils.furthest_point_sample(xyz, cfg["npoint"])
+    new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), inds).transpose(1, 2).contiguous()
+    idx = pointnet2_utils.ball_query(cfg["radius"], cfg["nsample"], xyz, new_xyz).long().cpu()
+    m.last_features_pm = None
+    m64 = copy.deepcopy(m).double().cpu()
+    x64, f64 = xyz.double().cpu(), feats.double().cpu().requires_grad_(True)
+    bi = torch.arange(idx.shape[0])[:, None, None]
+    grouped_xyz = (x64[bi, idx] - new_xyz.double().cpu()[:, :, None, :]) / cfg["radius"]
+    g = torch.cat([grouped_xyz, f64.transpose(1, 2)[bi, idx]], -1).permute(0, 3, 1, 2)
+    y64 = m64.mlp_module(g).max(-1)[0]
+    (y64 * probe.double().cpu()).sum().backward()
+    assert _err(y_l, y64) < 1e-4
+    pairs = [("d_feats", gf_g, gf_l, f64.grad)]
+    pairs += [(n, gp_g[n], gp_l[n], p.grad) for n, p in m64.named_parameters() if "mlp_module" in n and p.grad is not None]
+    for n, grouped, lin, truth in pairs:
+        (_, m_g, _, _), (bad, m_l, size, worst) = _stats(grouped, truth), _stats(lin, truth)
+        assert bad <= max(2, 1e-3 * size) and worst < 2e-2 and m_l <= 1e-4, (n, bad, size, worst, m_l)
+        assert m_l <= 1.5 * m_g + 1e-6, (n, m_l, m_g)
