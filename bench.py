@@ -44,7 +44,8 @@ def parse():
                          "device; surrogate: dense stand-in without matching")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="plain eager launches + DDP instead of hipGraph replay")
-    ap.add_argument("--cpu-scenes", type=int, default=1)
+    ap.add_argument("--cpu-scenes", type=int, default=8,
+                    help="scenes per step of the CPU baseline (8 = the batch of the GPU line, BASELINE.md section 3)")
     ap.add_argument("--encoder-layers", type=int, default=3,
                     help="BiEncoder depth: 3 = the reference (models/bdetr.py:104); 6 = the extra row BASELINE "
                          "configs[2] words as '6-layer BiEncoder'")
@@ -492,7 +493,7 @@ def cpu_baseline(args, scenes):
             criterion.set_criterion.matcher.match_dense = lsap_oracle.scipy_match_dense(criterion.set_criterion.matcher)
         train_step(model, opt, inputs, targets, criterion=criterion)      # warm-up
         t0 = time.perf_counter()
-        reps = 3
+        reps = 3 if scenes <= 2 else 2          # (bounded sample: ~1.2 s per scene and step on 16 cores)
         for _ in range(reps):
             train_step(model, opt, inputs, targets, criterion=criterion)
         dt = (time.perf_counter() - t0) / reps
@@ -644,6 +645,22 @@ def in_situ_row(args, model, opt, criterion, batches, gemm, sa_lin):
         with open(os.environ["BUTD_STEP_MARKS_OUT"], "w") as f:
             f.write(step_regions.format_intervals(res) + "\n")
     return out
+
+
+def batch24_row(args, model, opt, criterion, device):
+    """The reference's own training batch (scripts/train_test_det.sh:6: --batch_size 24) as an EXTRA operating
+    point: the same step at 24 scenes per GPU -- how much of the headline's matrix-core fraction is the 2048-row
+    granularity of B = 8 (the decoder's products have 24 x 256 = 6144 rows here)."""
+    from butd_detr_amd.train_step import synthetic_batch
+    B = 24
+    batches = [synthetic_batch(B, device, seed=2211 + 37 * k, n_points=args.points, tokens=args.tokens,
+                               max_targets=args.max_targets) for k in range(2)]
+    ns = argparse.Namespace(**vars(args))
+    ns.steps = max(4, args.steps // 3)
+    dt, loss = _time_recaptured(ns, model, opt, criterion, batches, warm=3)
+    return {"value": round(B * ns.steps / dt, 3), "unit": "scenes/s", "ms_per_step": round(dt / ns.steps * 1e3, 3),
+            "scenes_per_step": B, "ms_per_scene": round(dt / ns.steps * 1e3 / B, 3), "steps": ns.steps,
+            "final_loss": round(float(loss), 4)}
 
 
 def _flush_c_stdio():
@@ -798,7 +815,7 @@ def main():
             sa_lin = sa_linear_roofline(args, out["roofline"]) if args.dtype == "f32" else None
             if sa_lin:
                 out["roofline_sa_linear"] = sa_lin
-            if world == 1 and not args.eager and args.dtype == "f32":
+            if world == 1 and not args.eager and args.dtype == "f32" and os.environ.get("BUTD_BENCH_NO_CHILD") != "1":
                 out["in_situ"] = in_situ_row(args, model, opt, criterion, batches, out["roofline"], sa_lin)
             if not args.no_extras:
                 out["roofline_ball_query"] = ball_query_roofline(inputs)
@@ -815,6 +832,7 @@ def main():
             out["text_cache_operating_point"] = text_cache_row(args, model, opt, criterion, batches)
             if args.encoder_layers != 6:
                 out["encoder6_operating_point"] = encoder6_row(args, device, criterion, batches)
+            out["batch24_operating_point"] = batch24_row(args, model, opt, criterion, device)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
         _flush_c_stdio()

@@ -207,7 +207,7 @@ class BeaUTyDETR(nn.Module):
             # graphs get their hidden hazards); the trainable projector runs on the main stream after the join
             main = torch.cuda.current_stream(pc.device)
             if self._side_stream is None:
-                self._side_stream = graph_audit.own_stream(pc.device, role="model.text")
+                self._side_stream = graph_audit.own_stream(pc.device, role="model.text", owner=self)
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):

@@ -39,6 +39,34 @@ TU_FLAGS = {
 }
 
 
+_PROBED = {}
+
+
+def _supported(flags):
+    """Hidden LLVM options (-mllvm ...) are probed once on an empty translation unit: a hipcc that lacks or renamed one
+    builds without it (with a warning) instead of failing the whole library -- the flag is worth ~1 % of a step."""
+    key = tuple(flags)
+    if key not in _PROBED:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void butd_probe() {}\n")
+            rc = subprocess.call([HIPCC, "--offload-arch=gfx950", "-c", src, "-o", os.path.join(d, "probe.o")] + list(flags),
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _PROBED[key] = rc == 0
+        if rc != 0:
+            print(f"butd_detr_amd.build: {' '.join(flags)} is not accepted by {HIPCC}: building without it", file=sys.stderr)
+    return _PROBED[key]
+
+
+def _tu_flags(name):
+    flags = TU_FLAGS.get(name, [])
+    if "-mllvm" in flags and not _supported(flags):
+        return []
+    return flags
+
+
 def _sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -64,7 +92,7 @@ def build(force=False, verbose=False):
     objs, relink = [], force or not os.path.exists(LIB_PATH)
     for name in _sources():
         src = os.path.join(CSRC, name)
-        flags = COMMON + TU_FLAGS.get(name, [])
+        flags = COMMON + _tu_flags(name)
         obj = os.path.join(OBJDIR, name.replace(".hip", ".o"))
         stamp_file = obj + ".stamp"
         stamp = _stamp(src, flags)

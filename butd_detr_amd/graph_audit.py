@@ -70,23 +70,49 @@ def make_safe(cuda_graph):
 
 
 _OWN_STREAMS = {}
+_OWNED, _FREE = {}, {}      # (device, role, id(owner)) -> stream;  (device, role) -> streams whose owner is gone
 
 
-def own_stream(device=None, role="side", priority=0):
+def _create_stream(dev, priority):
+    import torch
+    handle = ctypes.c_void_p(0)
+    with torch.cuda.device(dev):
+        _hiplib.check(_hiplib.load().butd_stream_create(int(priority), ctypes.byref(handle)), "butd_stream_create")
+        return torch.cuda.ExternalStream(handle.value, device=dev)
+
+
+def _release(key):
+    stream = _OWNED.pop(key, None)
+    if stream is not None:
+        _FREE.setdefault(key[:2], []).append(stream)
+
+
+def own_stream(device=None, role="side", priority=0, owner=None):
     """A stream of our own (``butd_stream_create``) wrapped as ``torch.cuda.ExternalStream`` -- NOT a member of torch's
     round-robin pool of 32, which RCCL's stream and torch's default capture stream come from too (include/butd_graph.h).
     Everything the captured step forks, captures on or uploads through is created here.  One stream per (device, role)
     and process, never destroyed: torch's caching allocator keeps per-stream state keyed by the raw handle (block
-    pools, record_stream events), so a destroyed handle would be touched again by a later empty_cache()."""
+    pools, record_stream events), so a destroyed handle would be touched again by a later empty_cache().
+    ``owner`` (any weak-referenceable object: a GraphedTrainStep, a model): the stream belongs to that instance -- two steps
+    or models of one process (train + eval, the two-model tests) do not serialise their prefetch branches behind each
+    other, and a capture of one does not put a stream into capture mode on which the other still has eager work.  When the
+    owner is collected its streams go to a free list and serve the next owner of that role (still never destroyed)."""
     import torch
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
+    if owner is not None:
+        import weakref
+        key = (dev.index, role, id(owner))
+        stream = _OWNED.get(key)
+        if stream is None:
+            free = _FREE.get(key[:2])
+            stream = free.pop() if free else _create_stream(dev, priority)
+            _OWNED[key] = stream
+            weakref.finalize(owner, _release, key)
+        return stream
     key = (dev.index, role)
     stream = _OWN_STREAMS.get(key)
     if stream is None:
-        handle = ctypes.c_void_p(0)
-        with torch.cuda.device(dev):
-            _hiplib.check(_hiplib.load().butd_stream_create(int(priority), ctypes.byref(handle)), "butd_stream_create")
-            stream = _OWN_STREAMS[key] = torch.cuda.ExternalStream(handle.value, device=dev)
+        stream = _OWN_STREAMS[key] = _create_stream(dev, priority)
     return stream

@@ -918,7 +918,7 @@ class GraphedTrainStep:
         """The step's streams are its own HIP streams, one per role and shared by all captured signatures -- never members
         of torch's pool of 32, which RCCL's stream is drawn from as well (graph_audit.own_stream)."""
         from . import graph_audit
-        return graph_audit.own_stream(dev, role="step." + name)
+        return graph_audit.own_stream(dev, role="step." + name, owner=self)
 
     def _upload_stream(self, dev):
         if getattr(self, "_up", None) is None:

@@ -2,7 +2,8 @@
 # HBM bytes and time of SA1 / SA2 forward + backward in training mode -> gpurun_out/<round>_sa_train_traffic.txt
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/${ROUND:-r04}_sa_train_traffic.txt
+mkdir -p gpurun_out
+OUT=gpurun_out/${ROUND:-r06}_sa_train_traffic.txt
 echo "# set-abstraction levels in TRAINING mode at the bench size (8 x 50 000 points), forward + backward of fused_sa.sa_mlp_pool" > $OUT
 echo "# time: graph replay; bytes: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md), last of two steps" >> $OUT
 for L in 1 2; do
@@ -20,7 +21,10 @@ def load(C):
 f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
 names = [r["Kernel_Name"] for r in f]
 # the last step = the second half of the dispatches after the setup kernels: take the last occurrence block
-last = len(names) - 1 - names[::-1].index(next(n for n in names[::-1] if "sa_group" in n))
+# one step = the distance between the two sa_pool_bwd_stats launches (one per step); the last step = the last `per` dispatches
+marks = [i for i, n in enumerate(names) if "sa_pool_bwd_stats" in n]
+per = marks[-1] - marks[-2]
+last = len(names) - per
 short = lambda n: (n.split("::")[-1] if "anonymous" in n else n).split("(")[0][:44]
 tot = 0.0
 print(f"SA{os.environ['LEVEL']}: per kernel of one forward + backward")

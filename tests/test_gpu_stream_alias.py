@@ -29,6 +29,7 @@ def test_own_streams_are_outside_the_pool_and_stable():
     assert not {s.cuda_stream for s in mine} & pool
     assert graph_audit.own_stream(dev, role="test.alias.0").cuda_stream == mine[0].cuda_stream   # one per role, kept
     x = torch.ones(1 << 16, device=dev)
+    mine[0].wait_stream(torch.cuda.current_stream())          # (own streams are non-blocking: order the read after the fill)
     with torch.cuda.stream(mine[0]):
         y = x * 3
     torch.cuda.current_stream().wait_stream(mine[0])
@@ -38,8 +39,12 @@ def test_own_streams_are_outside_the_pool_and_stable():
 def test_a_capture_forking_every_own_stream_next_to_rccl_survives_the_watchdog():
     """The reproducer with the step's own streams: 32 captures, each forking another stream, a fresh collective in front
     of every capture and 0.3 s inside it for the watchdog to poll.  (``pool`` instead of ``own`` aborts the child.)"""
+    import socket
+    with socket.socket() as sock:              # a free rendezvous port (as bench._spawn_ranks picks one)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
-    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29657", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scratch", "stream_alias_probe.py"), "own"], cwd=ROOT, env=env,
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
