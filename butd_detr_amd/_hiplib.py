@@ -82,6 +82,7 @@ ATTENTION_SYMBOLS = {
     "butd_attention_bwd_long_keys_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 10 + [_c_long, _c_long, _c_float]
                                           + [_c_float, _c_u32, _c_void_p, _c_void_p, _c_long, _c_void_p]),
     "butd_attention_fwd_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
+    "butd_attention_fwd_split_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 6 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_attention_bwd_bf16": (_c_int, [_c_int] * 5 + [_c_void_p] * 11 + [_c_long, _c_long, _c_float]
                                 + [_c_float, _c_u32, _c_void_p, _c_void_p]),
     "butd_add_dropout_layernorm_fwd": (_c_int, [_c_int, _c_int] + [_c_void_p] * 4 + [_c_float] + [_c_void_p] * 3

@@ -1999,6 +1999,35 @@ struct StageH {
         p[0] = (__bf16)v[j].x; p[LD] = (__bf16)v[j].y; p[2 * LD] = (__bf16)v[j].z; p[3 * LD] = (__bf16)v[j].w;
       }
   }
+  // split-bf16 ("bf16 x 3", round 6 microbenchmark): x = hi + lo with hi = bf16(x), lo = bf16(x - hi): 16 bits of
+  // mantissa from two images
+  __device__ inline void commit_frag_split(__bf16 *hi, __bf16 *lo, const float4 (&v)[kVec]) const {
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+      if (row[j] < 64) {
+        const float x[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const __bf16 h = (__bf16)x[i];
+          hi[koff[j][i]] = h;
+          lo[koff[j][i]] = (__bf16)(x[i] - (float)h);
+        }
+      }
+  }
+  __device__ inline void commit_t_split(__bf16 *hi, __bf16 *lo, const float4 (&v)[kVec]) const {
+    constexpr int LD = TImgH<NT>::LD;
+#pragma unroll
+    for (int j = 0; j < kVec; ++j)
+      if (row[j] < 64) {
+        const float x[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const __bf16 h = (__bf16)x[i];
+          hi[toff[j] + i * LD] = h;
+          lo[toff[j] + i * LD] = (__bf16)(x[i] - (float)h);
+        }
+      }
+  }
 };
 // one lane's share of a head-dimension operand: NV x 8 bf16 (d = g * NS + s at slot s, zero beyond NS)
 template <int NS>
@@ -2024,6 +2053,17 @@ __device__ inline HFrag<NS> make_hfrag(const float (&f)[NS]) {
     for (int i = 0; i < 8; ++i) r.v[m][i] = (8 * m + i < NS) ? (__bf16)f[8 * m + i] : (__bf16)0.f;
   return r;
 }
+// the low halves of the same row: x - bf16(x), rounded to bf16
+template <int NS>
+__device__ inline HFrag<NS> make_hfrag_lo(const float (&f)[NS]) {
+  HFrag<NS> r;
+#pragma unroll
+  for (int m = 0; m < ImgH<NS>::NV; ++m)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      r.v[m][i] = (8 * m + i < NS) ? (__bf16)(f[8 * m + i] - (float)(__bf16)f[8 * m + i]) : (__bf16)0.f;
+  return r;
+}
 template <int NS>
 __device__ inline f32x4 mma_h(const HFrag<NS> &a, const HFrag<NS> &b, f32x4 acc) {
 #pragma unroll
@@ -2034,6 +2074,15 @@ __device__ inline f32x4 mma_h(const HFrag<NS> &a, const HFrag<NS> &b, f32x4 acc)
 // tile t (elements 0..3) and of tile t + 1 (elements 4..7) -- registers (probabilities, dS) ...
 __device__ inline bf16x8 pack8(const f32x4 &p, const f32x4 &q) {
   return (bf16x8){(__bf16)p[0], (__bf16)p[1], (__bf16)p[2], (__bf16)p[3], (__bf16)q[0], (__bf16)q[1], (__bf16)q[2], (__bf16)q[3]};
+}
+__device__ inline bf16x8 pack8_lo(const f32x4 &p, const f32x4 &q, const bf16x8 &hi) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    r[i] = (__bf16)(p[i] - (float)hi[i]);
+    r[4 + i] = (__bf16)(q[i] - (float)hi[4 + i]);
+  }
+  return r;
 }
 // ... or a transposed image row (`p` -> element 4g of tile t; tile t + 1 is 16 columns on)
 __device__ inline bf16x8 pair8(const __bf16 *p) {
@@ -2049,14 +2098,19 @@ __device__ inline void zero_halfs(__bf16 *p, int tid) {      // N halfs (a multi
   for (int e = tid; e < N / 2; e += kAttnThreads) w[e] = 0u;
 }
 
-template <int NS, int NT, int NG>
+// SPLIT (round 6 microbenchmark, butd_attention_fwd_split_bf16): every operand as hi + lo bf16 halves, every product as
+// hi.hi + lo.hi + hi.lo on the bf16 matrix cores (the lo.lo term, 2^-16 of the product, is dropped), fp32 accumulation:
+// ~16 bits of mantissa per operand instead of 8 (bf16) or 24 (fp32), three matrix instructions instead of one.
+template <int NS, int NT, int NG, bool SPLIT = false>
 __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_kernel(
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
     float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
   using I = ImgH<NS>;
   using T = TImgH<NT>;
-  constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD;
+  constexpr int NL = SPLIT ? 2 : 1;              // images per operand: hi (| lo behind it)
+  constexpr int kImg1 = 64 * I::LD, kTimg1 = T::ROWS * T::LD;
+  constexpr int kImg = NL * kImg1, kTimg = NL * kTimg1;
   __shared__ __attribute__((aligned(16))) __bf16 KimgG[NG][2][kImg];
   __shared__ __attribute__((aligned(16))) __bf16 VtG[NG][2][kTimg];
   __shared__ __attribute__((aligned(16))) float BiasG[NG][2][64];
@@ -2085,6 +2139,8 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_
   float qf[NS];
   load_row_frag<NS>(qf, qb, E, qi, Lq, fg, D);
   const HFrag<NS> qF = make_hfrag<NS>(qf);
+  HFrag<NS> qL;
+  if constexpr (SPLIT) qL = make_hfrag_lo<NS>(qf);
   float m = kNegInf, l = 0.f;
   f32x4 o[NT];
 #pragma unroll
@@ -2096,6 +2152,15 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_
   zero_halfs<2 * kImg>(&Kimg[0][0], tid);
   zero_halfs<2 * kTimg>(&Vt[0][0], tid);
   __syncthreads();
+  auto commit = [&](int buf, const float4 (&kreg)[StageH<NS, NT>::kVec], const float4 (&vreg)[StageH<NS, NT>::kVec]) {
+    if constexpr (SPLIT) {
+      sg.commit_frag_split(Kimg[buf], Kimg[buf] + kImg1, kreg);
+      sg.commit_t_split(Vt[buf], Vt[buf] + kTimg1, vreg);
+    } else {
+      sg.commit_frag(Kimg[buf], kreg);
+      sg.commit_t(Vt[buf], vreg);
+    }
+  };
 
   const int iters = ((Lk + 63) / 64 + NG - 1) / NG;
   float4 kr[StageH<NS, NT>::kVec], vr[StageH<NS, NT>::kVec];
@@ -2105,8 +2170,7 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_
     sg.fetch(kr, kb + (long)key0 * E, Lk - key0);
     sg.fetch(vr, vb + (long)key0 * E, Lk - key0);
     if (tid < 64) br = key_bias(mb, key0 + tid, Lk);
-    sg.commit_frag(Kimg[0], kr);
-    sg.commit_t(Vt[0], vr);
+    commit(0, kr, vr);
     if (tid < 64) Bias[0][tid] = br;
   }
   __syncthreads();
@@ -2123,8 +2187,15 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_
     if (live) {
       f32x4 st[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
-        st[t] = mma_h<NS>(frag_h<NS>(&Kimg[cur][(t * 16 + fr) * I::LD], fg), qF, (f32x4){0.f, 0.f, 0.f, 0.f});
+      for (int t = 0; t < 4; ++t) {
+        const HFrag<NS> kh = frag_h<NS>(&Kimg[cur][(t * 16 + fr) * I::LD], fg);
+        st[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if constexpr (SPLIT) {      // the small terms first
+          st[t] = mma_h<NS>(frag_h<NS>(&Kimg[cur][kImg1 + (t * 16 + fr) * I::LD], fg), qF, st[t]);
+          st[t] = mma_h<NS>(kh, qL, st[t]);
+        }
+        st[t] = mma_h<NS>(kh, qF, st[t]);
+      }
       // the first V operands (keys of tiles 0 and 1) travel while the softmax runs
       bf16x8 va[NT];
 #pragma unroll
@@ -2179,6 +2250,16 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) vb[nt] = pair8(&Vt[cur][(nt * 16 + fr) * T::LD + 32 + fg * 4]);
         const bf16x8 p01 = pack8(st[0], st[1]), p23 = pack8(st[2], st[3]);
+        if constexpr (SPLIT) {
+          const bf16x8 q01 = pack8_lo(st[0], st[1], p01), q23 = pack8_lo(st[2], st[3], p23);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            o[nt] = mma32(pair8(&Vt[cur][kTimg1 + (nt * 16 + fr) * T::LD + fg * 4]), p01, o[nt]);
+            o[nt] = mma32(pair8(&Vt[cur][kTimg1 + (nt * 16 + fr) * T::LD + 32 + fg * 4]), p23, o[nt]);
+            o[nt] = mma32(va[nt], q01, o[nt]);
+            o[nt] = mma32(vb[nt], q23, o[nt]);
+          }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) o[nt] = mma32(va[nt], p01, o[nt]);
 #pragma unroll
@@ -2187,8 +2268,7 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_
       m = m_new;
     }
     if (more) {
-      sg.commit_frag(Kimg[cur ^ 1], kr);
-      sg.commit_t(Vt[cur ^ 1], vr);
+      commit(cur ^ 1, kr, vr);
       if (tid < 64) Bias[cur ^ 1][tid] = br;
     }
     __syncthreads();
@@ -3138,6 +3218,18 @@ int butd_attention_fwd_bf16(int B, int H, int Lq, int Lk, int D, const float *q,
                             butd_stream_t stream) {
   return attention_fwd_impl(true, B, H, Lq, Lk, D, q, k, v, key_padding_mask, out, lse, dropout_p, dropout_site,
                             rng_counter, stream);
+}
+
+int butd_attention_fwd_split_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                  const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
+                                  float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                                  butd_stream_t stream) {
+  if (B <= 0 || H <= 0 || Lq <= 0) return 0;
+  if (D != 36 || Lk <= 0) return (int)hipErrorInvalidValue;       // (the microbenchmark's instance: head dimension 36)
+  const dim3 grid((Lq + 63) / 64, H, B);
+  hipLaunchKernelGGL((attn_fwd_h_kernel<9, 3, 1, true>), grid, dim3(kAttnThreads), 0, (hipStream_t)stream, H, Lq, Lk, D, q, k,
+                     v, key_padding_mask, out, lse, dropout_p, dropout_site, rng_counter);
+  return (int)hipGetLastError();
 }
 
 int butd_attention_bwd(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,

@@ -141,7 +141,12 @@ def set_compute_dtype(name):
     return prev
 
 
+_split_fwd = [False]     # round 6 microbenchmark hook (scratch/r6_split_bf16.py): the forward core on split-bf16 operands
+
+
 def _attn_fwd():
+    if _split_fwd[0]:
+        return _lib.butd_attention_fwd_split_bf16
     return _lib.butd_attention_fwd_bf16 if _compute_bf16[0] else _lib.butd_attention_fwd
 
 
@@ -1003,9 +1008,9 @@ class _HoistedKV(torch.autograd.Function):
                 queue += probs
         if queue:
             launches += [queue[k:k + _HOIST_GROUP[0]] for k in range(0, len(queue), _HOIST_GROUP[0])]
-        handle = (side if side is not None else main).cuda_stream
-        for probs in launches:
-            _launch(probs, dev, handle)
+        with torch.cuda.stream(side) if side is not None else _null():
+            for probs in launches:
+                _gemm(probs, mems[0])
         if mems[0].requires_grad or any(p.requires_grad for p in params):
             # the stacked K | V weights of a memory, for the one-product input gradient of the backward pass
             with torch.cuda.stream(side) if side is not None else _null():

@@ -156,6 +156,15 @@ int butd_attention_fwd(int B, int H, int Lq, int Lk, int D, const float *q, cons
                        float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
                        butd_stream_t stream);
 
+/* Round 6 microbenchmark (profiles/r06_split_bf16.txt): butd_attention_fwd with every operand split into two bf16 halves
+ * (x = hi + lo) and every product as hi.hi + lo.hi + hi.lo on v_mfma_f32_16x16x32_bf16, fp32 accumulation -- ~16 bits of
+ * mantissa per operand.  Same arguments and results as butd_attention_fwd; head dimension 36 only.  Not on the product
+ * path: a NAMED extra precision (neither the reference's fp32 arithmetic nor configs[3]'s bf16). */
+int butd_attention_fwd_split_bf16(int B, int H, int Lq, int Lk, int D, const float *q, const float *k,
+                                  const float *v, const uint8_t *key_padding_mask, float *out, float *lse,
+                                  float dropout_p, uint32_t dropout_site, const uint64_t *rng_counter,
+                                  butd_stream_t stream);
+
 /* Backward of the above.  delta (B,H,Lq) scratch (written here); dq (B,Lq,.), dk, dv (B,Lk,.) are
  * overwritten.  The gradient rows may be wider than H*D: ld_dq / ld_dkv are their row strides in floats
  * (0 = H*D), so dq|dk|dv (or dk|dv) can sit side by side in one matrix and the input-projection

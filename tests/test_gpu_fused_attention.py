@@ -304,6 +304,48 @@ def test_bf16_attention_core_alone(mods):
         _close(res["bf16"][i], res["f32"][i], 3e-2)
 
 
+@pytest.mark.parametrize("Lq,Lk,masked", [(512, 320, False), (256, 132, True), (100, 77, True)])
+def test_split_bf16_forward_core_tracks_fp32_and_float64(mods, Lq, Lk, masked):
+    """Round 6's microbenchmark kernel (butd_attention_fwd_split_bf16: hi + lo bf16 operands, three products per term):
+    against a float64 evaluation of the same attention within 5e-5 of the output scale (the fp32 kernel: ~1e-6, the bf16
+    kernel: ~8e-3), ragged key tiles and a key-padding mask included; the log-sum-exp within 1e-5.  Dropout draws the same
+    counter-hash mask as the fp32 kernel."""
+    from butd_detr_amd import _hiplib
+    ab, fa, _, _ = mods
+    lib = _hiplib.load()
+    B, H, D = 3, 8, 36
+    E = H * D
+    g = torch.Generator(device="cuda").manual_seed(Lq)
+    q = torch.randn(B, Lq, E, device="cuda", generator=g) / 6.0
+    k, v = (torch.randn(B, Lk, E, device="cuda", generator=g) for _ in range(2))
+    mask = None
+    if masked:
+        mask = torch.zeros(B, Lk, dtype=torch.bool, device="cuda")
+        mask[0, Lk // 2:] = True
+        mask[2, 5:9] = True
+    mptr = None if mask is None else mask.data_ptr()
+    ctr = fa.rng_counter(q.device).data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(fn, p):
+        out, lse = torch.empty_like(q), torch.empty(B, H, Lq, device="cuda")
+        assert fn(B, H, Lq, Lk, D, q.data_ptr(), k.data_ptr(), v.data_ptr(), mptr, out.data_ptr(), lse.data_ptr(), p, 9, ctr, st) == 0
+        torch.cuda.synchronize()
+        return out, lse
+    qd, kd, vd = (t.double().view(B, -1, H, D).transpose(1, 2) for t in (q, k, v))
+    sc = qd @ kd.transpose(-1, -2)
+    if mask is not None:
+        sc = sc.masked_fill(mask[:, None, None, :], float("-inf"))
+    truth = (torch.softmax(sc, -1) @ vd).transpose(1, 2).reshape(B, Lq, E)
+    out, lse = run(lib.butd_attention_fwd_split_bf16, 0.0)
+    scale = float(truth.abs().max())
+    assert float((out.double() - truth).abs().max()) / scale < 5e-5
+    assert float((lse.double() - torch.logsumexp(sc, -1)).abs().max()) < 1e-5 * max(1.0, float(torch.logsumexp(sc, -1).abs().max()))
+    o32, _ = run(lib.butd_attention_fwd, 0.1)
+    osp, _ = run(lib.butd_attention_fwd_split_bf16, 0.1)
+    assert float((osp - o32).abs().max()) / scale < 1e-4                    # same keep mask, same scaling by 1 / (1 - p)
+
+
 @pytest.mark.parametrize("B,Lq,Lk,masked", [(8, 1024, 1024, False), (8, 256, 1024, False), (8, 80, 1024, True), (4, 200, 1500, True),
                                             (8, 256, 256, False), (8, 256, 132, True), (8, 1024, 132, True), (8, 1024, 80, True),
                                             (8, 80, 80, True), (3, 77, 300, True)])
