@@ -20,6 +20,7 @@ POINTNET2_SYMBOLS = {
     "butd_error_string": (ctypes.c_char_p, [_c_int]),
     "butd_opt_n_threads": (_c_int, [_c_int]),
     "butd_furthest_point_sampling": (_c_int, [_c_int] * 3 + [_c_void_p] * 4),
+    "butd_fps_prefix_check": (_c_int, [_c_int] * 3 + [_c_void_p] * 3),
     "butd_fps_workspace_bytes": (_c_size_t, [_c_int, _c_int]),
     "butd_furthest_point_sampling_ws": (_c_int, [_c_int] * 3 + [_c_void_p] * 4 + [_c_size_t, _c_void_p]),
     "butd_gather_points": (_c_int, [_c_int] * 4 + [_c_void_p] * 4),

@@ -44,10 +44,16 @@ __host__ __device__ inline int ilog2_floor(unsigned v) {
 template <int THREADS, int PPT>
 __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, int log2bs,
                                                       const float *__restrict__ dataset,
-                                                      int *__restrict__ idxs) {
+                                                      int *__restrict__ idxs,
+                                                      const int *__restrict__ verdict, int verdict_stride) {
   constexpr int kNumWaves = THREADS / kWave;
   __shared__ fps::Slot slots[2][fps::kMaxWaves];
   const int tid = threadIdx.x;
+  // the prefix check (below) proved that this scene's samples are 0, 1, ..., m-1: write them, skip the serial chain
+  if (verdict != nullptr && verdict[(size_t)blockIdx.x * verdict_stride] == 0) {
+    for (int j = tid; j < m; j += THREADS) idxs[(size_t)blockIdx.x * m + j] = j;
+    return;
+  }
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float *pts = dataset + (size_t)blockIdx.x * n * 3;
@@ -100,6 +106,102 @@ __global__ __launch_bounds__(THREADS) void fps_kernel(int n, int m, int log2bs,
     const int old = fps::select_global_best<kNumWaves>(buf, lane, log2bs, p0x, p0y, p0z, x1, y1, z1);
     if (tid == 0) out[j] = old;
   }
+}
+
+// ----------------------------------------------------------------------------------------------
+// FPS of a cloud that is ALREADY in furthest-point order (levels 2-4 of the backbone: their input is the
+// previous level's samples in selection order, and the reference's own comments at models/backbone_module.py:131-140
+// say the indices come out as 0..m-1).  Instead of assuming it, DECIDE it with fully parallel work and run the serial
+// kernel only where the answer is no.  With the samples so far being 0..j-1, iteration j of sampling_gpu.cu:100-117
+// holds temp[k] = min(1e10, d(0,k), ..., d(j-1,k)) =: r_j(k) for every point that is not skipped (:105-106), and picks
+// the maximum of (r_j(k), -key(k)) -- key = the reference's tie order (fps_common.h), a total order on points.  So
+// the samples are 0..m-1 exactly when, for every j in 1..m-1, point j is not skipped and no other competing k has
+// r_j(k) > r_j(j), or r_j(k) == r_j(j) with a smaller key.  (Already selected points compete with r = 0, as in the
+// reference.)  The test is exact, not conservative: verdict 0 <=> the serial kernel would write 0..m-1.
+// d is the serial kernel's expression (this TU is built with -ffp-contract=off), symmetric in its two points bit for
+// bit.
+//   fps_prefix_threshold_kernel: T_j = r_j(j) for j < m, the i-range cut in `parts` pieces (partial minima, folded
+//                                when the next kernel stages them): m^2/2 distances per scene, no serial chain
+//   fps_prefix_check_kernel    : one thread per point k walks j = 1..m-1 keeping r_j(k) in a register and compares
+//                                with T_j from LDS: n*m distances per scene over n/256 workgroups, no barrier in
+//                                the loop; a wave that saw a violation leaves the loop
+// Workspace = the caller's `temp` (b, n): slot 0 of a scene is the verdict (0 = the samples are 0..m-1; T_0 is never
+// needed), slots part*m + j hold the partial thresholds (parts * m <= n).
+constexpr int kPrefixMaxM = 2048;      // 32 KB of LDS per workgroup
+constexpr int kPrefixMaxN = 8192;      // the register-resident serial kernels' range
+
+__device__ inline float fps_dist(float x2, float y2, float z2, float x1, float y1, float z1) {
+  return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+}
+
+__global__ __launch_bounds__(64) void fps_prefix_threshold_kernel(int n, int m, int parts,
+                                                                  const float *__restrict__ dataset,
+                                                                  float *__restrict__ temp) {
+  __shared__ float4 pts_s[kPrefixMaxM];
+  const int scene = blockIdx.z, part = blockIdx.y;
+  const int j0 = blockIdx.x * 64, lane = threadIdx.x;
+  const float *pts = dataset + (size_t)scene * n * 3;
+  float *ws = temp + (size_t)scene * n;
+  const int j = j0 + lane;
+  // this wave's lanes need the points [lo, hi) of the prefix: part p of lane j covers i in [p*j/parts, (p+1)*j/parts)
+  const int lo = (int)(((long long)part * j0) / parts);
+  int jl = j0 + 63; if (jl > m - 1) jl = m - 1;
+  const int hi = (int)(((long long)(part + 1) * jl) / parts);
+  for (int i = lo + lane; i < hi; i += 64)
+    pts_s[i] = make_float4(pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2], 0.f);
+  if (blockIdx.x == 0 && part == 0 && lane == 0) reinterpret_cast<int *>(ws)[0] = 0;   // verdict: nothing failed yet
+  __syncthreads();
+  if (j >= m || j == 0) return;
+  const float xj = pts[j * 3 + 0], yj = pts[j * 3 + 1], zj = pts[j * 3 + 2];
+  const int a = (int)(((long long)part * j) / parts), e = (int)(((long long)(part + 1) * j) / parts);
+  float t = 1e10f;
+#pragma unroll 8
+  for (int i = a; i < e; ++i) {
+    const float4 p = pts_s[i];
+    t = fminf(fps_dist(xj, yj, zj, p.x, p.y, p.z), t);
+  }
+  ws[(size_t)part * m + j] = t;
+}
+
+__global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int parts, int log2bs,
+                                                               const float *__restrict__ dataset,
+                                                               float *__restrict__ temp) {
+  __shared__ float4 sel_s[kPrefixMaxM];   // slot j-1: (point j-1, T_j) = what iteration j needs
+  const int scene = blockIdx.y, tid = threadIdx.x;
+  const float *pts = dataset + (size_t)scene * n * 3;
+  float *ws = temp + (size_t)scene * n;
+  for (int i = tid; i < m - 1; i += 256) {
+    float t = ws[i + 1];
+    for (int p = 1; p < parts; ++p) t = fminf(ws[(size_t)p * m + i + 1], t);
+    sel_s[i] = make_float4(pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2], t);
+  }
+  __syncthreads();
+  const int k = blockIdx.x * 256 + tid;
+  const int k0 = k & ~63;                 // first point of this wave
+  float x = 0.f, y = 0.f, z = 0.f;
+  bool competes = false;
+  if (k < n) {
+    x = pts[k * 3 + 0]; y = pts[k * 3 + 1]; z = pts[k * 3 + 2];
+    competes = !fps::skipped(x, y, z);
+  }
+  const unsigned mykey = fps::key_of((unsigned)k, log2bs);
+  // a skipped point inside the prefix 1..m-1 is never selected
+  unsigned long long viol = __ballot(k >= 1 && k < m && !competes);
+  float r = 1e10f;
+  for (int jb = 1; jb < m && viol == 0ull; jb += 32) {
+    const int je = jb + 32 < m ? jb + 32 : m;
+#pragma unroll 8
+    for (int j = jb; j < je; ++j) {
+      const float4 s = sel_s[j - 1];
+      r = fminf(fps_dist(x, y, z, s.x, s.y, s.z), r);
+      // lane (j - k0) owns point j itself (r == T_j there by construction); every other competing lane must stay
+      // below, or tie with a larger key (wave-uniform branch, taken on ties only)
+      const unsigned long long self = (unsigned)(j - k0) < 64u ? (1ull << (j - k0)) : 0ull;
+      const unsigned long long ge = __ballot(competes && r >= s.w) & ~self;
+      if (ge != 0ull) viol |= __ballot(r > s.w || mykey < fps::key_of((unsigned)j, log2bs)) & ge;
+    }
+  }
+  if (viol != 0ull && (tid & 63) == 0) atomicOr(reinterpret_cast<int *>(ws), 1);
 }
 
 // Streaming fallback for clouds that fit neither the register-resident kernel nor the pruned path's
@@ -420,6 +522,8 @@ __global__ __launch_bounds__(1024) void three_interpolate_grad_lds_kernel(
 
 inline int launch_status() { return (int)hipGetLastError(); }
 
+inline bool fps_prefix_eligible(int n, int m) { return m >= 2 && m <= kPrefixMaxM && m <= n && n <= kPrefixMaxN; }
+
 inline dim3 chan_grid(int P, int c, int b) {
   int gx = (P + 255) / 256;
   if (gx > 4096) gx = 4096;
@@ -445,14 +549,32 @@ int butd_opt_n_threads(int work_size) {
 
 // butd_fps_workspace_bytes / butd_furthest_point_sampling_ws: see fps_pruned.hip
 
+int butd_fps_prefix_check(int b, int n, int m, const float *dataset, float *temp, butd_stream_t stream) {
+  if (b <= 0 || !fps_prefix_eligible(n, m)) return 0;
+  if (temp == nullptr) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  int parts = n / m;
+  if (parts > 4) parts = 4;
+  hipLaunchKernelGGL(fps_prefix_threshold_kernel, dim3((m + 63) / 64, parts, b), dim3(64), 0, s, n, m, parts,
+                     dataset, temp);
+  hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((n + 255) / 256, b), dim3(256), 0, s, n, m, parts,
+                     ilog2_floor((unsigned)butd_opt_n_threads(n)), dataset, temp);
+  return launch_status();
+}
+
 int butd_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp, int *idxs,
                                  butd_stream_t stream) {
   if (b <= 0 || m <= 0) return 0;
   if (n <= 0) return (int)hipErrorInvalidValue;
   hipStream_t s = (hipStream_t)stream;
   const int log2bs = ilog2_floor((unsigned)butd_opt_n_threads(n));
+  // a cloud that is already in furthest-point order (the backbone's levels 2-4) is recognised by parallel work and
+  // the serial kernel below returns at once for it; any other cloud fails the check within its first iterations
+  const int *verdict = nullptr;
+  if (temp != nullptr && fps_prefix_eligible(n, m) && butd_fps_prefix_check(b, n, m, dataset, temp, stream) == 0)
+    verdict = reinterpret_cast<const int *>(temp);
 #define FPS_LAUNCH(T, P) \
-  hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), 0, s, n, m, log2bs, dataset, idxs)
+  hipLaunchKernelGGL((fps_kernel<T, P>), dim3(b), dim3(T), 0, s, n, m, log2bs, dataset, idxs, verdict, n)
   if (n <= 256) FPS_LAUNCH(256, 1);
   else if (n <= 512) FPS_LAUNCH(256, 2);
   else if (n <= 1024) FPS_LAUNCH(256, 4);

@@ -82,6 +82,22 @@ def furthest_point_sampling(points, nsamples):
     return output
 
 
+def fps_prefix_verdict(points, nsamples):
+    """(B,N,3) f32 -> (B,) i32: 0 exactly where furthest point sampling of the scene selects 0, 1, ..., nsamples-1
+    (the backbone's levels 2-4, models/backbone_module.py:131-140) -- decided by parallel work --, non-zero where the
+    serial kernel runs; None for shapes the check does not cover.  ``furthest_point_sampling`` runs the same check
+    itself -- this entry exists for tests and measurements."""
+    _check_contiguous(points, "points")
+    _check_float(points, "points")
+    _require_gpu(points)
+    b, n, m = points.size(0), points.size(1), int(nsamples)
+    if not (2 <= m <= 2048 and m <= n <= 8192):
+        return None
+    tmp = torch.empty((b, n), dtype=torch.float32, device=points.device)
+    _run("butd_fps_prefix_check", points, b, n, m, points.data_ptr(), tmp.data_ptr())
+    return tmp.view(torch.int32)[:, 0].clone()
+
+
 def gather_points(points, idx):
     """points (B,C,N) f32, idx (B,M) i32 -> (B,C,M).  src/sampling.cpp:20-44."""
     _check_contiguous(points, "points")

@@ -47,6 +47,16 @@ int butd_opt_n_threads(int work_size);
 int butd_furthest_point_sampling(int b, int n, int m, const float *dataset, float *temp,
                                  int *idxs, butd_stream_t stream);
 
+/* The parallel half of butd_furthest_point_sampling for clouds that are already in furthest-point order (the
+ * backbone's levels 2-4, models/backbone_module.py:131-140: "inds == arange(m)").  For 2 <= m <= 2048, m <= n <= 8192
+ * it leaves a verdict per scene in ((int *)temp)[scene * n]: 0 <=> the reference algorithm (sampling_gpu.cu:100-117,
+ * incl. the |p|^2 <= 1e-3 skip and the tree reduction's tie order) selects 0, 1, ..., m-1; non-zero otherwise.  The
+ * test is exact: every sample must win its iteration against every other competing point, ties by the tie order.
+ * n*m + m*m/2 independent distance evaluations instead of m-1 dependent iterations.  butd_furthest_point_sampling
+ * runs it first whenever temp is given; the serial kernel of a scene with verdict 0 writes 0..m-1 and returns.
+ * Other shapes: no-op. */
+int butd_fps_prefix_check(int b, int n, int m, const float *dataset, float *temp, butd_stream_t stream);
+
 /* Bytes of extra device workspace the pruned large-cloud FPS path wants for (b, n); 0 = none needed.
  * Pass it to butd_furthest_point_sampling_ws; without it the streaming kernel is used. */
 size_t butd_fps_workspace_bytes(int b, int n);
