@@ -41,6 +41,22 @@ def decoder_inputs():
                 text_mask=text_mask, box_mask=box_mask)
 
 
+def decoder_bench_inputs():
+    """A decoder layer at the bench's per-layer shapes (256 queries, 1024 seeds, 80 tokens, 132 boxes), 6 scenes: the
+    batch from which the attention backward's one-pass kernel takes its 256-key plan at the 1024-seed site, as at
+    the bench's 8 (csrc/attention_ops.hip longk_plan: (Lk / 256) * B * heads >= 192)."""
+    rng = np.random.default_rng(23)
+    b, q, v, l, d = 6, 256, 1024, 80, 132
+    text_mask = torch.zeros(b, l, dtype=torch.bool)
+    box_mask = torch.zeros(b, d, dtype=torch.bool)
+    for i in range(b):
+        text_mask[i, 12 + 9 * i:] = True            # 12 .. 57 tokens
+        box_mask[i, 20 + 17 * i:] = True            # 20 .. 105 boxes
+    return dict(query=_t(rng, b, q, D_MODEL), vis=_t(rng, b, v, D_MODEL), text=_t(rng, b, l, D_MODEL),
+                boxes=_t(rng, b, d, D_MODEL), query_pos=_t(rng, b, q, 6),
+                text_mask=text_mask, box_mask=box_mask)
+
+
 def backbone_inputs():
     from butd_detr_amd.synthetic_scenes import uniform_cloud
     return torch.from_numpy(uniform_cloud(seed=5, n_points=4096, batch=2))

@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 from golden import text_stub, weights  # noqa: E402
 from golden.cases import (PREFIXES, TRAIN_GRAD_KEYS, backbone_inputs, bdetr_inputs, by_seed,  # noqa: E402
-                          decoder_inputs, encoder_inputs, probe, train_loss, zero_dropout)
+                          decoder_bench_inputs, decoder_inputs, encoder_inputs, probe, train_loss, zero_dropout)
 
 
 def load_reference():
@@ -99,6 +99,32 @@ def golden_decoder(enc):
             g_cross_v_in_proj_weight=p["cross_v.in_proj_weight"].grad,
             g_self_posembed_0_weight=p["self_posembed.position_embedding_head.0.weight"].grad,
             g_ffn_3_weight=p["ffn.3.weight"].grad)
+
+
+def golden_decoder_bench_shape(enc):
+    """One decoder layer at the bench's shapes (cases.decoder_bench_inputs), train mode, dropout 0: the sites
+    256 x 256, 256 x 80, 256 x 132, 256 x 1024 that the one-pass attention backward serves in the step."""
+    layer = enc.BiDecoderLayer(288, n_heads=8, dim_feedforward=256, dropout=0.0, activation="relu",
+                               self_position_embedding="loc_learned", butd=True)
+    weights.fill_(layer, seed=16)
+    layer.train()
+    inp = decoder_bench_inputs()
+    for k in ("query", "vis", "text", "boxes"):
+        inp[k].requires_grad_(True)
+    out = layer(inp["query"], inp["vis"], inp["text"], inp["query_pos"], None, inp["text_mask"],
+                detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
+    (out * probe(out.shape, 5)).sum().backward()
+    p = dict(layer.named_parameters())
+    # (the fixture stays small: every 2nd query row, every 8th seed row + column sums, every 3rd row of the packed
+    # q | k | v weight gradients)
+    npz("decoder_256x1024_train.npz", out_rows2=out[:, ::2], g_query_rows2=inp["query"].grad[:, ::2],
+        g_vis_rows8=inp["vis"].grad[:, ::8], g_vis_colsum=inp["vis"].grad.double().sum(1),
+        g_text=inp["text"].grad, g_boxes_rows2=inp["boxes"].grad[:, ::2],
+        g_cross_v_in_proj_weight_rows3=p["cross_v.in_proj_weight"].grad[::3],
+        g_self_attn_in_proj_weight_rows3=p["self_attn.in_proj_weight"].grad[::3],
+        g_cross_d_out_proj_weight=p["cross_d.out_proj.weight"].grad,
+        g_self_posembed_0_weight=p["self_posembed.position_embedding_head.0.weight"].grad,
+        g_ffn_3_weight=p["ffn.3.weight"].grad)
 
 
 def golden_backbone(bb):
@@ -195,8 +221,12 @@ def golden_bdetr_train(bdetr):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     enc_m, bb_m, bdetr_m = load_reference()
+    if sys.argv[1:] == ["decoder_bench_shape"]:       # (one case alone: the others are unchanged)
+        golden_decoder_bench_shape(enc_m)
+        sys.exit(0)
     golden_encoder(enc_m)
     golden_decoder(enc_m)
+    golden_decoder_bench_shape(enc_m)
     golden_backbone(bb_m)
     golden_bdetr(bdetr_m)
     golden_bdetr_train(bdetr_m)

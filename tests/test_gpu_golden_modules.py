@@ -48,16 +48,16 @@ def _observe(err, tol):
     _OBSERVED.append([test, float(err.max()), float(err.mean()), float(tol), float((err > tol).mean())])
 
 
-def close(t, ref, tol=1e-3, outlier_frac=0.0):
-    """|t - ref| <= tol * max|ref| everywhere, except for at most ``outlier_frac`` of the elements
-    (max-pool arg-max flips between near-equal candidates reroute a few gradient entries)."""
+def close(t, ref, tol=1e-3, outlier_frac=0.0, outlier_max=0.2):
+    """|t - ref| <= tol * max|ref| everywhere, except for at most ``outlier_frac`` of the elements, which stay
+    within ``outlier_max`` (max-pool arg-max flips between near-equal candidates reroute a few gradient entries)."""
     a = t.detach().float().cpu().numpy()
     scale = max(float(np.abs(ref).max()), 1e-6)
     _observe(np.abs(a - ref) / scale, tol)
     if outlier_frac:
         bad = np.abs(a - ref) / scale > tol
         assert bad.mean() <= outlier_frac, f"{bad.sum()} of {bad.size} elements beyond {tol}"
-        assert np.abs(a - ref).max() / scale < 0.2
+        assert np.abs(a - ref).max() / scale < outlier_max
         return
     np.testing.assert_allclose(a / scale, ref / scale, rtol=0, atol=tol)
 
@@ -126,6 +126,45 @@ def test_decoder_layer_golden(backend, mode):
     close(p["ffn.3.weight"].grad, g["g_ffn_3_weight"], GRAD_TOL)
 
 
+def test_decoder_layer_golden_bench_shapes(backend):
+    """The reference's decoder layer at the bench's per-layer shapes (6 scenes x 256 queries over 256 / 80 / 132 / 1024
+    keys, train mode, dropout 0; tests/golden/make_golden.py golden_decoder_bench_shape): the shapes at which the
+    attention backward runs as ONE pass (butd_attention_bwd_long_keys: 64-key chunks with dQ slabs at the three short
+    sites, the 256-key plan at the 1024-seed site) -- pinned against the imported reference directly, not through the
+    small goldens (whose 16 queries x 64 seeds take the two-kernel walk) or the full model's train6 golden."""
+    from butd_detr_amd import _hiplib, fused_attention as fa
+    from butd_detr_amd.encoder_decoder_layers import BiDecoderLayer
+    from tests.golden.cases import decoder_bench_inputs
+    g = load("decoder_256x1024_train.npz")
+    layer = BiDecoderLayer(288, n_heads=8, dim_feedforward=256, dropout=0.0, activation="relu",
+                           self_position_embedding="loc_learned", butd=True)
+    weights.fill_(layer, seed=16).cuda()
+    layer.train()
+    inp = cuda(decoder_bench_inputs())
+    if backend == "hip":        # the one-pass kernel serves all four sites of this batch
+        lib = _hiplib.load()
+        assert fa._long_keys[0]
+        for lk in (256, 80, 132, 1024):
+            assert int(lib.butd_attention_bwd_long_keys_scratch(6, 8, 256, lk, 36, 288)) >= 0
+    for k in ("query", "vis", "text", "boxes"):
+        inp[k].requires_grad_(True)
+    out = layer(inp["query"], inp["vis"], inp["text"], inp["query_pos"], None, inp["text_mask"],
+                detected_feats=inp["boxes"], detected_mask=inp["box_mask"])
+    close(out[:, ::2], g["out_rows2"], OUT_TOL)
+    (out * probe(out.shape, 5).cuda()).sum().backward()
+    close(inp["query"].grad[:, ::2], g["g_query_rows2"], GRAD_TOL)
+    close(inp["vis"].grad[:, ::8], g["g_vis_rows8"], GRAD_TOL)
+    close(inp["vis"].grad.double().sum(1), g["g_vis_colsum"], GRAD_TOL)
+    close(inp["text"].grad, g["g_text"], GRAD_TOL)
+    close(inp["boxes"].grad[:, ::2], g["g_boxes_rows2"], GRAD_TOL)
+    p = dict(layer.named_parameters())
+    close(p["cross_v.in_proj_weight"].grad[::3], g["g_cross_v_in_proj_weight_rows3"], GRAD_TOL)
+    close(p["self_attn.in_proj_weight"].grad[::3], g["g_self_attn_in_proj_weight_rows3"], GRAD_TOL)
+    close(p["cross_d.out_proj.weight"].grad, g["g_cross_d_out_proj_weight"], GRAD_TOL)
+    close(p["self_posembed.position_embedding_head.0.weight"].grad, g["g_self_posembed_0_weight"], GRAD_TOL)
+    close(p["ffn.3.weight"].grad, g["g_ffn_3_weight"], GRAD_TOL)
+
+
 @pytest.mark.parametrize("mode", ["eval", "train"])
 @pytest.mark.parametrize("side", [False, True])
 def test_decoder_layer_golden_hoisted_memory(mode, side):
@@ -188,14 +227,16 @@ def test_backbone_golden(mode):
     p = dict(net.named_parameters())
     # weight gradients through up to 14 batch-norm layers: the GPU reduces the batch statistics in a
     # different order than the CPU reference run, so the deepest ones get a looser (1e-2) bound; observed in train mode:
-    # 0.07 % of the elements beyond 1e-2 (max-pool winners that flip between near-equal candidates), mean 2.2e-3
+    # max-pool winners that flip between near-equal candidates put a few elements beyond 1e-2 (profiles/r06_golden_errors.json:
+    # none in three of the tensors, 0.006 % of sa3's at <= 1.3e-2, 0.065 % of fp2's at <= 4.4e-2; means 0.5-2.2e-3): the
+    # budgets are twice the observed shares, the outliers' bound ~2x the largest one seen
     gtol = 1e-2 if mode == "train" else BACKBONE_EVAL_GRAD_TOL
-    frac = 1e-3 if mode == "train" else 0.0
-    close(p["sa1.mlp_module.layer0.conv.weight"].grad, g["g_sa1_layer0_conv"], gtol, frac)
-    close(p["sa3.mlp_module.layer2.conv.weight"].grad, g["g_sa3_layer2_conv"], gtol, frac)
-    close(p["sa2.mlp_module.layer1.bn.bn.weight"].grad, g["g_sa2_layer1_bn_weight"], gtol, frac)
-    close(p["fp1.mlp.layer0.conv.weight"].grad, g["g_fp1_layer0_conv"], gtol, frac)
-    close(p["fp2.mlp.layer1.conv.weight"].grad, g["g_fp2_layer1_conv"], gtol, frac)
+    frac, frac_fp2, omax = (1.5e-4, 1.3e-3, 0.1) if mode == "train" else (0.0, 0.0, 0.2)
+    close(p["sa1.mlp_module.layer0.conv.weight"].grad, g["g_sa1_layer0_conv"], gtol, frac, omax)
+    close(p["sa3.mlp_module.layer2.conv.weight"].grad, g["g_sa3_layer2_conv"], gtol, frac, omax)
+    close(p["sa2.mlp_module.layer1.bn.bn.weight"].grad, g["g_sa2_layer1_bn_weight"], gtol, frac, omax)
+    close(p["fp1.mlp.layer0.conv.weight"].grad, g["g_fp1_layer0_conv"], gtol, frac, omax)
+    close(p["fp2.mlp.layer1.conv.weight"].grad, g["g_fp2_layer1_conv"], gtol, frac_fp2, omax)
 
 
 def test_bdetr_golden(backend):
