@@ -154,9 +154,19 @@ __global__ __launch_bounds__(64) void fps_prefix_threshold_kernel(int n, int m, 
   if (j >= m || j == 0) return;
   const float xj = pts[j * 3 + 0], yj = pts[j * 3 + 1], zj = pts[j * 3 + 2];
   const int a = (int)(((long long)part * j) / parts), e = (int)(((long long)(part + 1) * j) / parts);
+  // eight independent distances per trip: the loop is a latency chain otherwise (one wave per SIMD)
   float t = 1e10f;
-#pragma unroll 8
-  for (int i = a; i < e; ++i) {
+  int i = a;
+  for (; i + 8 <= e; i += 8) {
+    float d[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 p = pts_s[i + u];
+      d[u] = fps_dist(xj, yj, zj, p.x, p.y, p.z);
+    }
+    t = fminf(t, fminf(fminf(fminf(d[0], d[1]), fminf(d[2], d[3])), fminf(fminf(d[4], d[5]), fminf(d[6], d[7]))));
+  }
+  for (; i < e; ++i) {
     const float4 p = pts_s[i];
     t = fminf(fps_dist(xj, yj, zj, p.x, p.y, p.z), t);
   }
@@ -188,18 +198,42 @@ __global__ __launch_bounds__(256) void fps_prefix_check_kernel(int n, int m, int
   // a skipped point inside the prefix 1..m-1 is never selected
   unsigned long long viol = __ballot(k >= 1 && k < m && !competes);
   float r = 1e10f;
-  for (int jb = 1; jb < m && viol == 0ull; jb += 32) {
-    const int je = jb + 32 < m ? jb + 32 : m;
-#pragma unroll 8
-    for (int j = jb; j < je; ++j) {
-      const float4 s = sel_s[j - 1];
-      r = fminf(fps_dist(x, y, z, s.x, s.y, s.z), r);
-      // lane (j - k0) owns point j itself (r == T_j there by construction); every other competing lane must stay
-      // below, or tie with a larger key (wave-uniform branch, taken on ties only)
-      const unsigned long long self = (unsigned)(j - k0) < 64u ? (1ull << (j - k0)) : 0ull;
-      const unsigned long long ge = __ballot(competes && r >= s.w) & ~self;
-      if (ge != 0ull) viol |= __ballot(r > s.w || mykey < fps::key_of((unsigned)j, log2bs)) & ge;
+  const unsigned long long cmask = __ballot(competes);
+  // one sample: lane (j - k0) owns point j itself (r == T_j there by construction); every other competing lane must
+  // stay below, or tie with a larger key (wave-uniform branch, taken on ties only)
+  auto one = [&](int j) {
+    const float4 s = sel_s[j - 1];
+    r = fminf(fps_dist(x, y, z, s.x, s.y, s.z), r);
+    const unsigned long long self = (unsigned)(j - k0) < 64u ? (1ull << (j - k0)) : 0ull;
+    const unsigned long long ge = __ballot(r >= s.w) & cmask & ~self;
+    if (ge != 0ull) viol |= __ballot(r > s.w || mykey < fps::key_of((unsigned)j, log2bs)) & ge;
+  };
+  int j = 1;
+  while (j < m && viol == 0ull) {
+    // eight samples per trip with independent distances (the loop is a latency chain otherwise: one wave per SIMD).
+    // Not where this wave owns one of the eight samples, and not when a lane reaches a threshold: then one by one.
+    const bool own = j + 8 > k0 && j < k0 + 64;
+    if (j + 8 <= m && !own) {
+      float4 s[8];
+      float rr[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s[u] = sel_s[j - 1 + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rr[u] = fps_dist(x, y, z, s[u].x, s[u].y, s[u].z);
+      rr[0] = fminf(rr[0], r);
+#pragma unroll
+      for (int u = 1; u < 8; ++u) rr[u] = fminf(rr[u], rr[u - 1]);
+      bool hit = false;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) hit |= rr[u] >= s[u].w;
+      if ((__ballot(hit) & cmask) == 0ull) {
+        r = rr[7];
+        j += 8;
+        continue;
+      }
     }
+    const int je = j + 8 < m ? j + 8 : m;
+    for (; j < je; ++j) one(j);
   }
   if (viol != 0ull && (tid & 63) == 0) atomicOr(reinterpret_cast<int *>(ws), 1);
 }
