@@ -22,6 +22,13 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + INCLUDE,
           "-Wall", "-Wno-unused-function"]
 # Per-TU flags.  The index kernels must round exactly like the oracle: no FMA contraction.
+# Wave priority of the MAIN queue's kernels (s_setprio at kernel entry; every unit but the index ops the prefetch branch
+# runs): the captured step's prefetch branches -- the next batch's furthest-point sampling on 8 CUs for 3.4 ms, its
+# language model -- share CUs with the step's own kernels; with the step's waves ahead in the issue arbitration the
+# level-1 sampling costs the step 0.41 instead of 0.61 ms: 20.51 -> 20.28 ms per step (profiles/r06_side_branches.txt).
+MAIN_PRIO = ["-DBUTD_MAIN_PRIO=3"]
+MAIN_UNITS = ("gemm_ops.hip", "attention_ops.hip", "mlp_ops.hip", "sa_ops.hip", "sa_last_bwd.hip", "sa_fused.hip",
+              "sa_first_linear.hip", "criterion_ops.hip", "lsap_ops.hip", "optim_ops.hip")
 TU_FLAGS = {
     "pointnet2_ops.hip": ["-ffp-contract=off"],
     "fps_pruned.hip": ["-ffp-contract=off"],
@@ -63,8 +70,8 @@ def _supported(flags):
 def _tu_flags(name):
     flags = TU_FLAGS.get(name, [])
     if "-mllvm" in flags and not _supported(flags):
-        return []
-    return flags
+        flags = []
+    return flags + (MAIN_PRIO if name in MAIN_UNITS else [])
 
 
 def _sources():

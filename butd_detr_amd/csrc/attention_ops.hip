@@ -6,6 +6,14 @@
 //                        for dgamma/dbeta reduced per workgroup before touching global atomics.
 //
 #include <hip/hip_runtime.h>
+// (ablation hook, scratch/r6_prio.sh: -DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels -- the captured
+// step's prefetch branches share CUs with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -49,6 +57,7 @@ __global__ __launch_bounds__(kLnThreads) void ln_fwd_kernel(
     float *__restrict__ y, float *__restrict__ mean, float *__restrict__ rstd, float dropout_p,
     uint32_t site, const uint64_t *__restrict__ rng_counter, const float *__restrict__ pos,
     float *__restrict__ y_pos) {
+  BUTD_MAIN_PRIO_SET();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * (kLnThreads / 64) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -107,6 +116,7 @@ __global__ __launch_bounds__(kLnBwdThreads) void ln_bwd_kernel(
     float *__restrict__ d_residual, float *__restrict__ dgamma, float *__restrict__ dbeta,
     float dropout_p, uint32_t site, const uint64_t *__restrict__ rng_counter, int rows_per_wave,
     float *__restrict__ partials) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float red[2][kLnBwdThreads / 64][64 * PER];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const bool drop = dropout_p > 0.f;
@@ -562,6 +572,7 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_ke
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
     float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = Img<NS>;
   using T = TImg<NT>;
   // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
@@ -836,6 +847,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_kernel(
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
     float *__restrict__ dq, long ldo, float dq_scale,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = Img<NS>;
   using T = TImg<NT>;
   // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
@@ -1059,6 +1071,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_kernel(
     const float *__restrict__ lse, const float *__restrict__ delta, float *__restrict__ dk,
     float *__restrict__ dv, long ldo, float p_drop, uint32_t site,
     const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = Img<NS>;
   // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
   constexpr bool THIN = !BF && NT == 3 && NS == 9;
@@ -1312,6 +1325,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_bwd_smallk_kernel(
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
     float *__restrict__ dq, float *__restrict__ dk, float *__restrict__ dv, long ld_dq, long ld_dkv, float dq_scale,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = Img<NS>;
   // (head dimension 36: the third, 4-row tile of the transposed products as v_mfma_f32_4x4x1 -- see attn_bwd_longk_kernel)
   constexpr bool THIN = NT == 3 && NS == 9;
@@ -1614,6 +1628,7 @@ __global__ __launch_bounds__(kLongWaves * 64) void attn_bwd_longk_kernel(
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ dq_out, long ld_dq,
     long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, long kv_stride,
     int chunks, int q_tiles_per_wg, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = Img<NS>;
   // head dimension 36 = two full 16-row tiles + FOUR rows: the third tile of the dV / dK / dQ products as
   // v_mfma_f32_4x4x1 (16 independent 4 x 4 blocks; ~10 cycles where the 16 x 16 x 4 instruction takes ~34,
@@ -1906,6 +1921,7 @@ struct FoldArgs {
   long total;
 };
 __global__ __launch_bounds__(256) void attn_dq_fold_kernel(FoldArgs args) {
+  BUTD_MAIN_PRIO_SET();
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= args.total) return;
   int sgi = 0;
@@ -2106,6 +2122,7 @@ __global__ __launch_bounds__(kAttnThreads * NG, ATTN_FWD_WAVES) void attn_fwd_h_
     int H, int Lq, int Lk, int D, const float *__restrict__ q, const float *__restrict__ k,
     const float *__restrict__ v, const uint8_t *__restrict__ mask, float *__restrict__ out,
     float *__restrict__ lse, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = ImgH<NS>;
   using T = TImgH<NT>;
   constexpr int NL = SPLIT ? 2 : 1;              // images per operand: hi (| lo behind it)
@@ -2326,6 +2343,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dq_h_kernel(
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ delta,
     float *__restrict__ dq, long ldo, float dq_scale,
     float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = ImgH<NS>;
   using T = TImgH<NT>;
   constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD;
@@ -2493,6 +2511,7 @@ __global__ __launch_bounds__(kAttnThreads * NG) void attn_bwd_dkv_h_kernel(
     const float *__restrict__ lse, const float *__restrict__ delta, float *__restrict__ dk,
     float *__restrict__ dv, long ldo, float p_drop, uint32_t site,
     const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = ImgH<NS>;
   using T = TImgH<NT>;
   constexpr int kImg = 64 * I::LD, kTimg = T::ROWS * T::LD;
@@ -2696,6 +2715,7 @@ __global__ __launch_bounds__(kWaves * 64) void attn_bwd_longk_h_kernel(
     const float *__restrict__ dout, const float *__restrict__ lse, float *__restrict__ dq_out, long ld_dq,
     long chunk_stride, float dq_scale, float *__restrict__ dk, float *__restrict__ dv, long ldo, long kv_stride,
     int chunks, int q_tiles_per_wg, float p_drop, uint32_t site, const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   using I = ImgH<NS>;
   using T = TImgH<NT>;
   static_assert(kSub == 1 || kSub == 2, "one K = 32 contraction per wave (a single sub-tile leaves its upper half zero)");

@@ -7,6 +7,14 @@
 // Compiled with -ffp-contract=off: the cost tensor feeds an arg-min (the assignment), so its arithmetic
 // follows the reference's separate multiply / add launches.
 #include <hip/hip_runtime.h>
+// (-DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels: the captured step's prefetch branches share CUs
+// with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 
 #include "zero_fill.h"
 #include <math.h>
@@ -72,6 +80,7 @@ __global__ __launch_bounds__(256) void match_cost_kernel(int Q, int G, int B,
                                                          const float *__restrict__ class_cost, float w_bbox,
                                                          float w_class, float w_giou,
                                                          float *__restrict__ cost) {
+  BUTD_MAIN_PRIO_SET();
   const int row = blockIdx.x;  // (p*B + b)*G + g
   const int g = row % G;
   const int pb = row / G;
@@ -154,6 +163,7 @@ __global__ __launch_bounds__(256) void box_loss_kernel(int B, int Q, int G,
                                                        const float *__restrict__ tgt_boxes,
                                                        const int *__restrict__ match,
                                                        float *__restrict__ sums, float *__restrict__ grad) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float red[2][256 / kWave];
   const int p = blockIdx.x;
   float acc_l1 = 0.0f, acc_g = 0.0f;
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(256) void box_loss_bwd_kernel(int total, int B, int
                                                            const float *__restrict__ grad,
                                                            const float *__restrict__ w,
                                                            float *__restrict__ grad_pred) {
+  BUTD_MAIN_PRIO_SET();
   const int slot = blockIdx.x * 256 + threadIdx.x;  // (p*B + b)*G + g
   if (slot >= total) return;
   const int q = match[slot];
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(kWave * kRowsPerBlock) void soft_token_ce_kernel(
     int rows, int Q, int G, int C, const float *__restrict__ logits, const int *__restrict__ match,
     const float *__restrict__ positive_map, int ldpm, int B, float eos_coef, float *__restrict__ row_loss,
     float *__restrict__ dlogits) {
+  BUTD_MAIN_PRIO_SET();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -272,6 +284,7 @@ __global__ __launch_bounds__(kWave * kRowsPerBlock) void contrastive_rows_kernel
     int rows, int Q, int G, int L, int B, const float *__restrict__ logits, const int *__restrict__ match,
     const float *__restrict__ positive_map, int ldpm, const int *__restrict__ last, float eos_coef,
     float *__restrict__ row_loss, float *__restrict__ dlogits, int *__restrict__ owner) {
+  BUTD_MAIN_PRIO_SET();
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * kRowsPerBlock + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -316,6 +329,7 @@ __global__ __launch_bounds__(kColThreads) void contrastive_cols_kernel(
     int Q, int G, int L, int B, const float *__restrict__ logits, const int *__restrict__ owner,
     const float *__restrict__ positive_map, int ldpm, const int *__restrict__ last, float eos_coef,
     float *__restrict__ col_loss, float *__restrict__ dlogits) {
+  BUTD_MAIN_PRIO_SET();
   extern __shared__ float smem[];
   const int pb = blockIdx.x, b = pb % B;
   const int l_last = last[b];
@@ -387,6 +401,7 @@ __global__ __launch_bounds__(kWave) void objectness_label_kernel(
     int K, int G, int N, int topk, const float *__restrict__ seed_xyz, const int *__restrict__ seed_inds,
     const int64_t *__restrict__ pil, const float *__restrict__ gt_center, const float *__restrict__ gt_size,
     const float *__restrict__ box_mask, unsigned char *__restrict__ label) {
+  BUTD_MAIN_PRIO_SET();
   extern __shared__ float dist[];
   const int lane = threadIdx.x;
   const int bg = blockIdx.x, b = bg / G, g = bg % G;
@@ -441,6 +456,7 @@ __global__ __launch_bounds__(256) void objectness_focal_kernel(int total, int K,
                                                                unsigned char *__restrict__ label,
                                                                float *__restrict__ elem_loss,
                                                                float *__restrict__ dlogits) {
+  BUTD_MAIN_PRIO_SET();
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int b = i / K;
@@ -463,6 +479,7 @@ __global__ __launch_bounds__(256) void objectness_focal_kernel(int total, int K,
 __global__ void loss_combine_kernel(int P, const float *ce, const float *bbox, const float *giou, const float *align,
                                     const float *generation, const int *status_words, int nstatus, float w_gen,
                                     float w_sum, float w_bbox, float *out) {
+  BUTD_MAIN_PRIO_SET();
   if (threadIdx.x != 0) return;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   const float *src[4] = {ce, bbox, giou, align};
@@ -482,6 +499,7 @@ __global__ void loss_combine_kernel(int P, const float *ce, const float *bbox, c
 __global__ void loss_combine_bwd_kernel(int P, const float *g, const int *status_words, int nstatus, float w_gen,
                                         float w_sum, float w_bbox, float *d_ce, float *d_bbox, float *d_giou,
                                         float *d_align, float *d_generation) {
+  BUTD_MAIN_PRIO_SET();
   const int i = threadIdx.x;
   bool bad = false;
   for (int j = 0; j < nstatus; ++j) bad = bad || status_words[j] != 0;
@@ -517,6 +535,7 @@ __global__ __launch_bounds__(1024) void criterion_reduce_kernel(
     const float *__restrict__ gen_elem, long n_gen, float gen_div, const float *__restrict__ num_boxes,
     const int *__restrict__ status_words, int nstatus, float w_gen, float w_sum, float w_bbox,
     float *__restrict__ per_prefix, float *__restrict__ out6) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float red[16];
   const float inv_nb = 1.f / num_boxes[0];
   float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -563,6 +582,7 @@ __global__ __launch_bounds__(256) void criterion_scale_kernel(
     int nstatus, float w_gen, float w_sum, float w_bbox, float gen_div, const float *__restrict__ dx_ce,
     float *__restrict__ d_logits, long n_ce, const float *__restrict__ dx_al, float *__restrict__ d_align, long n_al,
     const float *__restrict__ dx_gen, float *__restrict__ d_seed, long n_gen, float *__restrict__ box_w) {
+  BUTD_MAIN_PRIO_SET();
   bool bad = false;
   for (int j = 0; j < nstatus; ++j) bad = bad || status_words[j] != 0;
   const float gv = bad ? 0.f : g[0];

@@ -21,6 +21,14 @@
 //     a block ...) in a 1-D grid; epilogues: bias / scale / ReLU / dropout, column sums (BatchNorm
 //     statistics), accumulation into existing tensors (c_add / c2), atomics for split-K.
 #include <hip/hip_runtime.h>
+// (ablation hook, scratch/r6_prio.sh: -DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels -- the captured
+// step's prefetch branches share CUs with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <stdio.h>
 #include <stdlib.h>
 #include <math.h>
@@ -248,6 +256,7 @@ struct Ragged { static constexpr bool ragged = true; };
 template <int TM, int TN, bool FAST, int PIPE, bool BF = false>
 __global__ __launch_bounds__(kThreads) void gemm_kernel(GemmBatch batch,
                                                         const uint64_t *__restrict__ rng_counter) {
+  BUTD_MAIN_PRIO_SET();
   constexpr int kMI = TM / 32, kNJ = TN / 32;   // 16 x 16 MFMA tiles per wave: rows, columns
   constexpr int kSubA = TM / 32, kSubB = TN / 32;   // float4 per thread, operand and slab
   constexpr int kWM = TM / 2, kWN = TN / 2;     // wave tile

@@ -10,6 +10,14 @@
 // there is one and the FIRST otherwise -- an order-free rule, evaluated with three DPP reductions.
 // All per-problem state lives in LDS; one wave = no barriers.
 #include <hip/hip_runtime.h>
+// (-DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels: the captured step's prefetch branches share CUs
+// with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <math.h>
 #include <stdint.h>
 
@@ -31,6 +39,7 @@ __device__ inline unsigned long long ordered_key64(double d) {
 __global__ __launch_bounds__(kWave) void lsap_kernel(int nq, int ng, const float *__restrict__ cost,
                                                      const unsigned char *__restrict__ valid,
                                                      int *__restrict__ match, int *__restrict__ status) {
+  BUTD_MAIN_PRIO_SET();
   extern __shared__ unsigned char smem_raw[];
   const int lane = threadIdx.x;
   const int p = blockIdx.x;

@@ -6,6 +6,14 @@
 // BatchNorm backward.  P is a few thousand rows (B x queries), C a few hundred channels: everything is
 // launch-latency bound, so each stage is ONE launch over all concatenated chains.
 #include <hip/hip_runtime.h>
+// (ablation hook, scratch/r6_prio.sh: -DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels -- the captured
+// step's prefetch branches share CUs with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <math.h>
 #include <stdint.h>
 
@@ -23,6 +31,7 @@ __global__ void mlp_bn_finalize_kernel(Segments segs, int Cseg, long count,
                                        float eps, float momentum, int training,
                                        float *__restrict__ mean, float *__restrict__ rstd,
                                        float *__restrict__ scale, float *__restrict__ shift) {
+  BUTD_MAIN_PRIO_SET();
   const butd_bn_segment &S = segs.s[blockIdx.y];
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && training && S.num_batches_tracked) *S.num_batches_tracked += 1;
@@ -59,6 +68,7 @@ __global__ __launch_bounds__(256) void mlp_mask_stats_kernel(
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, float drop_p, uint32_t site0, int seg_cols,
     const uint64_t *__restrict__ rng_counter, double *__restrict__ S1, double *__restrict__ S2) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float red[2][4][256];
   const int cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.y * 256 + cq * 4;
@@ -117,6 +127,7 @@ __global__ __launch_bounds__(256) void mlp_dz_kernel(long P, int C, long ld, flo
                                                      const double *__restrict__ S1,
                                                      const double *__restrict__ S2, int training,
                                                      float *__restrict__ S1f, float *__restrict__ S2f) {
+  BUTD_MAIN_PRIO_SET();
   const int cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.y * 256 + cq * 4;
   if (c >= C) return;
@@ -156,6 +167,7 @@ __global__ __launch_bounds__(256) void mlp_bn_relu_apply_kernel(long P, int C, l
                                                                 const float *__restrict__ scale,
                                                                 const float *__restrict__ shift,
                                                                 float *__restrict__ out) {
+  BUTD_MAIN_PRIO_SET();
   const int cq = threadIdx.x & 63, ph = threadIdx.x >> 6;
   const int c = blockIdx.y * 256 + cq * 4;
   if (c >= C) return;

@@ -1,5 +1,13 @@
 // optim_ops.hip -- flat AdamW update (include/butd_optim.h): one float4 stream over p, g, m, v.
 #include <hip/hip_runtime.h>
+// (-DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels: the captured step's prefetch branches share CUs
+// with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <stdint.h>
 #include <math.h>
 
@@ -12,6 +20,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, 
                                                          float eps, float wd, const float *__restrict__ step,
                                                          const float *__restrict__ grad_scale,
                                                          const float *__restrict__ hyper) {
+  BUTD_MAIN_PRIO_SET();
   if (hyper) {   // {lr, weight_decay} of this group, device-resident: a captured graph follows the scheduler
     lr = hyper[0];
     wd = hyper[1];
@@ -44,6 +53,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float *__restrict__ p, 
 // one workgroup = one 4096-float chunk of one segment (binary search over the segments' first workgroups)
 __global__ __launch_bounds__(256) void gather_segments_kernel(int n, const int64_t *__restrict__ table,
                                                               float *__restrict__ dst) {
+  BUTD_MAIN_PRIO_SET();
   const int64_t *src_ptr = table, *dst_off = table + n, *numel = table + 2 * n, *blk = table + 3 * n;
   int lo = 0, hi = n - 1;
   const long b = blockIdx.x;
@@ -78,6 +88,7 @@ __device__ inline double block_sum_256(double v, double *lds) {
 }
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float *__restrict__ g, long n,
                                                             double *__restrict__ partial) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ double lds[4];
   const long n4 = n >> 2;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;     // four independent fp32 chains per lane, folded in fp64
@@ -97,6 +108,7 @@ __global__ __launch_bounds__(256) void clip_finalize_kernel(const double *__rest
                                                             float max_norm, float grad_div,
                                                             float *__restrict__ grad_scale,
                                                             float *__restrict__ norm_out) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ double lds[4];
   double acc = 0.0;
   for (int i = threadIdx.x; i < blocks; i += 256) acc += partial[i];
@@ -155,6 +167,7 @@ extern "C" int butd_adamw_flat(float *p, const float *g, float *m, float *v, lon
 namespace {
 struct SumSrc { const float *p[8]; };
 __global__ __launch_bounds__(256) void sum_n_kernel(SumSrc src, int n, long n4, long numel, float *__restrict__ out) {
+  BUTD_MAIN_PRIO_SET();
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
     float4 a = reinterpret_cast<const float4 *>(src.p[0])[i];
     for (int k = 1; k < n; ++k) {

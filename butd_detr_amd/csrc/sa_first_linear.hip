@@ -23,6 +23,14 @@
 //   sa_first_linear_bwd_kernel     T and per-workgroup partials of dWx  (a 32-lane group walks one point's list)
 //   sa_first_linear_dwx_kernel     partials -> dWx (summed in double, fixed order: bit-reproducible)
 #include <hip/hip_runtime.h>
+// (-DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels: the captured step's prefetch branches share CUs
+// with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <stdint.h>
 
 #include "../../include/butd_sa.h"
@@ -40,6 +48,7 @@ __global__ __launch_bounds__(kThreads) void sa_first_linear_fwd_kernel(
     long P, int N, int np, int ns, const float *__restrict__ xyz, const float *__restrict__ new_xyz,
     const int *__restrict__ idx, float radius, int normalize, const float *__restrict__ Y, const float *__restrict__ W1,
     long ldw, float *__restrict__ Z1, double *__restrict__ sum, double *__restrict__ sumsq, int slots, long slot_stride) {
+  BUTD_MAIN_PRIO_SET();
   constexpr int QN = C1 / 4, RP = kThreads / QN;
   __shared__ float red[RP][2][C1];
   const int tid = threadIdx.x, q = tid % QN, rsub = tid / QN;
@@ -112,6 +121,7 @@ __global__ __launch_bounds__(kThreads) void sa_first_linear_bwd_kernel(
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, const double *__restrict__ S1, const double *__restrict__ S2, int training,
     float *__restrict__ T, float *__restrict__ ws) {
+  BUTD_MAIN_PRIO_SET();
   constexpr int QN = C1 / 4, RP = kThreads / QN;
   __shared__ float red[RP][3][C1];
   const int tid = threadIdx.x, q = tid % QN, rsub = tid / QN;
@@ -192,6 +202,7 @@ __global__ __launch_bounds__(kThreads) void sa_first_linear_bwd_kernel(
 // dWx[c, j] = sum over the workgroups' partials: one workgroup per element, a fixed tree in double (bit-reproducible)
 __global__ __launch_bounds__(256) void sa_first_linear_dwx_kernel(int C1, int parts, const float *__restrict__ ws,
                                                                   float *__restrict__ dWx, long ld) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ double red[256];
   const int i = blockIdx.x;            // j * C1 + c
   const int j = i / C1, c = i - j * C1;

@@ -14,6 +14,14 @@
 //            LDS slab, v_mfma_f32_16x16x4_f32 (exact fp32), outputs <= 128 columns per pass
 //   pool     max over the rows of a centre: registers -> lane groups (v_permlane swaps) -> the two row-halves
 #include <hip/hip_runtime.h>
+// (-DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels: the captured step's prefetch branches share CUs
+// with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <stdint.h>
 
 #include "../../include/butd_sa.h"
@@ -127,6 +135,7 @@ __device__ inline void layer(const float *ain, int lda, int K, const float *__re
 
 template <int ROWS>
 __global__ __launch_bounds__(kThreads) void sa_fused_eval_kernel(Args a) {
+  BUTD_MAIN_PRIO_SET();
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *reg0 = smem;                                  // X, later H2
   float *h1 = smem + a.region0;

@@ -22,6 +22,14 @@
 //   sa_last_reduce_kernel   partials -> double totals (deterministic: no atomics anywhere on this path)
 //   sa_last_dw_kernel       dW3 and the layer-2 sums
 #include <hip/hip_runtime.h>
+// (-DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels: the captured step's prefetch branches share CUs
+// with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <math.h>
 #include <stdint.h>
 
@@ -60,6 +68,7 @@ __global__ __launch_bounds__(NW * 64) void sa_last_fwd_kernel(
     const float *__restrict__ sh2, const float *__restrict__ W3, double *__restrict__ sum,
     double *__restrict__ sumsq, float *__restrict__ zmax, float *__restrict__ zmin, uint8_t *__restrict__ amax,
     uint8_t *__restrict__ amin, unsigned int *__restrict__ sched, int chunk) {
+  BUTD_MAIN_PRIO_SET();
   constexpr int NT = NW * 64;
   constexpr int ST = C2 + 36;
   constexpr int NTO = C3 / (16 * NW);    // 16-column output tiles per wave
@@ -224,6 +233,7 @@ __global__ __launch_bounds__(256) void sa_last_coeffs_kernel(int C2, long P, con
                                                              const double *__restrict__ S1,
                                                              const double *__restrict__ S2, float *__restrict__ An,
                                                              float *__restrict__ dvec) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float Wj[C3][17], Wk[C3][17];
   __shared__ double u[C3], v[C3];
   const double invP = 1.0 / (double)P;
@@ -261,6 +271,7 @@ template <int C2>
 __global__ __launch_bounds__(kThreads) void sa_last_mfma_kernel(
     long P, long nblk, const float *__restrict__ Z2, const float *__restrict__ sc2, const float *__restrict__ sh2,
     const float *__restrict__ An, const float *__restrict__ dvec, float *__restrict__ O, float *__restrict__ ws) {
+  BUTD_MAIN_PRIO_SET();
   constexpr int ST = C2 + 36;
   constexpr int NTO = C2 / 64;   // output-column tiles of 16 per wave
   constexpr int KG = C2 / 16;    // contraction groups of 16 channels
@@ -371,6 +382,7 @@ __global__ __launch_bounds__(NW * 64) void sa_last_sparse_kernel(
     const float *__restrict__ rstd2, const float *__restrict__ W3, const float *__restrict__ d_out,
     const float *__restrict__ zsel, const uint8_t *__restrict__ asel, const float *__restrict__ sc3,
     const float *__restrict__ sh3, float *__restrict__ ws, long ws_stride, int abl) {
+  BUTD_MAIN_PRIO_SET();
   constexpr int NT = NW * 64;
   constexpr int ST = C2 + 4;
   constexpr int CPW = C3 / NW;       // channels per wave (<= 64: one record per lane)
@@ -551,6 +563,7 @@ __global__ __launch_bounds__(NW * 64) void sa_last_fused_kernel(
     const float *__restrict__ dvec, const float *__restrict__ d_out, const float *__restrict__ zsel,
     const uint8_t *__restrict__ asel, const float *__restrict__ sc3, const float *__restrict__ sh3,
     float *__restrict__ ws_gram, float *__restrict__ ws, long ws_stride) {
+  BUTD_MAIN_PRIO_SET();
   static_assert(C2 == 16 * NW, "a wave owns 16 columns");
   constexpr int NT = NW * 64;
   constexpr int ST = C2 + 36;        // H tile (matrix operand reads, see sa_last_mfma_kernel)
@@ -765,6 +778,7 @@ __global__ __launch_bounds__(NW * 64) void sa_last_fused_kernel(
 __global__ __launch_bounds__(256) void sa_last_reduce_kernel(const float *__restrict__ p1, long n1, int parts1,
                                                              const float *__restrict__ p2, long n2, int parts2,
                                                              double *__restrict__ tot) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ double red[16][17];
   const long i = (long)blockIdx.x * 16 + (threadIdx.x & 15);
   const int pl = threadIdx.x >> 4;
@@ -804,6 +818,7 @@ __global__ void sa_last_dw_kernel(int C2, int C3, long P, const float *__restric
                                   const float *__restrict__ rstd3, const double *__restrict__ S1_3,
                                   const double *__restrict__ S2_3, const double *__restrict__ tot,
                                   float *__restrict__ dW3, double *__restrict__ S1_2, double *__restrict__ S2_2) {
+  BUTD_MAIN_PRIO_SET();
   const int c = blockIdx.x, k = threadIdx.x;
   const double *gram = tot, *T = tot + (long)C2 * C2, *s1 = T + (long)C3 * C2, *s2 = s1 + C2, *S = s2 + C2;
   const double invP = 1.0 / (double)P;
@@ -839,6 +854,7 @@ __global__ __launch_bounds__(kThreads) void sa_first_stats_kernel(
     long P, int C, const float *__restrict__ dH, const float *__restrict__ Z, const float *__restrict__ X,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, float *__restrict__ ws, long ws_stride) {
+  BUTD_MAIN_PRIO_SET();
   static_assert(KP == 8, "grouped xyz + colour, padded to 8 columns");
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [tpg][C][KP + 2] then the X sums
   const int c4n = C >> 2, tpg = kThreads / c4n;
@@ -914,6 +930,7 @@ template <int KP>
 __global__ void sa_first_dw_kernel(int C, long P, int ldw, const float *__restrict__ W1, const float *__restrict__ scale,
                                    const float *__restrict__ rstd, const double *__restrict__ tot,
                                    float *__restrict__ dW1, double *__restrict__ S1, double *__restrict__ S2) {
+  BUTD_MAIN_PRIO_SET();
   constexpr int W = KP + 2;
   const int c = blockIdx.x, k = threadIdx.x;
   const double *row = tot + (long)c * W, *SX = tot + (long)C * W, *XX = SX + KP;
@@ -943,6 +960,7 @@ __global__ void sa_first_dw_kernel(int C, long P, int ldw, const float *__restri
 // (sa_mid_first_kernel<RECOMP>) recomputes z1 the same way.  Replaces butd_sa_thin_conv (writes Z1), the layer-2 product
 // launch (reads it) and butd_sa_colstats (reads Z2 back): 1.1 GB -> 0.3 GB at SA1, B = 8.
 __global__ __launch_bounds__(256) void sa_x_moments_kernel(long P, const float *__restrict__ X, double *__restrict__ mom) {
+  BUTD_MAIN_PRIO_SET();
   // thread = (row lane t / 8, column k = t % 8): SX[k] and row k of XX over its rows; mom = [SX 8 | XX 64], zero on entry
   __shared__ float red[32][72];
   const int k = threadIdx.x & 7, rl = threadIdx.x >> 3;
@@ -968,6 +986,7 @@ __global__ __launch_bounds__(256) void sa_x_moments_kernel(long P, const float *
 
 __global__ void sa_l1_stats_kernel(int C, const float *__restrict__ W1, const double *__restrict__ mom,
                                    double *__restrict__ sum, double *__restrict__ sumsq) {
+  BUTD_MAIN_PRIO_SET();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s = 0.0, q = 0.0;
@@ -986,6 +1005,7 @@ __global__ __launch_bounds__(256) void sa_l12_fwd_kernel(long P, long nblk, cons
                                                          const float *__restrict__ sh1, const float *__restrict__ W2,
                                                          float *__restrict__ Z2, double *__restrict__ sum,
                                                          double *__restrict__ sumsq) {
+  BUTD_MAIN_PRIO_SET();
   static_assert(C == 64, "SA1");
   constexpr int KP = 8, ST = C + 36, SO = C + 4, KG = C / 16, QN = C / 4, RP = 256 / QN, NP = kRows / RP;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1090,6 +1110,7 @@ __global__ __launch_bounds__(256, 2) void sa_mid_first_kernel(
     const float *__restrict__ sh1, const float *__restrict__ mean1, const float *__restrict__ rstd1,
     const float *__restrict__ W2, const float *__restrict__ W1, float *__restrict__ ws_w, float *__restrict__ ws,
     long ws_stride) {
+  BUTD_MAIN_PRIO_SET();
   static_assert(C == 64, "SA1: 64-wide layers");
   constexpr int KP = 8;
   constexpr int ST = C + 36, SO = C + 4, KG = C / 16, GN = C / 16, QN = C / 4, RP = 256 / QN, NP = kRows / RP;
@@ -1310,6 +1331,7 @@ __global__ __launch_bounds__(512, 2) void sa_mid_wide_kernel(
     const double *__restrict__ S2_2, const float *__restrict__ sc1, const float *__restrict__ sh1,
     const float *__restrict__ mean1, const float *__restrict__ rstd1, const float *__restrict__ W2,
     float *__restrict__ G1, float *__restrict__ ws_w, float *__restrict__ ws) {
+  BUTD_MAIN_PRIO_SET();
   static_assert(C == 128, "SA2-4: 128-wide layers");
   constexpr int NT = 512;
   constexpr int ST = C + 36, SO = C + 4, KG = C / 16, GN = C / 16, QN = C / 4, RP = NT / QN, NP = kRowsW / RP;
@@ -1441,6 +1463,7 @@ __global__ __launch_bounds__(512, 2) void sa_mid_wide_kernel(
 // tot = [dW2 C*C | S1 C | S2 C] (double) -> dW2 (float), S1 / S2 (double: what butd_sa_dz_mid reads)
 __global__ void sa_mid_wide_finish_kernel(int C, const double *__restrict__ tot, float *__restrict__ dW2,
                                           double *__restrict__ S1, double *__restrict__ S2) {
+  BUTD_MAIN_PRIO_SET();
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x, nw = (long)C * C;
   if (i < nw) dW2[i] = (float)tot[i];
   else if (i < nw + C) S1[i - nw] = tot[i];
@@ -1448,6 +1471,7 @@ __global__ void sa_mid_wide_finish_kernel(int C, const double *__restrict__ tot,
 }
 
 __global__ void sa_d2f_kernel(const double *__restrict__ src, float *__restrict__ dst, long n) {
+  BUTD_MAIN_PRIO_SET();
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (float)src[i];
 }

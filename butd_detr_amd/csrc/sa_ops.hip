@@ -7,6 +7,14 @@
 // first-occurrence arg-max, and the element-wise halves of the backward.  All are HBM-streaming
 // kernels: coalesced float4 rows, one pass per tensor.
 #include <hip/hip_runtime.h>
+// (-DBUTD_MAIN_PRIO=n raises the wave priority of this unit's kernels: the captured step's prefetch branches share CUs
+// with them; profiles/r06_side_branches.txt)
+#ifdef BUTD_MAIN_PRIO
+#define BUTD_MAIN_PRIO_SET() __builtin_amdgcn_s_setprio(BUTD_MAIN_PRIO)
+#else
+#define BUTD_MAIN_PRIO_SET()
+#endif
+
 #include <stdlib.h>
 #include <math.h>
 #include <stdint.h>
@@ -26,6 +34,7 @@ __global__ __launch_bounds__(kThreads) void sa_group_kernel(int N, int np, int n
                                                             const int *__restrict__ idx, float radius,
                                                             int normalize, float *__restrict__ X,
                                                             int ldx, long total) {
+  BUTD_MAIN_PRIO_SET();
   const int Cin = 3 + C;
   for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
     const long p = e / ldx;
@@ -68,6 +77,7 @@ __global__ __launch_bounds__(kThreads) void sa_colstats_kernel(
     long P, int C, const float *__restrict__ Z, double *__restrict__ sum, double *__restrict__ sumsq,
     int pool_ns, float *__restrict__ zmax, float *__restrict__ zmin, uint8_t *__restrict__ amax,
     uint8_t *__restrict__ amin, int chunk) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float red[2][kThreads][4];
   const int c4n = C >> 2;                 // float4 columns (16, 32 or 64)
   const int tpg = kThreads / c4n;         // row phases (16, 8 or 4)
@@ -162,6 +172,7 @@ __global__ __launch_bounds__(kThreads) void sa_colstats_kernel(
 __global__ __launch_bounds__(kThreads) void sa_thin_conv_kernel(
     long P, int C, int K, const float *__restrict__ X, int ldx, const float *__restrict__ W,
     float *__restrict__ Z, double *__restrict__ sum, double *__restrict__ sumsq, int chunk) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float red[2][kThreads][4];
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
@@ -217,6 +228,7 @@ __global__ void sa_bn_finalize_kernel(int C, long count, const double *__restric
                                       float *__restrict__ running_var, int64_t *__restrict__ nbt,
                                       float *__restrict__ mean, float *__restrict__ rstd,
                                       float *__restrict__ scale, float *__restrict__ shift) {
+  BUTD_MAIN_PRIO_SET();
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c == 0 && training && nbt) *nbt += 1;
   if (c >= C) return;
@@ -251,6 +263,7 @@ __global__ __launch_bounds__(kThreads) void sa_pool_finalize_kernel(
     const uint8_t *__restrict__ amax, const uint8_t *__restrict__ amin, const float *__restrict__ scale,
     const float *__restrict__ shift, float *__restrict__ out_cm, float *__restrict__ out_pm,
     float *__restrict__ zsel, uint8_t *__restrict__ asel) {
+  BUTD_MAIN_PRIO_SET();
   const long e = (long)blockIdx.x * kThreads + threadIdx.x;  // over (g, c), c fastest
   if (e >= total) return;
   const int c = (int)(e % C);
@@ -272,6 +285,7 @@ __global__ __launch_bounds__(kThreads) void sa_pool_bwd_stats_kernel(
     int np, int C, long G, int groups_per_block, const float *__restrict__ d_out_pm, const float *__restrict__ zsel,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, double *__restrict__ S1, double *__restrict__ S2) {
+  BUTD_MAIN_PRIO_SET();
   // block = groups_per_block groups x all channels: thread t owns column (t % C), groups sub, sub+tpc, ...
   __shared__ float red[2][kThreads];
   const int tpc = kThreads / C;
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(kThreads) void sa_dz_last_kernel(
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, const double *__restrict__ S1, const double *__restrict__ S2,
     int training, int chunk) {
+  BUTD_MAIN_PRIO_SET();
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
   const long row0 = (long)blockIdx.x * chunk;
@@ -353,6 +368,7 @@ __global__ __launch_bounds__(kThreads) void sa_mask_stats_kernel(
     long P, int C, const float *__restrict__ dH, const float *__restrict__ Z,
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, double *__restrict__ S1, double *__restrict__ S2, int chunk) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ float red[2][kThreads][4];
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
@@ -401,6 +417,7 @@ __global__ __launch_bounds__(kThreads) void sa_dz_mid_kernel(
     const float *__restrict__ scale, const float *__restrict__ shift, const float *__restrict__ mean,
     const float *__restrict__ rstd, const double *__restrict__ S1, const double *__restrict__ S2,
     int training, int chunk) {
+  BUTD_MAIN_PRIO_SET();
   const int c4n = C >> 2, tpg = kThreads / c4n;
   const int cq = threadIdx.x % c4n, sub = threadIdx.x / c4n;
   const long row0 = (long)blockIdx.x * chunk;
@@ -435,6 +452,7 @@ __global__ __launch_bounds__(kThreads) void sa_scatter_rows_kernel(int N, int np
                                                                    const int *__restrict__ idx,
                                                                    float *__restrict__ d_feats,
                                                                    int ldx, long total) {
+  BUTD_MAIN_PRIO_SET();
   for (long e = (long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long)gridDim.x * kThreads) {
     const long p = e / C;
     const int c = (int)(e - p * C);
@@ -458,6 +476,7 @@ inline bool cols_ok(int C) { return C >= 16 && C <= kThreads && kThreads % C == 
 // row reads.
 __global__ __launch_bounds__(kThreads) void sa_inv_count_kernel(int N, long npns, long P, const int *__restrict__ idx,
                                                                 int *__restrict__ count) {
+  BUTD_MAIN_PRIO_SET();
   for (long p = (long)blockIdx.x * kThreads + threadIdx.x; p < P; p += (long)gridDim.x * kThreads)
     atomicAdd(count + (p / npns) * N + idx[p], 1);
 }
@@ -465,6 +484,7 @@ __global__ __launch_bounds__(kThreads) void sa_inv_count_kernel(int N, long npns
 // one workgroup per batch element: start[b*N + i] = b*npns + exclusive prefix of count; count is zeroed (the fill's cursor)
 __global__ __launch_bounds__(1024) void sa_inv_scan_kernel(int N, long npns, int *__restrict__ count, int *__restrict__ start,
                                                            int last_batch) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ int part[1024];
   const int b = blockIdx.x, t = threadIdx.x;
   const int per = (N + 1023) / 1024, i0 = t * per, i1 = min(N, i0 + per);
@@ -491,6 +511,7 @@ __global__ __launch_bounds__(1024) void sa_inv_scan_kernel(int N, long npns, int
 __global__ __launch_bounds__(kThreads) void sa_inv_fill_kernel(int N, long npns, long P, const int *__restrict__ idx,
                                                                int *__restrict__ cursor, const int *__restrict__ start,
                                                                int *__restrict__ list) {
+  BUTD_MAIN_PRIO_SET();
   for (long p = (long)blockIdx.x * kThreads + threadIdx.x; p < P; p += (long)gridDim.x * kThreads) {
     const long i = (p / npns) * N + idx[p];
     list[start[i] + atomicAdd(cursor + i, 1)] = (int)p;
@@ -502,6 +523,7 @@ __global__ __launch_bounds__(kThreads) void sa_inv_fill_kernel(int N, long npns,
 // of the gather's sums, are then the same on every run.  (First version: one THREAD per slice -- 0.3 ms per level on the
 // prefetch stream from the imbalance of a few long slices.)
 __global__ __launch_bounds__(64) void sa_inv_sort_kernel(long R, const int *__restrict__ start, int *__restrict__ list) {
+  BUTD_MAIN_PRIO_SET();
   __shared__ int buf[1024];
   const long r = blockIdx.x;
   if (r >= R) return;
@@ -548,6 +570,7 @@ __global__ __launch_bounds__(kThreads) void sa_gather_rows_kernel(long R, int C,
                                                                   const int *__restrict__ start,
                                                                   const int *__restrict__ list,
                                                                   float *__restrict__ d_feats) {
+  BUTD_MAIN_PRIO_SET();
   const int c = threadIdx.x % C;
   const long r = (long)blockIdx.x * (kThreads / C) + threadIdx.x / C;
   if (r >= R) return;

@@ -917,6 +917,9 @@ class GraphedTrainStep:
     def _own_stream(self, name, dev=None):
         """The step's streams are its own HIP streams, one per role and shared by all captured signatures -- never members
         of torch's pool of 32, which RCCL's stream is drawn from as well (graph_audit.own_stream)."""
+        # (LOW-priority streams for the prefetch branches were measured in round 6: 26.1 instead of 20.5 ms per step -- a graph
+        # with nodes of another priority leaves the runtime's fast path, as round 4 saw for a high-priority launch stream;
+        # profiles/r06_side_branches.txt)
         from . import graph_audit
         return graph_audit.own_stream(dev, role="step." + name, owner=self)
 

@@ -10,7 +10,7 @@ args = argparse.Namespace(backend="auto", queries=256, points=50000, tokens=80, 
 batches = [synthetic_batch(8, dev, seed=1184 + 50 * i, n_points=50000, tokens=80) for i in range(4)]
 
 
-def run(skip_fps, skip_text, reps=30, prio=None):
+def run(skip_fps, skip_text, reps=30, prio=None, variant=None):
     if prio is not None:
         st = torch.cuda.Stream(dev, priority=prio)
         with torch.cuda.stream(st):
@@ -19,6 +19,25 @@ def run(skip_fps, skip_text, reps=30, prio=None):
     step = GraphedTrainStep(model, FlatAdamW(model), criterion=HungarianCriterion())
     o_s, o_t = step._sample_into_next, step._encode_text_into_next
     step._sample_into_next = lambda: None if (skip_fps and torch.cuda.is_current_stream_capturing()) else o_s()
+    if variant == "fps1only":      # the branch holds ONLY the first level's sampling (3.4 ms on 8 CUs, 5 launches)
+        from butd_detr_amd import pointnet2_utils as pu
+        def only_fps1():
+            if not torch.cuda.is_current_stream_capturing():
+                return o_s()
+            keep.append(pu.furthest_point_sample(step._slot.next_pc[..., 0:3].contiguous(), 2048))
+        keep = []
+        step._sample_into_next = only_fps1
+    if variant == "nofps1":        # everything of the branch EXCEPT the first level's sampling (its ~150 small launches)
+        from butd_detr_amd import pointnet2_utils as pu
+        real, cache = pu.furthest_point_sample, {}
+        def fps(xyz, m):
+            if m == 2048 and torch.cuda.is_current_stream_capturing() and "i" in cache:
+                return cache["i"]
+            out = real(xyz, m)
+            if m == 2048:
+                cache["i"] = out
+            return out
+        pu.furthest_point_sample = fps
     step._encode_text_into_next = lambda: None if (skip_text and torch.cuda.is_current_stream_capturing()) else o_t()
     for it in range(5):
         step(batches[it % 4][0], batches[it % 4][1], next_inputs=batches[(it + 1) % 4][0])
@@ -40,3 +59,15 @@ elif mode == "lo":
     print(f"both on, issued on a NEW priority 0 stream: {run(False, False, prio=0):.3f} ms / step")
 elif mode == "none":
     print(f"both off: {run(True, True):.3f} ms / step")
+elif mode == "fps1only":
+    print(f"branch = level-1 sampling only, RoBERTa off: {run(False, True, reps=60, variant='fps1only'):.3f} ms / step")
+elif mode == "nofps1":
+    print(f"branch = plan without level-1 sampling, RoBERTa off: {run(False, True, reps=60, variant='nofps1'):.3f} ms / step")
+elif mode == "nofps":
+    print(f"FPS chain off, RoBERTa on: {run(True, False, reps=60):.3f} ms / step")
+elif mode == "notext":
+    print(f"FPS chain on, RoBERTa off: {run(False, True, reps=60):.3f} ms / step")
+elif mode == "base60":
+    print(f"both on: {run(False, False, reps=60):.3f} ms / step")
+elif mode == "none60":
+    print(f"both off: {run(True, True, reps=60):.3f} ms / step")
