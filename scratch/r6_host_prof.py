@@ -28,7 +28,17 @@ for it in range(6):
     step(batches[it % 4][0], batches[it % 4][1], next_inputs=batches[(it + 1) % 4][0])
 torch.cuda.synchronize()
 wrap(step, "_tokenize", "tokenize"); wrap(crit, "prepare", "criterion.prepare"); wrap(step, "_copy_in", "copy_in")
-wrap(opt, "sync_hyper", "sync_hyper"); wrap(torch.cuda.CUDAGraph, "replay", "graph replays")
+wrap(opt, "sync_hyper", "sync_hyper")
+sl = step._slot
+for nm in ("g_fwd_bwd", "g_update"):
+    g = getattr(sl, nm)
+    orig = g.replay
+    class _W:
+        def __init__(self, g, tag): self.g, self.tag = g, tag
+        def replay(self):
+            t = time.perf_counter(); self.g.replay(); acc[self.tag] += time.perf_counter() - t
+        def __getattr__(self, k): return getattr(self.g, k)
+    setattr(sl, nm, _W(g, "replay " + nm))
 wrap(step, "_exchange_whole", "exchange")
 reps = 40
 t0 = time.perf_counter()
