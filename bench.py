@@ -365,10 +365,10 @@ def attention_roofline(batch, reps=10, bf16=False):
 
 
 def _pmc_traffic(kernel, with_source=False):
-    """HBM bytes per launch from the newest committed PMC profile (profiles/r05_pmc.json, else r04 / r03 / r02), or None.
+    """HBM bytes per launch from the newest committed PMC profile (profiles/r06_pmc.json, else r05 / r04 / r03 / r02), or None.
     NOT measured in this run: the counters need their own rocprofv3 --pmc passes (scratch/pmc.sh); ``traffic_source``
     in the record names the file."""
-    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name))).get(kernel, {}).get("hbm_bytes_per_launch")
         except Exception:
