@@ -101,6 +101,9 @@ class HungarianCriterion:
     def prepare(self, targets):
         if "num_boxes" in targets:          # already prepared (e.g. a rank-local replay of a batch)
             return targets
+        from .losses import is_dist_avail_and_initialized
+        if not is_dist_avail_and_initialized():
+            return targets                  # no collective to keep outside the graph: the criterion counts the boxes itself
         targets = dict(targets)
         targets["num_boxes"] = self.set_criterion.num_boxes(targets["box_label_mask"] > 0)
         return targets
@@ -772,41 +775,53 @@ class GraphedTrainStep:
         eagerly between two steps is time the GPU idles (0.39 ms per step before this, profiles/r06_side_branches.txt).
         Pairs that are not 4-byte granular, not contiguous or not resident on the device take ``copy_``."""
         fast, dev = [], None
+        capturing = torch.cuda.is_current_stream_capturing()
         for dst, src in pairs:
-            ok = (dst.is_cuda and src.is_cuda and src.device == dst.device and src.dtype == dst.dtype
-                  and src.shape == dst.shape and src.is_contiguous() and dst.is_contiguous()
-                  and (src.numel() * src.element_size()) % 4 == 0 and src.data_ptr() % 4 == 0 and dst.data_ptr() % 4 == 0
-                  and src.numel() > 0)
-            if ok and not torch.cuda.is_current_stream_capturing():
+            ok = (not capturing and dst.is_cuda and src.is_cuda and src.dtype == dst.dtype and src.shape == dst.shape
+                  and src.device == dst.device and src.is_contiguous() and dst.is_contiguous() and src.numel() > 0
+                  and (src.numel() * src.element_size()) % 4 == 0 and src.data_ptr() % 4 == 0 and dst.data_ptr() % 4 == 0)
+            if ok:
                 fast.append((dst, src))
                 dev = dst.device
             else:
                 dst.copy_(src, non_blocking=True)
         if not fast:
             return
+        import numpy as np
         from . import _hiplib
         n, chunk = len(fast), FlatGradients.GATHER_CHUNK
         ring = getattr(self, "_copy_ring", None)
         if ring is None or ring["n"] < n:
             cap = max(32, 2 * n)
-            ring = self._copy_ring = {"n": cap, "i": 0, "slots": [
-                [torch.empty(4 * cap + 1, dtype=torch.int64).pin_memory(), torch.empty(4 * cap + 1, dtype=torch.int64, device=dev),
-                 torch.cuda.Event()] for _ in range(self._COPY_RING)]}
-        host, table, done = ring["slots"][ring["i"] % self._COPY_RING]
+            ring = self._copy_ring = {"n": cap, "i": 0, "static": {}, "slots": []}
+            for _ in range(self._COPY_RING):
+                host = torch.empty(4 * cap + 1, dtype=torch.int64).pin_memory()
+                ring["slots"].append([host, host.numpy(), torch.empty(4 * cap + 1, dtype=torch.int64, device=dev),
+                                      torch.cuda.Event()])
+        # the destinations are a slot's static buffers: offsets / sizes / workgroup ranges are computed once per set
+        dkey = tuple(d.data_ptr() for d, _ in fast) + tuple(d.numel() * d.element_size() for d, _ in fast)
+        st = ring["static"].get(dkey)
+        if st is None:
+            base = min(d.data_ptr() for d, _ in fast)
+            words = [d.numel() * d.element_size() // 4 for d, _ in fast]
+            blk = [0]
+            for w in words:
+                blk.append(blk[-1] + (w + chunk - 1) // chunk)
+            if len(ring["static"]) >= 64:
+                ring["static"].clear()
+            st = ring["static"][dkey] = (base, np.array([(d.data_ptr() - base) // 4 for d, _ in fast] + words + blk,
+                                                        dtype=np.int64), blk[-1])
+        base, tail, total = st
+        host, host_np, table, done = ring["slots"][ring["i"] % self._COPY_RING]
         ring["i"] += 1
         done.synchronize()                                   # (the upload that last read this pinned table: long finished)
-        base = min(d.data_ptr() for d, _ in fast)
-        words = [d.numel() * d.element_size() // 4 for d, _ in fast]
-        blk = [0]
-        for w in words:
-            blk.append(blk[-1] + (w + chunk - 1) // chunk)
-        host[:4 * n + 1].copy_(torch.tensor([x.data_ptr() for _, x in fast] + [(d.data_ptr() - base) // 4 for d, _ in fast]
-                                            + words + blk, dtype=torch.int64))
+        host_np[:n] = [x.data_ptr() for _, x in fast]
+        host_np[n:4 * n + 1] = tail
         stream = torch.cuda.current_stream(dev)
         table[:4 * n + 1].copy_(host[:4 * n + 1], non_blocking=True)
         done.record(stream)
         with torch.cuda.device(dev):
-            err = _hiplib.load().butd_gather_segments(n, table.data_ptr(), base, stream.cuda_stream, blk[-1])
+            err = _hiplib.load().butd_gather_segments(n, table.data_ptr(), base, stream.cuda_stream, total)
         _hiplib.check(err, "butd_gather_segments")
 
     # -- warm-up steps must not train
@@ -986,29 +1001,29 @@ class GraphedTrainStep:
         # (the tokeniser is a pure function of the utterances: a batch seen before -- every epoch revisits the same
         # utterances -- costs a dictionary look-up instead of 0.2 ms of host time in front of the step's graph launch)
         memo = self.__dict__.setdefault("_tok_memo", {})
-        key = tuple(inputs["text"])
-        host = memo.get(key)
-        if host is None:
+        key = (dev.index,) + tuple(inputs["text"])
+        out = memo.get(key)
+        if out is None:
             host = module.tokenizer.batch_encode_plus(inputs["text"], padding="longest", return_tensors="pt")
+            up = self._upload_stream(dev)
+            self._up_done.synchronize()                  # the previous upload has left its staging buffers
+            out = {}
+            with torch.cuda.stream(up):
+                for k, v in host.items():
+                    pk = (k, tuple(v.shape), v.dtype)
+                    pin = self._up_pinned.get(pk)
+                    if pin is None:
+                        pin = self._up_pinned[pk] = torch.empty_like(v).pin_memory()
+                    pin.copy_(v)
+                    out[k] = pin.to(dev, non_blocking=True)
+                self._up_done.record(up)
+            main = torch.cuda.current_stream(dev)
+            main.wait_event(self._up_done)
+            for v in out.values():
+                v.record_stream(main)
             if len(memo) >= 4096:
                 memo.pop(next(iter(memo)))
-            memo[key] = host
-        up = self._upload_stream(dev)
-        self._up_done.synchronize()                  # the previous upload has left its staging buffers
-        out = {}
-        with torch.cuda.stream(up):
-            for k, v in host.items():
-                key = (k, tuple(v.shape), v.dtype)
-                pin = self._up_pinned.get(key)
-                if pin is None:
-                    pin = self._up_pinned[key] = torch.empty_like(v).pin_memory()
-                pin.copy_(v)
-                out[k] = pin.to(dev, non_blocking=True)
-            self._up_done.record(up)
-        main = torch.cuda.current_stream(dev)
-        main.wait_event(self._up_done)
-        for v in out.values():
-            v.record_stream(main)
+            memo[key] = out          # (the ids stay resident: 8 x 80 int64 x 2 per batch of utterances)
         return self._pad_tokens(BatchEncoding(out))
 
     def __call__(self, inputs, targets, next_inputs=None):
