@@ -73,6 +73,18 @@ def bdetr_inputs():
             "det_class_ids": torch.from_numpy(cls)}
 
 
+def bdetr_bench_inputs():
+    """Two scenes at the bench's size: 50 000 ScanNet-shaped points each, 132 box slots, utterances of the text stub."""
+    from butd_detr_amd.synthetic_scenes import detected_boxes, scene_batch
+    pc = torch.from_numpy(np.ascontiguousarray(scene_batch(2, 4242, 50000)))
+    boxes, mask, cls = detected_boxes(2, seed=7, min_valid=20, max_valid=90)
+    return {"point_clouds": pc,
+            "text": ["the office chair between the desk and the window that faces the door",
+                     "find the trash can under the table next to the whiteboard"],
+            "det_boxes": torch.from_numpy(boxes), "det_bbox_label_mask": torch.from_numpy(mask),
+            "det_class_ids": torch.from_numpy(cls)}
+
+
 # ---- train-mode BeaUTyDETR golden (bdetr_4096_train6.npz): shared by make_golden.py and the tests ----
 TRAIN_GRAD_KEYS = (
     "backbone_net.sa1.mlp_module.layer0.conv.weight", "backbone_net.fp2.mlp.layer1.conv.weight",

@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
 from golden import text_stub, weights  # noqa: E402
-from golden.cases import (PREFIXES, TRAIN_GRAD_KEYS, backbone_inputs, bdetr_inputs, by_seed,  # noqa: E402
+from golden.cases import (PREFIXES, TRAIN_GRAD_KEYS, backbone_inputs, bdetr_bench_inputs, bdetr_inputs, by_seed,  # noqa: E402
                           decoder_bench_inputs, decoder_inputs, encoder_inputs, probe, train_loss, zero_dropout)
 
 
@@ -180,6 +180,41 @@ def golden_bdetr(bdetr):
     npz("bdetr_4096_eval.npz", **out)
 
 
+def golden_bdetr_bench_shape(bdetr):
+    """The reference model at the bench's size -- 2 scenes x 50 000 points, 256 queries, 3 encoder + 6 decoder layers --
+    in eval mode: the sampled indices of levels 1 and 2, the centres of level 4, the query seeds (the tests hand them
+    back as ``inputs["query_seed_inds"]``: two objectness logits within rounding distance may otherwise swap a seed in or
+    out of the top 256), and every prefix's outputs.  Index ops: the CPU oracle (ext_adapter), as in every golden."""
+    tok, txt = text_stub.factory()
+    bdetr.RobertaTokenizerFast = types.SimpleNamespace(from_pretrained=lambda *_a, **_k: tok)
+    bdetr.RobertaModel = types.SimpleNamespace(from_pretrained=lambda *_a, **_k: txt)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        model = bdetr.BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3,
+                                 num_queries=256, num_decoder_layers=6,
+                                 self_position_embedding="loc_learned", contrastive_align_loss=True,
+                                 butd=True, pointnet_ckpt=None, self_attend=True)
+    finally:
+        os.chdir(cwd)
+    weights.fill_(model, seed=17, skip_prefixes=("text_encoder.",))
+    model.eval()
+    with torch.no_grad():
+        ep = model(bdetr_bench_inputs())
+    out = {"sa1_inds_head": ep["sa1_inds"][:, :256], "sa1_inds_sum": ep["sa1_inds"].long().sum(1),
+           "sa2_inds": ep["sa2_inds"], "sa4_xyz": ep["sa4_xyz"], "seed_inds": ep["seed_inds"],
+           "query_points_sample_inds": ep["query_points_sample_inds"],
+           "seeds_obj_cls_logits": ep["seeds_obj_cls_logits"], "proj_tokens": ep["proj_tokens"],
+           "text_memory": ep["text_memory"], "seed_features_b0_rows4": ep["seed_features"][0][::4]}
+    for pre in PREFIXES:
+        out[pre + "center"] = ep[pre + "center"]
+        out[pre + "pred_size"] = ep[pre + "pred_size"]
+    out["last_sem_cls_scores_head"] = ep["last_sem_cls_scores"][:, :, :48]
+    out["last_proj_queries"] = ep["last_proj_queries"]
+    out["2head_proj_queries"] = ep["2head_proj_queries"]
+    npz("bdetr_50k_eval.npz", **out)
+
+
 def golden_bdetr_train(bdetr):
     """BeaUTyDETR in TRAIN mode (BatchNorm batch statistics, dropout p = 0), all 6 decoder layers,
     forward + gradients -- the config-2 architecture on a 4096-point cloud."""
@@ -218,15 +253,63 @@ def golden_bdetr_train(bdetr):
     npz("bdetr_4096_train6.npz", **out)
 
 
+def golden_bdetr_bench_shape_train(bdetr):
+    """The reference model at the bench's size in TRAIN mode (BatchNorm batch statistics, dropout p = 0): 2 scenes x 50 000
+    points, 256 queries, 3 + 6 layers, forward + backward of tests.golden.cases.train_loss -- the set-abstraction levels at
+    their real row counts (2 x 2048 x 64 ... groups), every attention site at its real length.  Per-query tensors by seed;
+    large tensors stored as every 4th / 3rd row."""
+    tok, txt = text_stub.factory()
+    bdetr.RobertaTokenizerFast = types.SimpleNamespace(from_pretrained=lambda *_a, **_k: tok)
+    bdetr.RobertaModel = types.SimpleNamespace(from_pretrained=lambda *_a, **_k: txt)
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        model = bdetr.BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3,
+                                 num_queries=256, num_decoder_layers=6,
+                                 self_position_embedding="loc_learned", contrastive_align_loss=True,
+                                 butd=True, pointnet_ckpt=None, self_attend=True)
+    finally:
+        os.chdir(cwd)
+    weights.fill_(model, seed=18, skip_prefixes=("text_encoder.",))
+    model.train()
+    zero_dropout(model)
+    ep = model(bdetr_bench_inputs())
+    train_loss(ep).backward()
+    out = {"seed_inds": ep["seed_inds"],
+           "query_seeds_sorted": torch.sort(ep["query_points_sample_inds"].long(), dim=1)[0],
+           "seeds_obj_cls_logits": ep["seeds_obj_cls_logits"], "proj_tokens": ep["proj_tokens"],
+           "seed_features_b0_rows4": ep["seed_features"][0][::4]}
+    for pre in PREFIXES:
+        out[pre + "center"] = by_seed(ep, ep[pre + "center"])
+        out[pre + "pred_size"] = by_seed(ep, ep[pre + "pred_size"])
+    out["last_sem_cls_scores_head"] = by_seed(ep, ep["last_sem_cls_scores"])[:, :, :32]
+    out["last_proj_queries"] = by_seed(ep, ep["last_proj_queries"])
+    p = dict(model.named_parameters())
+    assert not [n for n, q in p.items() if q.requires_grad and q.grad is None]
+    for k in TRAIN_GRAD_KEYS:
+        gk = p[k].grad
+        out["g_" + k] = gk[::3] if gk.dim() == 2 and gk.shape[0] >= 864 else gk
+    out["running_mean_sa2_l1"] = model.backbone_net.sa2.mlp_module.layer1.bn.bn.running_mean
+    npz("bdetr_50k_train.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     enc_m, bb_m, bdetr_m = load_reference()
     if sys.argv[1:] == ["decoder_bench_shape"]:       # (one case alone: the others are unchanged)
         golden_decoder_bench_shape(enc_m)
         sys.exit(0)
+    if sys.argv[1:] == ["bdetr_bench_shape"]:
+        golden_bdetr_bench_shape(bdetr_m)
+        sys.exit(0)
+    if sys.argv[1:] == ["bdetr_bench_shape_train"]:
+        golden_bdetr_bench_shape_train(bdetr_m)
+        sys.exit(0)
     golden_encoder(enc_m)
     golden_decoder(enc_m)
     golden_decoder_bench_shape(enc_m)
     golden_backbone(bb_m)
     golden_bdetr(bdetr_m)
+    golden_bdetr_bench_shape(bdetr_m)
     golden_bdetr_train(bdetr_m)
+    golden_bdetr_bench_shape_train(bdetr_m)
