@@ -194,3 +194,32 @@ def test_bdetr_train_mode_six_decoder_layers_matches_reference_golden(cpu_ops):
     ep = model(bdetr_inputs())
     train_loss(ep).backward()
     _check_train6(ep, model, g, close, grad_close)
+
+
+def test_bdetr_at_the_bench_size_matches_reference_golden(cpu_ops):
+    """The host-side mirror at the bench's size (2 scenes x 50 000 points, 256 queries, 3 + 6 layers, eval mode) on the
+    CPU with the oracle's index ops, against the reference's vectors (bdetr_50k_eval.npz): what the GPU test of the same
+    name checks for the HIP path, here for the module code alone."""
+    import warnings
+    from butd_detr_amd.bdetr import BeaUTyDETR
+    from tests.golden.cases import PREFIXES, bdetr_bench_inputs
+    g = load("bdetr_50k_eval.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = BeaUTyDETR(num_class=256, num_obj_class=485, input_feature_dim=3, num_queries=256,
+                           num_decoder_layers=6, self_position_embedding="loc_learned",
+                           contrastive_align_loss=True, butd=True, pointnet_ckpt=None, self_attend=True,
+                           text_encoder_factory=text_stub.factory,
+                           class_embeddings_path="/nonexistent/class_embeddings3d.npy")
+    weights.fill_(model, seed=17, skip_prefixes=("text_encoder.",))
+    model.eval()
+    with torch.no_grad():
+        ep = model(bdetr_bench_inputs())
+    for k in ("sa2_inds", "seed_inds", "query_points_sample_inds"):
+        np.testing.assert_array_equal(ep[k].cpu().numpy(), g[k])
+    np.testing.assert_array_equal(ep["sa1_inds"][:, :256].cpu().numpy(), g["sa1_inds_head"])
+    for pre in PREFIXES:
+        close(ep[pre + "center"], g[pre + "center"])
+        close(ep[pre + "pred_size"], g[pre + "pred_size"])
+    close(ep["last_proj_queries"], g["last_proj_queries"])
+    close(ep["seeds_obj_cls_logits"], g["seeds_obj_cls_logits"])
