@@ -73,14 +73,23 @@ def bdetr_inputs():
             "det_class_ids": torch.from_numpy(cls)}
 
 
-def bdetr_bench_inputs():
-    """Two scenes at the bench's size: 50 000 ScanNet-shaped points each, 132 box slots, utterances of the text stub."""
+_BENCH_TEXTS = ["the office chair between the desk and the window that faces the door",
+                "find the trash can under the table next to the whiteboard",
+                "the brown wooden cabinet left of the sink",
+                "a monitor on the second desk from the entrance",
+                "the couch facing the television",
+                "it is the lamp standing in the corner behind the armchair",
+                "the smaller of the two bookshelves near the bed",
+                "select the door that is closest to the refrigerator"]
+
+
+def bdetr_bench_inputs(batch=2):
+    """``batch`` scenes at the bench's size: 50 000 ScanNet-shaped points each, 132 box slots, utterances of the text stub
+    (2: the eval golden; 8: the train golden -- the bench's own batch, so every kernel takes the plan it takes there)."""
     from butd_detr_amd.synthetic_scenes import detected_boxes, scene_batch
-    pc = torch.from_numpy(np.ascontiguousarray(scene_batch(2, 4242, 50000)))
-    boxes, mask, cls = detected_boxes(2, seed=7, min_valid=20, max_valid=90)
-    return {"point_clouds": pc,
-            "text": ["the office chair between the desk and the window that faces the door",
-                     "find the trash can under the table next to the whiteboard"],
+    pc = torch.from_numpy(np.ascontiguousarray(scene_batch(batch, 4242, 50000)))
+    boxes, mask, cls = detected_boxes(batch, seed=7, min_valid=20, max_valid=90)
+    return {"point_clouds": pc, "text": list(_BENCH_TEXTS[:batch]),
             "det_boxes": torch.from_numpy(boxes), "det_bbox_label_mask": torch.from_numpy(mask),
             "det_class_ids": torch.from_numpy(cls)}
 

@@ -28,10 +28,11 @@ GRAD_TOL = 2e-5         # encoder, decoder layer: gradients
 BACKBONE_EVAL_GRAD_TOL = 1.5e-3
 TRAIN_OUT_TOL = 1e-4    # train-mode backbone outputs (batch statistics reduced in another order than the CPU reference)
 TRAIN6_OUT_TOL = 5e-4   # train-mode 3 + 6-layer model outputs
-# train-mode model at the bench's size (bdetr_50k_train.npz), observed on MI355X (profiles/r06_golden_errors.json): outputs
-# 4.1e-5 (fused) / 8.7e-5 (stock ops) of scale; the 14 gradient tensors 2.6e-2 / 2.0e-2 max (single ReLU-gate / max-pool flips:
-# the tensor with the largest maximum has a mean of 2e-5), worst mean 2.0e-3 / 1.9e-3 -- the two backends are as far from the
-# reference as from each other.  Bounds ~2x the observations.
+# train-mode model at the bench's size and batch (bdetr_50k_train.npz, 8 scenes), observed on MI355X
+# (profiles/r06_golden_errors_bench_size_train.json): outputs 1.1e-5 (fused) / 1.5e-5 (stock ops) of scale; the 14 gradient tensors
+# 1.1e-2 / 1.8e-2 max, worst mean 3.4e-3 / 3.5e-3 (with 2 scenes: 4.1e-5 / 8.7e-5, 2.6e-2 / 2.0e-2 max -- single ReLU-gate /
+# max-pool flips: that tensor's mean was 2e-5 --, 2.0e-3 / 1.9e-3): the two backends are as far from the reference as from each
+# other.  Bounds: 1.5-4x the observations.
 BENCH_TRAIN_OUT_TOL, BENCH_TRAIN_GRAD_MAX, BENCH_TRAIN_GRAD_MEAN = 2e-4, 5e-2, 5e-3
 
 _OBSERVED = []      # (test, max error, bound, share beyond the bound): written to gpurun_out/golden_errors.json
@@ -367,11 +368,11 @@ def test_bdetr_train_six_layers_golden(backend):
 
 
 def test_bdetr_train_golden_at_the_bench_size(backend):
-    """The REFERENCE model in TRAIN mode at the bench's size (2 scenes x 50 000 points, 256 queries, 3 + 6 layers, dropout 0;
+    """The REFERENCE model in TRAIN mode at the bench's size and batch (8 scenes x 50 000 points, 256 queries, 3 + 6 layers, dropout 0;
     golden_bdetr_bench_shape_train): forward + backward through the set-abstraction levels at their real row counts (the
     linearity paths of csrc/sa_last_bwd.hip / sa_first_linear.hip, the 10^5-row products) and every attention site at its
-    real length, against the reference's own outputs and gradients -- the full-size complement of the 4096-point train6
-    golden.  The reference's query seeds are handed back; per-query tensors are compared by seed."""
+    real length and batch (so every kernel takes the plan it takes in the bench), against the reference's own outputs and
+    gradients -- the full-size complement of the 4096-point train6 golden.  The reference's query seeds are handed back; per-query tensors are compared by seed."""
     import warnings
     from butd_detr_amd.bdetr import BeaUTyDETR
     from tests.golden.cases import PREFIXES, TRAIN_GRAD_KEYS, bdetr_bench_inputs, by_seed, train_loss, zero_dropout
@@ -385,7 +386,7 @@ def test_bdetr_train_golden_at_the_bench_size(backend):
                            class_embeddings_path="/nonexistent/class_embeddings3d.npy")
     weights.fill_(model, seed=18, skip_prefixes=("text_encoder.",))
     zero_dropout(model.cuda().train())
-    inputs = cuda(bdetr_bench_inputs())
+    inputs = cuda(bdetr_bench_inputs(8))
     inputs["query_seed_inds"] = torch.from_numpy(g["query_seeds_sorted"].astype(np.int32)).cuda()
     ep = model(inputs)
     train_loss(ep).backward()
@@ -397,8 +398,8 @@ def test_bdetr_train_golden_at_the_bench_size(backend):
     for pre in PREFIXES:
         close(by_seed(ep, ep[pre + "center"]), g[pre + "center"], out_tol)
         close(by_seed(ep, ep[pre + "pred_size"]), g[pre + "pred_size"], out_tol)
-    close(by_seed(ep, ep["last_sem_cls_scores"])[:, :, :32], g["last_sem_cls_scores_head"], out_tol)
-    close(by_seed(ep, ep["last_proj_queries"]), g["last_proj_queries"], out_tol)
+    close(by_seed(ep, ep["last_sem_cls_scores"])[:, ::2, :32], g["last_sem_cls_scores_head"], out_tol)
+    close(by_seed(ep, ep["last_proj_queries"])[:, ::2], g["last_proj_queries"], out_tol)
     close(model.backbone_net.sa2.mlp_module.layer1.bn.bn.running_mean, g["running_mean_sa2_l1"], out_tol)
     p = dict(model.named_parameters())
     worst = {}
