@@ -56,9 +56,15 @@ def run(skip_fps, skip_text, reps=30, prio=None, variant=None):
     a.record()
     h0 = time.perf_counter()
     per = []
+    extra = os.environ.get("EXTRA_EAGER", "0")
+    probe = torch.zeros(512, dtype=torch.int64, device=dev)
     for it in range(reps):
         c0 = time.perf_counter()
         step(batches[it % 4][0], batches[it % 4][1], next_inputs=batches[(it + 1) % 4][0])
+        if extra == "clone":
+            keep_alive = probe.clone()
+        elif extra == "add":
+            probe.add_(1)
         per.append(time.perf_counter() - c0)
     h1 = time.perf_counter()
     b.record(); torch.cuda.synchronize()
