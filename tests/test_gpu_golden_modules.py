@@ -234,10 +234,11 @@ def test_backbone_golden(mode):
     # weight gradients through up to 14 batch-norm layers: the GPU reduces the batch statistics in a
     # different order than the CPU reference run, so the deepest ones get a looser (1e-2) bound; observed in train mode:
     # max-pool winners that flip between near-equal candidates put a few elements beyond 1e-2 (profiles/r06_golden_errors.json:
-    # none in three of the tensors, 0.006 % of sa3's at <= 1.3e-2, 0.065 % of fp2's at <= 4.4e-2; means 0.5-2.2e-3): the
-    # budgets are twice the observed shares, the outliers' bound ~2x the largest one seen
+    # none in three of the tensors, 0.006 % of sa3's at <= 1.3e-2, 0.065 % of fp2's at <= 4.4e-2; means 0.5-2.2e-3).  The count
+    # moves from run to run with the arrival order of the float atomics (sa3's: 2 of 32 768 in four runs, 5 in a fifth): the
+    # budgets are 0.05 % (16 elements of sa3's) resp. twice fp2's observed share, the outliers' bound ~2x the largest one seen
     gtol = 1e-2 if mode == "train" else BACKBONE_EVAL_GRAD_TOL
-    frac, frac_fp2, omax = (1.5e-4, 1.3e-3, 0.1) if mode == "train" else (0.0, 0.0, 0.2)
+    frac, frac_fp2, omax = (5e-4, 1.3e-3, 0.1) if mode == "train" else (0.0, 0.0, 0.2)
     close(p["sa1.mlp_module.layer0.conv.weight"].grad, g["g_sa1_layer0_conv"], gtol, frac, omax)
     close(p["sa3.mlp_module.layer2.conv.weight"].grad, g["g_sa3_layer2_conv"], gtol, frac, omax)
     close(p["sa2.mlp_module.layer1.bn.bn.weight"].grad, g["g_sa2_layer1_bn_weight"], gtol, frac, omax)
