@@ -583,6 +583,29 @@ def encoder6_row(args, device, criterion, batches):
             "final_loss": round(float(loss), 4)}
 
 
+def torch_backend_row(args, device, criterion, batches):
+    """What a straightforward PyTorch-ROCm port runs at on the same GPU, as an EXTRA row: the same model, criterion, batches and
+    hipGraph step with ``--backend torch`` -- every attention / FFN / set-abstraction / Conv+BN block as stock torch ops
+    (rocBLAS / hipBLASLt / MIOpen / ATen kernels), only the nine index ops of pointnet2._ext (which have no stock
+    counterpart) and the device-side assignment from this library.  The closest thing to "the reference on MI355X" that
+    can run here: the reference's own CUDA extension cannot be built."""
+    from butd_detr_amd import attention_blocks
+    from butd_detr_amd.train_step import FlatAdamW
+    prev_backend, prev_strict = attention_blocks.get_backend(), attention_blocks.set_strict(False)
+    ns = argparse.Namespace(**vars(args))
+    ns.backend = "torch"
+    ns.steps = max(4, args.steps // 3)
+    try:
+        model, _ = build_model(ns, device)                 # (sets the backend to "torch")
+        dt, loss = _time_recaptured(ns, model, FlatAdamW(model), criterion, batches, warm=3)
+    finally:
+        attention_blocks.set_backend(prev_backend)
+        attention_blocks.set_strict(prev_strict)
+    return {"value": round(args.batch * ns.steps / dt, 3), "unit": "scenes/s", "ms_per_step": round(dt / ns.steps * 1e3, 3),
+            "attention_backend": "torch", "steps": ns.steps, "final_loss": round(float(loss), 4),
+            "note": "stock torch ops for every block + this library's index ops and assignment, same hipGraph step"}
+
+
 def in_situ_row(args, model, opt, criterion, batches, gemm, sa_lin):
     """What the kernels achieve INSIDE the step (the stand-alone microbenchmarks of one site are the best case):
     * attention core over ALL sites of the step, from the roofline child's trace: the flops of every attention call
@@ -833,6 +856,7 @@ def main():
             if args.encoder_layers != 6:
                 out["encoder6_operating_point"] = encoder6_row(args, device, criterion, batches)
             out["batch24_operating_point"] = batch24_row(args, model, opt, criterion, device)
+            out["torch_backend_operating_point"] = torch_backend_row(args, device, criterion, batches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_scenes)
         _flush_c_stdio()
