@@ -135,6 +135,60 @@ def run_case(ref, name, weights, use_contrastive, **shape):
     print(name, "loss", float(loss), "->", path, os.path.getsize(path) // 1024, "KiB")
 
 
+BENCH_SHAPE = dict(B=8, Q=256, G=132, C=256, L=80, D=64, K=1024, N=50000, layers=6, topk=4, seed=5,
+                   n_valid=[1, 16, 5, 132, 66, 9, 3, 12])
+
+
+def run_bench_case(ref):
+    """The criterion at the bench's size (8 scenes x 256 queries x 7 prefixes, 132 target slots holding 1 .. 132 targets,
+    256 token classes, 1024 seeds of 50 000 points) with the training run's matcher weights: losses, the assignment of every
+    prefix and the gradients w.r.t. every prediction.  The inputs are NOT stored (47 MB): the test regenerates them with
+    make_inputs(**BENCH_SHAPE) (torch's CPU generator is deterministic); the gradients are stored as every 8th row."""
+    weights = (1, 0, 2)
+    ep, prefixes = make_inputs(**BENCH_SHAPE)
+    leaves = {}
+    for k, v in ep.items():
+        if torch.is_tensor(v) and v.dtype == torch.float32 and any(
+                k.endswith(s) for s in ("center", "pred_size", "sem_cls_scores", "proj_queries")) or k in (
+                "proj_tokens", "seeds_obj_cls_logits"):
+            ep[k] = v.clone().requires_grad_(True)
+            leaves[k] = ep[k]
+    matcher = ref.HungarianMatcher(*weights, True)
+    crit = ref.SetCriterion(matcher=matcher, losses=["boxes", "labels", "contrastive_align"], eos_coef=0.1, temperature=0.07)
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:29581", rank=0, world_size=1)
+    inputs = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in ep.items()}
+    loss, out = ref.compute_hungarian_loss(dict(ep), BENCH_SHAPE["layers"], crit, BENCH_SHAPE["topk"])
+    loss.backward()
+    save = {}
+    for k in ("loss", "loss_ce", "loss_bbox", "loss_giou", "query_points_generation_loss", "loss_constrastive_align"):
+        save["out_" + k] = np.asarray(float(out[k]), dtype=np.float64)
+    for p in prefixes:
+        for key in ("loss_ce", "loss_bbox", "loss_giou", "loss_contrastive_align"):
+            if f"{p}_{key}" in out:
+                save[f"out_{p}_{key}"] = np.asarray(float(out[f"{p}_{key}"]), dtype=np.float64)
+    B, G = inputs["box_label_mask"].shape
+    match = -np.ones((len(prefixes), B, G), dtype=np.int32)
+    tgt = [{"labels": inputs["sem_cls_label"][b, inputs["box_label_mask"][b].bool()],
+            "boxes": torch.cat([inputs["center_label"], inputs["size_gts"]], -1)[b, inputs["box_label_mask"][b].bool()],
+            "positive_map": inputs["positive_map"][b, inputs["box_label_mask"][b].bool()]} for b in range(B)]
+    for i, p in enumerate(prefixes):
+        o = {"pred_logits": inputs[f"{p}sem_cls_scores"],
+             "pred_boxes": torch.cat([inputs[f"{p}center"], inputs[f"{p}pred_size"]], -1)}
+        for b, (qi, ti) in enumerate(matcher(o, tgt)):
+            slots = torch.nonzero(inputs["box_label_mask"][b]).flatten()
+            match[i, b, slots[ti].numpy()] = qi.numpy()
+    save["out_match"] = match
+    for k, v in leaves.items():
+        gk = v.grad if v.grad is not None else torch.zeros_like(v)
+        save["grad8_" + k] = (gk[:, ::8] if gk.dim() == 3 and gk.shape[1] >= 64 else gk).numpy()
+        save["gradsum_" + k] = np.asarray(float(gk.double().abs().sum()))
+    path = os.path.join(HERE, "criterion_bench_size.npz")
+    np.savez_compressed(path, **save)
+    print("bench size: loss", float(loss), "->", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     if not os.path.exists(REF):
         sys.exit("the reference is not mounted here")
@@ -144,7 +198,11 @@ def main():
     run_case(ref, "default_weights", (1, 5, 2), True, seed=2, n_valid=[5, 2, 6], **base)
     run_case(ref, "no_contrastive", (1, 0, 2), False, seed=3, n_valid=[4, 4, 2], **base)
     run_case(ref, "empty_scene", (1, 5, 2), True, seed=4, n_valid=[0, 3, 5], **base)
+    run_bench_case(ref)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["bench_size"]:
+        run_bench_case(load_reference())
+    else:
+        main()

@@ -101,6 +101,21 @@ def test_criterion_on_gpu_reproduces_the_reference(path):
         np.testing.assert_allclose(got, want, rtol=1e-3, atol=1e-6 + 1e-3 * np.abs(want).max(), err_msg=name)
 
 
+def test_criterion_at_the_bench_size_reproduces_the_reference():
+    """8 scenes x 256 queries x 7 prefixes, 1 .. 132 targets per scene, 256 token classes, 1024 seeds of 50 000 points
+    (tests/golden/criterion_bench_size.npz, inputs regenerated from the reference run's seed): the device-side assignment
+    of all 56 problems equals the reference's (scipy), every loss term and the gradients w.r.t. every prediction follow."""
+    from butd_detr_amd import losses as L
+    from tests.test_losses_cpu import bench_size_case, check_bench_size_grads
+    z, ep, leaves, crit, shape = bench_size_case("cuda")
+    loss, out = L.compute_hungarian_loss(ep, shape["layers"], crit, shape["topk"])
+    np.testing.assert_array_equal(out["hungarian_match"].cpu().numpy(), z["out_match"])
+    check_outputs(z, {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in out.items() if k != "tokenized"},
+                  L.hungarian_prefixes(shape["layers"]), tol=5e-5)
+    loss.backward()
+    check_bench_size_grads(z, leaves, 1e-3)
+
+
 def test_a_failed_assignment_makes_the_loss_nan():
     """Where scipy would raise (matcher.py:105: NaN costs) the device solver sets its status word; the criterion
     turns that into a NaN loss so that a graph replay cannot train on a silently wrong match."""

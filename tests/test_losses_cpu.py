@@ -110,3 +110,42 @@ def test_box_helpers():
     g = L.generalized_box_iou3d(corners, corners)
     assert torch.allclose(torch.diag(g), torch.ones(2))
     assert g[0, 1] < 0      # disjoint boxes: negative GIoU
+
+
+def bench_size_case(device="cpu"):
+    """The bench-size criterion case (tests/golden/criterion_bench_size.npz): its inputs are regenerated from the seed the
+    reference run used (make_losses_golden.BENCH_SHAPE), only the reference's outputs are stored."""
+    from tests.golden.make_losses_golden import BENCH_SHAPE, make_inputs
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "criterion_bench_size.npz"))
+    ep, _ = make_inputs(**BENCH_SHAPE)
+    leaves = {}
+    for k, v in list(ep.items()):
+        if k == "tokenized":
+            ep[k] = {"attention_mask": v["attention_mask"].to(device)}
+            continue
+        t = v.to(device)
+        if ("grad8_" + k) in z.files:
+            t = t.clone().requires_grad_(True)
+            leaves[k] = t
+        ep[k] = t
+    crit = L.SetCriterion(L.HungarianMatcher(1, 0, 2, True), losses=["boxes", "labels", "contrastive_align"], eos_coef=0.1,
+                          temperature=0.07)
+    return z, ep, leaves, crit, BENCH_SHAPE
+
+
+def check_bench_size_grads(z, leaves, rtol):
+    for name, t in leaves.items():
+        g = t.grad if t.grad is not None else torch.zeros_like(t)
+        want = z["grad8_" + name]
+        got = (g[:, ::8] if g.dim() == 3 and g.shape[1] >= 64 else g).detach().cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=rtol, atol=1e-7 + rtol * np.abs(want).max(), err_msg=name)
+        total = float(g.detach().double().abs().sum())
+        np.testing.assert_allclose(total, float(z["gradsum_" + name]), rtol=10 * rtol, err_msg=name + " (sum of |grad|)")
+
+
+def test_dense_criterion_at_the_bench_size_given_the_reference_assignment():
+    z, ep, leaves, crit, shape = bench_size_case()
+    loss, out = L.compute_hungarian_loss(ep, shape["layers"], crit, shape["topk"], match=torch.from_numpy(z["out_match"]))
+    check_outputs(z, out, L.hungarian_prefixes(shape["layers"]), tol=5e-5)
+    loss.backward()
+    check_bench_size_grads(z, leaves, 1e-4)
